@@ -1,0 +1,183 @@
+/*
+ * ripor_hip.h — C ABI of libripor_hip.so: the MI355X (gfx950) trie-constrained beam-search
+ * generative-retrieval hot path.
+ *
+ * The reference (HansiZeng/RIPOR) has no FFI layer: its boundary for this path is the Python call
+ *   generate_for_constrained_prefix_beam_search(model, prefix_constrain_processor, input_ids,
+ *       attention_mask, max_new_tokens=L, num_beams=B, num_return_sequences=B, ...)
+ *   (reference t5_pretrainer/tasks/generation.py:35-78; callers t5_pretrainer/evaluate.py:60,102,149)
+ * plus the constructors T5SeqAQEncoder.from_pretrained (modeling/t5_generative_retriever.py:772-855)
+ * and PrefixConstrainLogitProcessorFastSparse (tasks/generation.py:603-642).
+ * Each entry point below names the reference interface it replaces. The Python mirror of those
+ * interfaces (ripor_amd/tasks/generation.py, ripor_amd/modeling/t5_generative_retriever.py)
+ * binds these symbols with ctypes (ripor_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative rpr_status; nothing throws
+ * across the ABI; rpr_last_error() returns a human-readable message for the last failure on the
+ * calling thread. All tensor arguments are plain pointers + sizes. Pointers marked [dev] are HIP
+ * device pointers (e.g. torch tensor .data_ptr()), [host] are host pointers. Caller owns every
+ * in/out buffer; the library owns its workspaces, KV cache and hipGraphs. One rpr_ctx per device,
+ * not thread-safe per ctx. `stream` is a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef RIPOR_HIP_H
+#define RIPOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RPR_OK = 0,
+  RPR_ERR_INVALID = -1,  /* bad argument / unsupported configuration */
+  RPR_ERR_HIP = -2,      /* a HIP runtime call failed */
+  RPR_ERR_NO_DEVICE = -3,
+  RPR_ERR_OOM = -4
+} rpr_status;
+
+typedef struct rpr_ctx rpr_ctx;
+typedef struct rpr_model rpr_model;
+typedef struct rpr_trie rpr_trie;
+
+/* Weights of a T5ForDocIDGeneration checkpoint (reference modeling/t5_generative_retriever.py:84-112;
+ * SURVEY.md §8 row a14). All matrices are float32, row-major [out_features, in_features] exactly
+ * as torch.nn.Linear stores them; q/k/v of one attention are concatenated along out_features by
+ * the host (rows 0..inner-1 = q, then k, then v). Per-layer pointers are host arrays of device
+ * pointers with num_layers / num_decoder_layers entries. */
+typedef struct {
+  int32_t vocab_size, d_model, d_kv, d_ff, num_heads;
+  int32_t num_layers, num_decoder_layers;
+  int32_t rel_buckets, rel_max_distance;
+  int32_t L;                     /* len(config.decoder_vocab_sizes) = max decoder positions      */
+  int32_t V;                     /* decoder_vocab_sizes[i], must be equal for all i (evaluate.py:433) */
+  int32_t scaleup_output_hidden; /* config.scaleup_output_hidden (t5_generative_retriever.py:427)  */
+  float layer_norm_eps;
+  const float* shared;           /* [dev] shared.weight [vocab_size, d_model]                     */
+  const float* enc_rel_bias;     /* [dev] encoder.block.0...relative_attention_bias [buckets, H]   */
+  const float* dec_rel_bias;     /* [dev] decoder.block.0...relative_attention_bias [buckets, H]   */
+  const float* enc_final_ln;     /* [dev] [d_model] */
+  const float* dec_final_ln;     /* [dev] [d_model] */
+  const float* start_embed;      /* [dev] start_token_embed [d_model]                             */
+  const float* in_embeds;        /* [dev] list_decoder_embeds stacked [L, V, d_model]              */
+  const float* out_embeds;       /* [dev] list_output_embeds stacked [L, V, d_model] (== in_embeds if shared) */
+  const float* dec_xkv;          /* [dev] all decoder layers' EncDecAttention k,v stacked
+                                    [num_decoder_layers * 2 * inner, d_model]: layer i rows
+                                    [2i*inner, (2i+1)*inner) = k, next inner rows = v               */
+  const float* const* enc_ln0;   /* [host][num_layers] -> [dev] layer.0.layer_norm [d_model]       */
+  const float* const* enc_qkv;   /*                    -> [dev] [3*inner, d_model]                 */
+  const float* const* enc_o;     /*                    -> [dev] [d_model, inner]                   */
+  const float* const* enc_ln1;
+  const float* const* enc_wi;    /* [d_ff, d_model] */
+  const float* const* enc_wo;    /* [d_model, d_ff] */
+  const float* const* dec_ln0;   /* [host][num_decoder_layers] */
+  const float* const* dec_qkv;   /* SelfAttention [3*inner, d_model] */
+  const float* const* dec_o;
+  const float* const* dec_ln1;
+  const float* const* dec_xq;    /* EncDecAttention.q [inner, d_model] */
+  const float* const* dec_xo;    /* EncDecAttention.o [d_model, inner] */
+  const float* const* dec_ln2;
+  const float* const* dec_wi;
+  const float* const* dec_wo;
+} rpr_model_desc;
+
+/* rpr_search flags */
+#define RPR_FLAG_LOG_SOFTMAX 1u /* apply_log_softmax_for_scores (generation.py:453-455)           */
+#define RPR_FLAG_NO_GRAPH 2u    /* launch kernels eagerly instead of replaying a hipGraph           */
+
+/* Optional per-step taps for parity tests (all [dev], any may be NULL). */
+typedef struct {
+  float* encoder_out;   /* [Q, Lq, d_model] final encoder hidden states                            */
+  float* step_logits;   /* [L, Q*B, V] logits of position t for the beams alive at step t           */
+  double* step_scores;  /* [L, Q, B] cumulative float64 beam scores after step t (slot order)        */
+  int32_t* step_tokens; /* [L, Q, B] token chosen for each new slot at step t                       */
+  int32_t* step_parent; /* [L, Q, B] parent slot of each new slot at step t                         */
+} rpr_debug_taps;
+
+/* Timing of one kernel class, accumulated with hipEvents on the launch stream while
+ * profiling is enabled (bench.py's roofline leg). */
+typedef struct {
+  double total_ms;
+  int64_t launches;
+  double flops;  /* algorithmic flops of those launches */
+  double bytes;  /* algorithmic bytes of those launches */
+} rpr_kernel_stats;
+
+enum { RPR_K_GEMM = 0, RPR_K_DEC_SELF_ATTN = 1, RPR_K_DEC_CROSS_ATTN = 2, RPR_K_ENC_ATTN = 3,
+       RPR_K_RMSNORM = 4, RPR_K_SELECT = 5, RPR_K_OTHER = 6, RPR_K_COUNT = 7 };
+
+/* ---- lifecycle (replaces: model.to(local_rank), evaluate.py:470; ddp_setup device binding) ---- */
+int rpr_init(int device, rpr_ctx** out_ctx);
+void rpr_free_ctx(rpr_ctx* ctx);
+const char* rpr_last_error(void);
+/* Library/ABI version; bumped when a signature changes. */
+int rpr_abi_version(void);
+
+/* Host-only: HF T5Attention._relative_position_bucket evaluated the way the library fills its
+ * device lookup tables (float32 log, truncation); rel = key_pos - query_pos. Needs no GPU. */
+int rpr_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance);
+
+/* ---- model (replaces T5SeqAQEncoder.from_pretrained(...).base_model, t5_generative_retriever.py:772-784) ---- */
+int rpr_load_model(rpr_ctx* ctx, const rpr_model_desc* desc, rpr_model** out_model);
+void rpr_free_model(rpr_model* model);
+
+/* ---- trie (replaces list_smtid_to_nextids + PrefixConstrainLogitProcessorFastSparse(list, V),
+ *      evaluate.py:404-434, generation.py:603-642, and smtid_to_docids, evaluate.py:439-446) ----
+ * codes: [host] [N, L] row-major, codes[i*L + l] in [0, V); row i is the smtid of docid index i.
+ * The library sorts the rows lexicographically (stable), keeps the sorted matrix on the device and
+ * the permutation on the host. A beam's trie node is the half-open range [lo, hi) of sorted rows
+ * sharing its prefix; the docids under a final smtid are perm[lo..hi). */
+int rpr_build_trie(rpr_ctx* ctx, const uint16_t* codes, int64_t N, int32_t L, int32_t V, rpr_trie** out_trie);
+void rpr_free_trie(rpr_trie* trie);
+int64_t rpr_trie_num_rows(const rpr_trie* trie);
+/* [host] perm[N]: perm[sorted_row] = original row index (docid index). Valid until rpr_free_trie. */
+const int64_t* rpr_trie_perm(const rpr_trie* trie);
+/* Binary trie cache replacing list_smtid_to_nextids.pkl (evaluate.py:404-408,428-432). */
+int rpr_trie_save(const rpr_trie* trie, const char* path);
+int rpr_trie_load(rpr_ctx* ctx, const char* path, rpr_trie** out_trie);
+/* Host-side child mask of arbitrary prefixes — the processor's __call__ (generation.py:666-677)
+ * without a model, for processor-only parity tests. prefix: [host] [R, T] with column 0 ignored
+ * (start id); out_mask: [host] [R, V] bytes 0/1. Runs the device kernel used by the search. */
+int rpr_trie_mask(rpr_ctx* ctx, const rpr_trie* trie, const int32_t* prefix, int32_t R, int32_t T,
+                  uint8_t* out_mask);
+
+/* ---- the hot path (replaces generate_for_constrained_prefix_beam_search, generation.py:35-251,
+ *      -> beam_search_for_constrained_prefix :253-575 incl. BeamSearchScorer.process/finalize) ----
+ * input_ids, attention_mask: [dev] int32 [Q, Lq] (pad id 0 / mask 0 on padding, any Lq <= 256).
+ * out_tokens: [dev] int32 [Q, B, L] generated smtid tokens, beams ranked best-first per query
+ *             (= outputs.sequences[:, 1:] of the reference, which prepends the start id 0).
+ * out_scores: [dev] float32 [Q, B] = float32(sum of step scores (float64) / (L+1))
+ *             (= outputs.sequences_scores).
+ * out_row_lo/out_row_hi: [dev] int64 [Q, B] sorted-row range of each returned smtid (empty range:
+ *             the smtid is not in the trie; the reference prints "smtid not in smtid_to_docid").
+ * L may be smaller than the model's decoder length (prefix search, evaluate.py:134-178). */
+int rpr_search(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, const int32_t* input_ids,
+               const int32_t* attention_mask, int32_t Q, int32_t Lq, int32_t B, int32_t L, uint32_t flags,
+               int32_t* out_tokens, float* out_scores, int64_t* out_row_lo, int64_t* out_row_hi,
+               const rpr_debug_taps* taps, void* stream);
+
+/* ---- measurement ---- */
+/* Enable/disable per-kernel-class hipEvent timing (forces eager launches while enabled). */
+int rpr_profile_enable(rpr_ctx* ctx, int enable);
+int rpr_profile_reset(rpr_ctx* ctx);
+/* Synchronises the recorded events and returns the accumulated statistics for one class. */
+int rpr_profile_get(rpr_ctx* ctx, int kernel_class, rpr_kernel_stats* out);
+/* Bytes of device memory the ctx currently holds for workspaces + KV cache. */
+int64_t rpr_workspace_bytes(const rpr_ctx* ctx);
+
+/* ---- single-operator entry points (kernel-level parity tests; same kernels the search uses) ---- */
+/* C[M,N] = act(A[M,K] @ W[N,K]^T) (+ residual[M,N]); fp32 MFMA. K % 32 == 0, N % 32 == 0. */
+int rpr_op_linear(rpr_ctx* ctx, const float* A, const float* W, const float* residual, float* C,
+                  int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
+/* out[rows,d] = w * x * rsqrt(mean(x^2) + eps) */
+int rpr_op_rmsnorm(rpr_ctx* ctx, const float* x, const float* w, float* out, int32_t rows, int32_t d,
+                   float eps, void* stream);
+/* Encoder forward only (reference generation.py:132-137): out [Q, Lq, d_model]. */
+int rpr_encode(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask,
+               int32_t Q, int32_t Lq, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIPOR_HIP_H */

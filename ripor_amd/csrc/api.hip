@@ -1,0 +1,612 @@
+// C-ABI of libripor_hip.so (see include/ripor_hip.h): context, model binding, trie, and the
+// orchestration of one constrained beam search = T5 encoder once + L KV-cached decoder steps, each
+// fused with the trie mask / top-B / beam expand, all enqueued on one HIP stream and replayed as a
+// hipGraph (no host synchronisation inside the search; the reference syncs >= 1 + 2*B*Q times per
+// step).
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "trie.h"
+
+namespace rpr {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_err = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what + " at " +
+          file + ":" + std::to_string(line);
+  (void)hipGetLastError();
+  return e == hipErrorOutOfMemory ? RPR_ERR_OOM : RPR_ERR_HIP;
+}
+
+// HF T5Attention._relative_position_bucket in float32 (log in float32, truncation toward zero);
+// rel = key_pos - query_pos. Pinned against the torch expression in tests/test_host_logic.py.
+int rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
+  int bucket = 0, n;
+  if (bidirectional) {
+    num_buckets /= 2;
+    if (rel > 0) bucket += num_buckets;
+    n = rel < 0 ? -rel : rel;
+  } else {
+    n = rel < 0 ? -rel : 0;
+  }
+  const int max_exact = num_buckets / 2;
+  if (n < max_exact) return bucket + n;
+  const float v = logf((float)n / (float)max_exact) / (float)log((double)max_distance / (double)max_exact) *
+                  (float)(num_buckets - max_exact);
+  int large = max_exact + (int)v;
+  if (large > num_buckets - 1) large = num_buckets - 1;
+  return bucket + large;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace rpr
+
+using namespace rpr;
+
+struct rpr_model {
+  rpr_ctx* ctx;
+  rpr_model_desc d;
+  std::vector<const float*> enc_ln0, enc_qkv, enc_o, enc_ln1, enc_wi, enc_wo;
+  std::vector<const float*> dec_ln0, dec_qkv, dec_o, dec_ln1, dec_xq, dec_xo, dec_ln2, dec_wi, dec_wo;
+  int32_t* enc_bucket = nullptr;  // [2*MAX_LQ-1]
+  int32_t* dec_bucket = nullptr;  // [MAX_DEC_LEN]
+  int inner() const { return d.num_heads * d.d_kv; }
+};
+
+struct rpr_trie {
+  rpr_ctx* ctx;
+  int64_t N;
+  int L, V;
+  uint16_t* codes = nullptr;  // [dev] sorted [N, L]
+  std::vector<int64_t> perm;
+  std::vector<uint16_t> host_sorted;
+};
+
+struct GraphKey {
+  const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(m, t, Q, Lq, B, L, flags) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags);
+  }
+};
+
+struct Workspace {
+  // encoder
+  DevBuf ids, mask, ex, eh, eqkv, eattn, eff, enc_out, xkv;
+  // decoder
+  DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
+  // beam state (2 ping-pong buffers)
+  DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
+  // staged outputs
+  DevBuf o_tokens, o_scores, o_lo, o_hi;
+};
+
+struct rpr_ctx {
+  int device;
+  Workspace ws;
+  size_t ws_bytes = 0;
+  hipStream_t cap_stream = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  // profiling
+  bool profiling = false;
+  struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  rpr_kernel_stats done[RPR_K_COUNT];
+};
+
+namespace {
+
+int ensure(rpr_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    RPR_HIP(hipFree(b.p));
+    c->ws_bytes -= b.cap;
+    b.p = nullptr; b.cap = 0;
+    // graphs captured against the old pointers are stale
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+  }
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  RPR_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  c->ws_bytes += want;
+  return 0;
+}
+
+template <class T> T* P(const DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+// Launch wrapper: optional hipEvent timing per kernel class (bench.py roofline leg).
+struct Launcher {
+  rpr_ctx* c;
+  hipStream_t s;
+  int err = 0;
+  hipEvent_t get_event() {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  template <class F> void run(int cls, double flops, double bytes, F&& f) {
+    if (err) return;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (c->profiling) {
+      ea = get_event(); eb = get_event();
+      if (ea) (void)hipEventRecord(ea, s);
+    }
+    hipError_t e = f();
+    if (e != hipSuccess) { err = hip_fail(e, "kernel launch", __FILE__, __LINE__); return; }
+    if (c->profiling && ea && eb) {
+      (void)hipEventRecord(eb, s);
+      c->recs.push_back({cls, ea, eb, flops, bytes});
+    }
+  }
+};
+
+void gemm(Launcher& L, const float* A, int lda, const float* W, int N, int K, int M, const float* resid,
+          float* out, int ldo, int relu) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.resid = resid; g.ldr = ldo;
+  g.out[0] = out; g.out[1] = out; g.out[2] = out; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldo;
+  g.split_n = N; g.M = M; g.N = N; g.K = K; g.relu = relu;
+  const double fl = 2.0 * M * (double)N * K;
+  const double by = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (resid ? 2 : 1));
+  hipStream_t s = L.s;
+  L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
+}
+
+int flush_profile(rpr_ctx* c) {
+  for (auto& r : c->recs) {
+    RPR_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    RPR_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    auto& d = c->done[r.cls];
+    d.total_ms += ms; d.launches += 1; d.flops += r.flops; d.bytes += r.bytes;
+    c->pool.push_back(r.a); c->pool.push_back(r.b);
+  }
+  c->recs.clear();
+  return 0;
+}
+
+int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L) {
+  const auto& d = m->d;
+  const size_t T = (size_t)Q * Lq, R = (size_t)Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
+  const size_t nd = d.num_decoder_layers, f = sizeof(float);
+  Workspace& w = c->ws;
+  int e = 0;
+  auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = ensure(c, b, bytes); };
+  E(w.ids, T * 4); E(w.mask, T * 4);
+  E(w.ex, T * dm * f); E(w.eh, T * dm * f); E(w.eqkv, T * 3 * inner * f); E(w.eattn, T * inner * f);
+  E(w.eff, T * dff * f); E(w.enc_out, T * dm * f); E(w.xkv, T * nd * 2 * inner * f);
+  E(w.x, R * dm * f); E(w.h, R * dm * f); E(w.q, R * inner * f); E(w.attn, R * inner * f);
+  E(w.ff, R * dff * f); E(w.logits, R * (size_t)d.V * f);
+  E(w.kcache, nd * L * R * inner * f); E(w.vcache, nd * L * R * inner * f);
+  E(w.lb, R * (size_t)d.V * 4);
+  for (int i = 0; i < 2; ++i) {
+    E(w.score[i], R * 8); E(w.lo[i], R * 4); E(w.hi[i], R * 4);
+    E(w.tokens[i], R * (size_t)L * 2); E(w.anc[i], R * (size_t)L * 2);
+  }
+  E(w.o_tokens, R * (size_t)L * 4); E(w.o_scores, R * 4); E(w.o_lo, R * 8); E(w.o_hi, R * 8);
+  return e;
+}
+
+// Encoder forward into ws.enc_out (reference generation.py:132-137 -> model.encoder(...)).
+void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq) {
+  const auto& d = m->d;
+  Workspace& w = c->ws;
+  const int T = Q * Lq, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
+  hipStream_t s = Ln.s;
+  float *x = P<float>(w.ex), *h = P<float>(w.eh), *qkv = P<float>(w.eqkv), *attn = P<float>(w.eattn),
+        *ff = P<float>(w.eff);
+  Ln.run(RPR_K_OTHER, 0, 2.0 * T * dm * 4, [&] {
+    return launch_embed_rows(d.shared, P<int32_t>(w.ids), x, T, dm, d.vocab_size, s);
+  });
+  for (int i = 0; i < d.num_layers; ++i) {
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] { return launch_rmsnorm(x, m->enc_ln0[i], h, T, dm, d.layer_norm_eps, s); });
+    gemm(Ln, h, dm, m->enc_qkv[i], 3 * inner, dm, T, nullptr, qkv, 3 * inner, 0);
+    EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets};
+    Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV, 4.0 * T * 4 * inner,
+           [&] { return launch_enc_attn(a, s); });
+    gemm(Ln, attn, inner, m->enc_o[i], dm, inner, T, x, x, dm, 0);
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] { return launch_rmsnorm(x, m->enc_ln1[i], h, T, dm, d.layer_norm_eps, s); });
+    gemm(Ln, h, dm, m->enc_wi[i], dff, dm, T, nullptr, ff, dff, 1);
+    gemm(Ln, ff, dff, m->enc_wo[i], dm, dff, T, x, x, dm, 0);
+  }
+  Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] {
+    return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, d.layer_norm_eps, s);
+  });
+}
+
+BeamState beam_state(Workspace& w, int i, int L) {
+  BeamState st;
+  st.score = P<double>(w.score[i]); st.lo = P<int32_t>(w.lo[i]); st.hi = P<int32_t>(w.hi[i]);
+  st.tokens = P<uint16_t>(w.tokens[i]); st.anc = P<uint16_t>(w.anc[i]); st.ld = L;
+  return st;
+}
+
+// Everything between the staged inputs (ws.ids/ws.mask) and the staged outputs (ws.o_*).
+void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, int Q, int Lq, int B, int L,
+                    unsigned flags, const rpr_debug_taps* taps) {
+  const auto& d = m->d;
+  Workspace& w = c->ws;
+  const int T = Q * Lq, R = Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
+  const int nd = d.num_decoder_layers, V = d.V;
+  hipStream_t s = Ln.s;
+  enqueue_encoder(Ln, c, m, Q, Lq);
+  if (taps && taps->encoder_out && !Ln.err) {
+    hipError_t e = hipMemcpyAsync(taps->encoder_out, w.enc_out.p, (size_t)T * dm * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { Ln.err = hip_fail(e, "tap copy", __FILE__, __LINE__); return; }
+  }
+  // cross-attention K/V of every decoder layer in one GEMM (shared by the B beams of a query;
+  // the reference recomputes them for every beam at every step)
+  const int xld = nd * 2 * inner;
+  gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, xld, dm, T, nullptr, P<float>(w.xkv), xld, 0);
+
+  BeamState st0 = beam_state(w, 0, L);
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(st0, Q, B, tr->N, s); });
+
+  float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
+        *logits = P<float>(w.logits);
+  const size_t layer_stride = (size_t)L * R * inner;
+  for (int t = 0; t < L; ++t) {
+    BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
+    Ln.run(RPR_K_OTHER, 0, 2.0 * R * dm * 4, [&] {
+      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, R, dm, V, t, s);
+    });
+    for (int i = 0; i < nd; ++i) {
+      float* kc = P<float>(w.kcache) + i * layer_stride;
+      float* vc = P<float>(w.vcache) + i * layer_stride;
+      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln0[i], h, R, dm, d.layer_norm_eps, s); });
+      {  // q -> qb, k/v -> cache row block of position t
+        GemmArgs g{};
+        g.A = h; g.lda = dm; g.W = m->dec_qkv[i]; g.ldw = dm; g.resid = nullptr; g.ldr = 0;
+        g.out[0] = qb; g.out[1] = kc + (size_t)t * R * inner; g.out[2] = vc + (size_t)t * R * inner;
+        g.ldo[0] = g.ldo[1] = g.ldo[2] = inner; g.split_n = inner; g.M = R; g.N = 3 * inner; g.K = dm; g.relu = 0;
+        Ln.run(RPR_K_GEMM, 2.0 * R * 3.0 * inner * dm, 4.0 * ((double)R * dm + 3.0 * inner * dm + 3.0 * R * inner),
+               [&] { return launch_gemm(g, s); });
+      }
+      {
+        DecSelfAttnArgs a{qb, kc, vc, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t};
+        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * R * H * (double)(t + 1) * DKV,
+               4.0 * ((double)R * inner * 2 + 2.0 * R * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
+      }
+      gemm(Ln, attn, inner, m->dec_o[i], dm, inner, R, x, x, dm, 0);
+      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln1[i], h, R, dm, d.layer_norm_eps, s); });
+      gemm(Ln, h, dm, m->dec_xq[i], inner, dm, R, nullptr, qb, inner, 0);
+      {
+        const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq};
+        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * R * H * (double)Lq * DKV,
+               4.0 * ((double)R * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
+      }
+      gemm(Ln, attn, inner, m->dec_xo[i], dm, inner, R, x, x, dm, 0);
+      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln2[i], h, R, dm, d.layer_norm_eps, s); });
+      gemm(Ln, h, dm, m->dec_wi[i], dff, dm, R, nullptr, ff, dff, 1);
+      gemm(Ln, ff, dff, m->dec_wo[i], dm, dff, R, x, x, dm, 0);
+    }
+    const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] {
+      return launch_rmsnorm(x, d.dec_final_ln, h, R, dm, d.layer_norm_eps, s, post);
+    });
+    // logits of position t only (the reference computes every position and keeps [-1])
+    float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
+    gemm(Ln, h, dm, d.out_embeds + (size_t)t * V * dm, V, dm, R, nullptr, lg, V, 0);
+    SelectArgs sa{};
+    sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
+    sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
+    sa.log_softmax = (flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
+    if (taps) {
+      sa.tap_scores = taps->step_scores ? taps->step_scores + (size_t)t * R : nullptr;
+      sa.tap_tokens = taps->step_tokens ? taps->step_tokens + (size_t)t * R : nullptr;
+      sa.tap_parent = taps->step_parent ? taps->step_parent + (size_t)t * R : nullptr;
+    }
+    Ln.run(RPR_K_SELECT, 0, (double)R * V * 4 + (double)R * 40, [&] { return launch_select(sa, s); });
+  }
+  FinalizeArgs fa{beam_state(w, L & 1, L), Q, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
+                  P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_finalize(fa, s); });
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpr_abi_version(void) { return 1; }
+const char* rpr_last_error(void) { return g_err.c_str(); }
+
+int rpr_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
+  return rel_bucket(rel, bidirectional, num_buckets, max_distance);
+}
+
+int rpr_init(int device, rpr_ctx** out_ctx) {
+  RPR_REQUIRE(out_ctx != nullptr, "out_ctx is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible: libripor_hip.so has no CPU fallback");
+    return RPR_ERR_NO_DEVICE;
+  }
+  RPR_REQUIRE(device >= 0 && device < n, "device index out of range");
+  RPR_HIP(hipSetDevice(device));
+  RPR_HIP(init_t5_kernel_attributes());
+  RPR_HIP(init_beam_kernel_attributes());
+  auto* c = new rpr_ctx();
+  c->device = device;
+  std::memset(c->done, 0, sizeof(c->done));
+  hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+  *out_ctx = c;
+  return RPR_OK;
+}
+
+void rpr_free_ctx(rpr_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+  Workspace& w = c->ws;
+  DevBuf* all[] = {&w.ids, &w.mask, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
+                   &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
+                   &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
+                   &w.o_scores, &w.o_lo, &w.o_hi};
+  for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  delete c;
+}
+
+int64_t rpr_workspace_bytes(const rpr_ctx* c) { return c ? (int64_t)c->ws_bytes : 0; }
+
+int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
+  RPR_REQUIRE(c && d && out, "NULL argument");
+  RPR_REQUIRE(d->d_kv == DKV, "only d_kv == 64 is supported (t5-base / t5-large)");
+  RPR_REQUIRE(d->d_model % 32 == 0 && d->d_ff % 32 == 0, "d_model and d_ff must be multiples of 32");
+  RPR_REQUIRE(d->V % 64 == 0 && d->V <= 65536, "decoder vocab size must be a multiple of 64 and <= 65536");
+  RPR_REQUIRE(d->L >= 1 && d->L <= MAX_DEC_LEN, "decoder length out of range");
+  RPR_REQUIRE(d->rel_buckets >= 2 && d->rel_buckets <= 64, "relative_attention_num_buckets out of range");
+  RPR_REQUIRE(d->num_layers >= 1 && d->num_decoder_layers >= 1 && d->num_heads >= 1, "bad layer/head count");
+  RPR_REQUIRE(d->shared && d->enc_rel_bias && d->dec_rel_bias && d->enc_final_ln && d->dec_final_ln &&
+                  d->start_embed && d->in_embeds && d->out_embeds && d->dec_xkv, "NULL weight pointer");
+  RPR_HIP(hipSetDevice(c->device));
+  auto m = std::make_unique<rpr_model>();
+  m->ctx = c;
+  m->d = *d;
+  auto copyv = [](std::vector<const float*>& v, const float* const* src, int n) -> bool {
+    if (!src) return false;
+    v.assign(src, src + n);
+    for (auto p : v) if (!p) return false;
+    return true;
+  };
+  bool ok = copyv(m->enc_ln0, d->enc_ln0, d->num_layers) && copyv(m->enc_qkv, d->enc_qkv, d->num_layers) &&
+            copyv(m->enc_o, d->enc_o, d->num_layers) && copyv(m->enc_ln1, d->enc_ln1, d->num_layers) &&
+            copyv(m->enc_wi, d->enc_wi, d->num_layers) && copyv(m->enc_wo, d->enc_wo, d->num_layers);
+  const int nd = d->num_decoder_layers;
+  ok = ok && copyv(m->dec_ln0, d->dec_ln0, nd) && copyv(m->dec_qkv, d->dec_qkv, nd) && copyv(m->dec_o, d->dec_o, nd) &&
+       copyv(m->dec_ln1, d->dec_ln1, nd) && copyv(m->dec_xq, d->dec_xq, nd) && copyv(m->dec_xo, d->dec_xo, nd) &&
+       copyv(m->dec_ln2, d->dec_ln2, nd) && copyv(m->dec_wi, d->dec_wi, nd) && copyv(m->dec_wo, d->dec_wo, nd);
+  RPR_REQUIRE(ok, "NULL per-layer weight pointer");
+  // the desc's host arrays need not outlive this call
+  m->d.enc_ln0 = m->d.enc_qkv = m->d.enc_o = m->d.enc_ln1 = m->d.enc_wi = m->d.enc_wo = nullptr;
+  m->d.dec_ln0 = m->d.dec_qkv = m->d.dec_o = m->d.dec_ln1 = m->d.dec_xq = m->d.dec_xo = nullptr;
+  m->d.dec_ln2 = m->d.dec_wi = m->d.dec_wo = nullptr;
+  std::vector<int32_t> eb(2 * MAX_LQ - 1), db(MAX_DEC_LEN);
+  for (int rel = -(MAX_LQ - 1); rel <= MAX_LQ - 1; ++rel)
+    eb[rel + MAX_LQ - 1] = rel_bucket(rel, 1, d->rel_buckets, d->rel_max_distance);
+  for (int n = 0; n < MAX_DEC_LEN; ++n) db[n] = rel_bucket(-n, 0, d->rel_buckets, d->rel_max_distance);
+  RPR_HIP(hipMalloc(&m->enc_bucket, eb.size() * 4));
+  RPR_HIP(hipMalloc(&m->dec_bucket, db.size() * 4));
+  RPR_HIP(hipMemcpy(m->enc_bucket, eb.data(), eb.size() * 4, hipMemcpyHostToDevice));
+  RPR_HIP(hipMemcpy(m->dec_bucket, db.data(), db.size() * 4, hipMemcpyHostToDevice));
+  *out = m.release();
+  return RPR_OK;
+}
+
+void rpr_free_model(rpr_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipDeviceSynchronize();
+  // graphs that reference this model's tables are dropped
+  for (auto it = m->ctx->graphs.begin(); it != m->ctx->graphs.end();) {
+    if (it->first.m == m) { (void)hipGraphExecDestroy(it->second); it = m->ctx->graphs.erase(it); } else ++it;
+  }
+  if (m->enc_bucket) (void)hipFree(m->enc_bucket);
+  if (m->dec_bucket) (void)hipFree(m->dec_bucket);
+  delete m;
+}
+
+static int upload_trie(rpr_ctx* c, std::unique_ptr<rpr_trie>& t) {
+  RPR_HIP(hipSetDevice(c->device));
+  RPR_HIP(hipMalloc(&t->codes, t->host_sorted.size() * sizeof(uint16_t)));
+  RPR_HIP(hipMemcpy(t->codes, t->host_sorted.data(), t->host_sorted.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  return RPR_OK;
+}
+
+int rpr_build_trie(rpr_ctx* c, const uint16_t* codes, int64_t N, int32_t L, int32_t V, rpr_trie** out) {
+  RPR_REQUIRE(c && codes && out, "NULL argument");
+  RPR_REQUIRE(N > 0 && N < ((int64_t)1 << 31) - 1, "N out of range");
+  RPR_REQUIRE(L >= 1 && L <= 4096 && V >= 1 && V <= 65536, "L or V out of range");
+  for (int64_t i = 0; i < N * L; ++i) RPR_REQUIRE(codes[i] < V, "code >= V");
+  auto t = std::make_unique<rpr_trie>();
+  t->ctx = c; t->N = N; t->L = L; t->V = V;
+  sort_codes(codes, N, L, t->host_sorted, t->perm);
+  int e = upload_trie(c, t);
+  if (e) return e;
+  *out = t.release();
+  return RPR_OK;
+}
+
+void rpr_free_trie(rpr_trie* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto it = t->ctx->graphs.begin(); it != t->ctx->graphs.end();) {
+    if (it->first.t == t) { (void)hipGraphExecDestroy(it->second); it = t->ctx->graphs.erase(it); } else ++it;
+  }
+  if (t->codes) (void)hipFree(t->codes);
+  delete t;
+}
+
+int64_t rpr_trie_num_rows(const rpr_trie* t) { return t ? t->N : 0; }
+const int64_t* rpr_trie_perm(const rpr_trie* t) { return t ? t->perm.data() : nullptr; }
+
+int rpr_trie_save(const rpr_trie* t, const char* path) {
+  RPR_REQUIRE(t && path, "NULL argument");
+  if (save_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V) != 0) {
+    set_error(std::string("cannot write trie file ") + path);
+    return RPR_ERR_INVALID;
+  }
+  return RPR_OK;
+}
+
+int rpr_trie_load(rpr_ctx* c, const char* path, rpr_trie** out) {
+  RPR_REQUIRE(c && path && out, "NULL argument");
+  auto t = std::make_unique<rpr_trie>();
+  t->ctx = c;
+  if (load_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V) != 0) {
+    set_error(std::string("cannot read trie file ") + path);
+    return RPR_ERR_INVALID;
+  }
+  int e = upload_trie(c, t);
+  if (e) return e;
+  *out = t.release();
+  return RPR_OK;
+}
+
+int rpr_trie_mask(rpr_ctx* c, const rpr_trie* t, const int32_t* prefix, int32_t R, int32_t T, uint8_t* out_mask) {
+  RPR_REQUIRE(c && t && prefix && out_mask, "NULL argument");
+  RPR_REQUIRE(R >= 1 && T >= 1, "R and T must be >= 1");
+  RPR_HIP(hipSetDevice(c->device));
+  int32_t* dp = nullptr; uint8_t* dm = nullptr;
+  RPR_HIP(hipMalloc(&dp, (size_t)R * T * 4));
+  RPR_HIP(hipMalloc(&dm, (size_t)R * t->V));
+  RPR_HIP(hipMemcpy(dp, prefix, (size_t)R * T * 4, hipMemcpyHostToDevice));
+  RPR_HIP(launch_prefix_mask(t->codes, t->L, t->N, dp, R, T, t->V, dm, nullptr));
+  RPR_HIP(hipMemcpy(out_mask, dm, (size_t)R * t->V, hipMemcpyDeviceToHost));
+  RPR_HIP(hipFree(dp));
+  RPR_HIP(hipFree(dm));
+  return RPR_OK;
+}
+
+int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask,
+               int32_t Q, int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores,
+               int64_t* out_row_lo, int64_t* out_row_hi, const rpr_debug_taps* taps, void* stream) {
+  RPR_REQUIRE(c && m && tr && input_ids && attention_mask && out_tokens && out_scores, "NULL argument");
+  RPR_REQUIRE(m->ctx == c && tr->ctx == c, "model/trie belong to another ctx");
+  RPR_REQUIRE(Q >= 1 && B >= 1 && B <= 65535, "Q or B out of range");
+  RPR_REQUIRE(Lq >= 1 && Lq <= MAX_LQ, "Lq out of range (1..256)");
+  RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
+  RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
+  RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int e = alloc_workspace(c, m, Q, Lq, B, L);
+  if (e) return e;
+  Workspace& w = c->ws;
+  const size_t T = (size_t)Q * Lq, R = (size_t)Q * B;
+  RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
+  RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
+
+  const bool eager = (flags & RPR_FLAG_NO_GRAPH) || taps || c->profiling;
+  if (eager) {
+    Launcher Ln{c, s};
+    enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps);
+    if (Ln.err) return Ln.err;
+  } else {
+    GraphKey key{m, tr, Q, Lq, B, L, flags};
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      RPR_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+      Launcher Ln{c, c->cap_stream};
+      enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, nullptr);
+      hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
+      if (Ln.err) { if (graph) (void)hipGraphDestroy(graph); return Ln.err; }
+      if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
+      hipGraphExec_t exec = nullptr;
+      hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate", __FILE__, __LINE__);
+      it = c->graphs.emplace(key, exec).first;
+    }
+    RPR_HIP(hipGraphLaunch(it->second, s));
+  }
+  RPR_HIP(hipMemcpyAsync(out_tokens, w.o_tokens.p, R * (size_t)L * 4, hipMemcpyDeviceToDevice, s));
+  RPR_HIP(hipMemcpyAsync(out_scores, w.o_scores.p, R * 4, hipMemcpyDeviceToDevice, s));
+  if (out_row_lo) RPR_HIP(hipMemcpyAsync(out_row_lo, w.o_lo.p, R * 8, hipMemcpyDeviceToDevice, s));
+  if (out_row_hi) RPR_HIP(hipMemcpyAsync(out_row_hi, w.o_hi.p, R * 8, hipMemcpyDeviceToDevice, s));
+  return RPR_OK;
+}
+
+int rpr_encode(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t Q,
+               int32_t Lq, float* out, void* stream) {
+  RPR_REQUIRE(c && m && input_ids && attention_mask && out, "NULL argument");
+  RPR_REQUIRE(Q >= 1 && Lq >= 1 && Lq <= MAX_LQ, "Q or Lq out of range");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int e = alloc_workspace(c, m, Q, Lq, 1, 1);
+  if (e) return e;
+  Workspace& w = c->ws;
+  const size_t T = (size_t)Q * Lq;
+  RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
+  RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
+  Launcher Ln{c, s};
+  enqueue_encoder(Ln, c, m, Q, Lq);
+  if (Ln.err) return Ln.err;
+  RPR_HIP(hipMemcpyAsync(out, w.enc_out.p, T * m->d.d_model * 4, hipMemcpyDeviceToDevice, s));
+  return RPR_OK;
+}
+
+int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* residual, float* C, int32_t M, int32_t N,
+                  int32_t K, int32_t relu, void* stream) {
+  RPR_REQUIRE(c && A && W && C, "NULL argument");
+  RPR_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0, "bad GEMM shape (K must be a multiple of 32)");
+  RPR_HIP(hipSetDevice(c->device));
+  Launcher Ln{c, reinterpret_cast<hipStream_t>(stream)};
+  gemm(Ln, A, K, W, N, K, M, residual, C, N, relu);
+  return Ln.err;
+}
+
+int rpr_op_rmsnorm(rpr_ctx* c, const float* x, const float* w, float* out, int32_t rows, int32_t d, float eps,
+                   void* stream) {
+  RPR_REQUIRE(c && x && w && out, "NULL argument");
+  RPR_REQUIRE(rows >= 1 && d >= 4 && d % 4 == 0, "bad shape");
+  RPR_HIP(hipSetDevice(c->device));
+  RPR_HIP(launch_rmsnorm(x, w, out, rows, d, eps, reinterpret_cast<hipStream_t>(stream)));
+  return RPR_OK;
+}
+
+int rpr_profile_enable(rpr_ctx* c, int enable) {
+  RPR_REQUIRE(c, "NULL ctx");
+  if (!enable && c->profiling) { int e = flush_profile(c); if (e) return e; }
+  c->profiling = enable != 0;
+  return RPR_OK;
+}
+
+int rpr_profile_reset(rpr_ctx* c) {
+  RPR_REQUIRE(c, "NULL ctx");
+  int e = flush_profile(c);
+  if (e) return e;
+  std::memset(c->done, 0, sizeof(c->done));
+  return RPR_OK;
+}
+
+int rpr_profile_get(rpr_ctx* c, int cls, rpr_kernel_stats* out) {
+  RPR_REQUIRE(c && out, "NULL argument");
+  RPR_REQUIRE(cls >= 0 && cls < RPR_K_COUNT, "bad kernel class");
+  int e = flush_profile(c);
+  if (e) return e;
+  *out = c->done[cls];
+  return RPR_OK;
+}
+
+}  // extern "C"

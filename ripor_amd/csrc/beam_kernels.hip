@@ -1,0 +1,279 @@
+// Trie-constrained beam selection on the device (gfx950, wave64).
+//
+// Replaces, per decode step, the reference's host-side pipeline
+//   PrefixConstrainLogitProcessorFastSparse.__call__   (tasks/generation.py:666-677: D2H ids -> string
+//       keys -> dict -> scipy CSR rows -> float64 mask -> H2D)
+//   mask/score combine                                   (generation.py:453-463)
+//   torch.topk(2B) + // and %                             (generation.py:484-492)
+//   BeamSearchScorer.process (first B of the sorted 2B)   (generation.py:496-503; HF 4.17)
+//   input_ids = cat(input_ids[beam_idx], tokens)          (generation.py:511)
+// and at the end BeamSearchScorer.finalize                (generation.py:532-540).
+//
+// Trie representation: the docid code matrix sorted lexicographically ([N, L] uint16). A beam's
+// trie node is the half-open row range [lo, hi) sharing its prefix; inside that range column t is
+// sorted, so "token c is a child" <=> lower_bound(c) lands on a row whose column t equals c, and
+// the child's range is [lower_bound(c), lower_bound(c+1)). A beam that ever took a masked token has
+// an empty range, which reproduces the reference's all-zero mask row for unknown prefixes.
+//
+// Float semantics kept bit-for-bit: candidate = ((double)logit_f32 + (valid ? 0 : -1e9)) + beam_score
+// in float64; ties broken by ascending flat index beam*V + token (torch.topk leaves ties
+// unspecified); finalize ranks by float64 sum/(L+1) descending with exact ties in reverse slot order
+// (stable ascending sort + pop), scores rounded once to float32.
+#include "common.h"
+
+namespace rpr {
+
+__device__ __forceinline__ int lower_bound_col(const uint16_t* __restrict__ codes, int Lc, int col, int lo, int hi,
+                                               int c) {
+  while (lo < hi) {
+    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if ((int)codes[(size_t)mid * Lc + col] < c) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void init_beams_kernel(BeamState st, int Q, int B, int N) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Q * B) return;
+  st.score[r] = (r % B == 0) ? 0.0 : -1e9;  // generation.py:418-420
+  st.lo[r] = 0;
+  st.hi[r] = N;
+}
+
+hipError_t launch_init_beams(const BeamState& st, int Q, int B, int64_t N, hipStream_t s) {
+  const int R = Q * B;
+  hipLaunchKernelGGL(init_beams_kernel, dim3((R + 255) / 256), dim3(256), 0, s, st, Q, B, (int)N);
+  return hipGetLastError();
+}
+
+struct Cand {
+  double s;
+  int item;
+};
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b) {
+  return a.s > b.s || (a.s == b.s && a.item < b.item);
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Cand d;
+    d.s = __shfl_xor(c.s, o, 64);
+    d.item = __shfl_xor(c.item, o, 64);
+    if (better(d, c)) c = d;
+  }
+  return c;
+}
+
+// One block (256 threads) per query.
+__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int B = a.B, V = a.V, t = a.t, Lc = a.Lc;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int items = B * V, words = items >> 6;
+  // LDS carve (all 8-byte aligned)
+  double* bscore = reinterpret_cast<double*>(smem_raw);                  // [B]
+  double* wscore = bscore + B;                                           // [B]
+  double* red_s = wscore + B;                                            // [4]
+  unsigned long long* valid = reinterpret_cast<unsigned long long*>(red_s + 4);  // [words]
+  unsigned long long* taken = valid + words;                             // [words]
+  int* blo = reinterpret_cast<int*>(taken + words);                      // [B]
+  int* bhi = blo + B;                                                    // [B]
+  int* widx = bhi + B;                                                   // [B]
+  int* red_i = widx + B;                                                 // [4]
+  float* lmax = reinterpret_cast<float*>(red_i + 4);                     // [B]
+  float* lsum = lmax + B;                                                // [B] log(sum exp)
+
+  const int r0 = q * B;
+  for (int b = tid; b < B; b += 256) {
+    bscore[b] = a.cur.score[r0 + b];
+    blo[b] = a.cur.lo[r0 + b];
+    bhi[b] = a.cur.hi[r0 + b];
+  }
+  for (int w = tid; w < words; w += 256) taken[w] = 0ull;
+  __syncthreads();
+
+  // ---- phase A: child mask of every beam (64 consecutive tokens of one beam per wave) ----
+  const float* lg_q = a.logits + (size_t)r0 * V;
+  int* lb_q = a.lb_scratch + (size_t)r0 * V;
+  for (int item = tid; item < items; item += 256) {
+    const int b = item / V, c = item - b * V;
+    const int lo = blo[b], hi = bhi[b];
+    bool ok = false;
+    int l = lo;
+    if (t < Lc && lo < hi) {
+      l = lower_bound_col(a.codes, Lc, t, lo, hi, c);
+      ok = (l < hi) && ((int)a.codes[(size_t)l * Lc + t] == c);
+    }
+    lb_q[item] = l;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) valid[item >> 6] = m;
+  }
+  if (a.log_softmax) {  // fp32 log_softmax over V (generation.py:453-455): (x - max) - log(sum exp(x - max))
+    for (int b = wave; b < B; b += 4) {
+      const float* row = lg_q + (size_t)b * V;
+      float mx = -INFINITY;
+      for (int c = lane; c < V; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sm = 0.f;
+      for (int c = lane; c < V; c += 64) sm += expf(row[c] - mx);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      if (lane == 0) { lmax[b] = mx; lsum[b] = logf(sm); }
+    }
+  }
+  __syncthreads();
+
+  auto cand_score = [&](int item) -> double {
+    const int b = item / V;
+    float lg = lg_q[item];
+    if (a.log_softmax) lg = (lg - lmax[b]) - lsum[b];
+    const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
+    return ((double)lg + (ok ? 0.0 : -1e9)) + bscore[b];
+  };
+  auto scan_best = [&]() -> Cand {
+    Cand best; best.s = -INFINITY; best.item = 0x7fffffff;
+    for (int item = tid; item < items; item += 256) {
+      if ((taken[item >> 6] >> (item & 63)) & 1ull) continue;
+      Cand c; c.s = cand_score(item); c.item = item;
+      if (better(c, best)) best = c;
+    }
+    return best;
+  };
+
+  // ---- phase B/C: B rounds of block-wide argmax ----
+  Cand mine = scan_best();
+  for (int j = 0; j < B; ++j) {
+    const Cand wb = wave_best(mine);
+    if (lane == 0) { red_s[wave] = wb.s; red_i[wave] = wb.item; }
+    __syncthreads();
+    Cand win; win.s = red_s[0]; win.item = red_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      Cand c; c.s = red_s[w]; c.item = red_i[w];
+      if (better(c, win)) win = c;
+    }
+    const bool owner = (win.item != 0x7fffffff) && ((win.item & 255) == tid);
+    if (tid == 0) { wscore[j] = win.s; widx[j] = win.item; }
+    if (owner) taken[win.item >> 6] |= 1ull << (win.item & 63);  // single writer per round (one winner), fenced by the barriers
+    __syncthreads();
+    if (owner) mine = scan_best();
+  }
+  __syncthreads();
+
+  // ---- phase D: write the next beam state (new slot j <- winner j) ----
+  const int ld = a.cur.ld;
+  for (int j = tid; j < B; j += 256) {
+    const int item = widx[j];
+    const int b = item / V, c = item - b * V;
+    const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
+    int nlo = 0, nhi = 0;
+    if (ok) {
+      nlo = lb_q[item];
+      nhi = (c + 1 < V) ? lb_q[item + 1] : bhi[b];
+    }
+    const int r = r0 + j;
+    a.nxt.score[r] = wscore[j];
+    a.nxt.lo[r] = nlo;
+    a.nxt.hi[r] = nhi;
+    a.nxt.tokens[(size_t)r * ld + t] = (uint16_t)c;
+    a.nxt.anc[(size_t)r * ld + t] = (uint16_t)b;
+    if (a.tap_scores) a.tap_scores[r] = wscore[j];
+    if (a.tap_tokens) a.tap_tokens[r] = c;
+    if (a.tap_parent) a.tap_parent[r] = b;
+  }
+  for (int i = tid; i < B * t; i += 256) {
+    const int j = i / t, p = i - j * t;
+    const int b = widx[j] / V;
+    a.nxt.tokens[(size_t)(r0 + j) * ld + p] = a.cur.tokens[(size_t)(r0 + b) * ld + p];
+    a.nxt.anc[(size_t)(r0 + j) * ld + p] = a.cur.anc[(size_t)(r0 + b) * ld + p];
+  }
+}
+
+static size_t select_smem(int B, int V) {
+  const size_t words = (size_t)B * V / 64;
+  return (2 * (size_t)B + 4) * sizeof(double) + 2 * words * sizeof(unsigned long long) +
+         (3 * (size_t)B + 4) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
+}
+
+hipError_t init_beam_kernel_attributes() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
+  if (a.V % 64 != 0) return hipErrorInvalidValue;
+  const size_t smem = select_smem(a.B, a.V);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(select_kernel, dim3(a.Q), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// One block per query: rank slots by float64 score/(L+1) descending, exact ties in reverse slot order.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sc = reinterpret_cast<double*>(smem_raw);  // [B]
+  const int B = a.B, L = a.L, q = blockIdx.x, tid = threadIdx.x, r0 = q * B;
+  for (int j = tid; j < B; j += 256) sc[j] = a.st.score[r0 + j] / (double)(L + 1);
+  __syncthreads();
+  int* rank = reinterpret_cast<int*>(sc + B);  // [B]
+  for (int j = tid; j < B; j += 256) {
+    const double s = sc[j];
+    int rk = 0;
+    for (int i = 0; i < B; ++i) rk += (sc[i] > s) || (sc[i] == s && i > j);
+    rank[j] = rk;
+    const size_t o = (size_t)r0 + rk;
+    a.out_scores[o] = (float)s;
+    a.out_lo[o] = a.st.lo[r0 + j];
+    a.out_hi[o] = a.st.hi[r0 + j];
+  }
+  __syncthreads();
+  for (int i = tid; i < B * L; i += 256) {
+    const int j = i / L, p = i - j * L;
+    a.out_tokens[((size_t)r0 + rank[j]) * L + p] = (int32_t)a.st.tokens[(size_t)(r0 + j) * a.st.ld + p];
+  }
+}
+
+hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)a.B * (sizeof(double) + sizeof(int)) + 16;
+  hipLaunchKernelGGL(finalize_kernel, dim3(a.Q), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// Processor-only entry (rpr_trie_mask): one block per prefix row.
+__global__ __launch_bounds__(256) void prefix_mask_kernel(const uint16_t* __restrict__ codes, int Lc, int N,
+                                                           const int32_t* __restrict__ prefix, int R, int T, int V,
+                                                           uint8_t* __restrict__ out_mask) {
+  __shared__ int s_lo, s_hi;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int lo = 0, hi = N;
+    for (int p = 1; p < T && lo < hi; ++p) {
+      const int c = prefix[(size_t)r * T + p];
+      if (c < 0 || c >= V || p - 1 >= Lc) { hi = lo; break; }
+      const int l = lower_bound_col(codes, Lc, p - 1, lo, hi, c);
+      const int h = lower_bound_col(codes, Lc, p - 1, l, hi, c + 1);
+      lo = l; hi = h;
+    }
+    s_lo = lo; s_hi = hi;
+  }
+  __syncthreads();
+  const int lo = s_lo, hi = s_hi, col = T - 1;
+  for (int c = tid; c < V; c += 256) {
+    bool ok = false;
+    if (col < Lc && lo < hi) {
+      const int l = lower_bound_col(codes, Lc, col, lo, hi, c);
+      ok = (l < hi) && ((int)codes[(size_t)l * Lc + col] == c);
+    }
+    out_mask[(size_t)r * V + c] = ok ? 1 : 0;
+  }
+}
+
+hipError_t launch_prefix_mask(const uint16_t* codes, int Lc, int64_t N, const int32_t* prefix, int R, int T,
+                              int V, uint8_t* out_mask, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(prefix_mask_kernel, dim3(R), dim3(256), 0, s, codes, Lc, (int)N, prefix, R, T, V, out_mask);
+  return hipGetLastError();
+}
+
+}  // namespace rpr

@@ -1,0 +1,130 @@
+// Shared declarations for libripor_hip.so (gfx950 only; wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ripor_hip.h"
+
+namespace rpr {
+
+constexpr int WAVE = 64;
+constexpr int MAX_LQ = 256;          // encoder tokens per query supported by the attention kernels
+constexpr int MAX_DEC_LEN = 64;      // decoder positions supported (reference uses 32 or 16)
+constexpr int DKV = 64;              // head dim the attention kernels are written for (t5-base/large)
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define RPR_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) return ::rpr::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define RPR_REQUIRE(cond, msg)                                               \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      ::rpr::set_error(std::string("invalid argument: ") + (msg));           \
+      return RPR_ERR_INVALID;                                                \
+    }                                                                        \
+  } while (0)
+
+// ---- GEMM: C = act(A @ W^T) (+ residual), fp32 MFMA --------------------------------------------
+struct GemmArgs {
+  const float* A; int lda;      // [M, K]
+  const float* W; int ldw;      // [N, K]  (torch Linear layout)
+  const float* resid; int ldr;  // nullable, [M, N]
+  float* out[3]; int ldo[3];    // column n is written to out[n / split_n][:, n % split_n]
+  int split_n;                  // == N when there is a single output
+  int M, N, K;
+  int relu;
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- T5 elementwise / attention kernels -----------------------------------------------------------
+// post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5
+hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
+                          float post_scale = 1.0f);
+hipError_t init_t5_kernel_attributes();
+hipError_t init_beam_kernel_attributes();
+hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
+                             hipStream_t s);
+// x[r] = t==0 ? start : in_embeds[t-1][tokens[r][t-1]]
+hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
+                            float* out, int R, int d, int V, int t, hipStream_t s);
+
+struct EncAttnArgs {
+  const float* qkv;        // [Q*Lq, 3*inner]  (q | k | v)
+  const int32_t* mask;     // [Q, Lq]
+  const float* rel_bias;   // [buckets, H]
+  const int32_t* bucket;   // [2*MAX_LQ-1]: bucket of rel = key - query, index rel + MAX_LQ-1
+  float* out;              // [Q*Lq, inner]
+  int Q, Lq, H, buckets;
+};
+hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
+
+struct DecSelfAttnArgs {
+  const float* q;          // [R, inner]
+  const float* kcache;     // this layer: [Lmax, R, inner]
+  const float* vcache;
+  const uint16_t* anc;     // [R, anc_ld]: slot (within the query) that produced position p < t
+  int anc_ld;
+  const float* rel_bias;   // [buckets, H]
+  const int32_t* bucket;   // [MAX_DEC_LEN]: bucket of rel = -(n), n = t - p
+  float* out;              // [R, inner]
+  int Q, B, H, t;
+};
+hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
+
+struct DecCrossAttnArgs {
+  const float* q;          // [R, inner]
+  const float* xk;         // K of this layer: row (q, j) at xk + (q*Lq + j) * xld
+  const float* xv;
+  int xld;
+  const int32_t* mask;     // [Q, Lq]
+  float* out;              // [R, inner]
+  int Q, B, H, Lq;
+};
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
+
+// ---- beam state + trie-constrained selection ------------------------------------------------------
+struct BeamState {           // one of two ping-pong buffers
+  double* score;             // [R]
+  int32_t* lo;               // [R] trie row range of the beam's prefix
+  int32_t* hi;
+  uint16_t* tokens;          // [R, ld]
+  uint16_t* anc;             // [R, ld]
+  int ld;
+};
+hipError_t launch_init_beams(const BeamState& st, int Q, int B, int64_t N, hipStream_t s);
+
+struct SelectArgs {
+  const float* logits;       // [R, V]
+  const uint16_t* codes;     // sorted [N, Lc]
+  int Lc;                    // row stride of codes (trie depth)
+  BeamState cur, nxt;
+  int32_t* lb_scratch;       // [R, V] lower bounds found by the mask phase
+  int Q, B, V, t;
+  int log_softmax;
+  // debug taps for step t (nullable)
+  double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
+};
+hipError_t launch_select(const SelectArgs& a, hipStream_t s);
+
+struct FinalizeArgs {
+  BeamState st;
+  int Q, B, L;
+  int32_t* out_tokens;       // [Q, B, L]
+  float* out_scores;         // [Q, B]
+  int64_t* out_lo;           // [Q, B]
+  int64_t* out_hi;
+};
+hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+// mask-only kernel for rpr_trie_mask: prefix rows -> child byte mask
+hipError_t launch_prefix_mask(const uint16_t* codes, int Lc, int64_t N, const int32_t* prefix, int R, int T,
+                              int V, uint8_t* out_mask, hipStream_t s);
+hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s);
+
+}  // namespace rpr

@@ -1,0 +1,319 @@
+// T5 elementwise + attention kernels of the search path (gfx950, wave64).
+//
+// Arithmetic follows HF T5Stack as the reference exercises it (reference
+// t5_pretrainer/modeling/t5_generative_retriever.py:358-366 encoder, :403-416 decoder):
+//   RMSNorm without mean/bias; attention scores NOT scaled by 1/sqrt(dkv); bucketed relative
+//   position bias from block 0 shared by all blocks; additive masks that make masked keys
+//   contribute exactly 0 after the fp32 softmax (here: masked keys are skipped); softmax
+//   normalised before the PV product.
+// All of these are HBM/L2-bound row kernels: 16-byte per-lane loads, one wave per row / per
+// (beam, head), cross-lane reductions with DPP/shuffles, no LDS staging of data that is read once.
+#include "common.h"
+
+namespace rpr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------ RMSNorm
+// one wave per row; d % 4 == 0
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ out, int rows, int d, float eps,
+                                                       float post_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  float4* orow = reinterpret_cast<float4*>(out + (size_t)row * d);
+  const int n4 = d >> 2;
+  float ss = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    const float4 v = xr[i];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)d + eps);
+  for (int i = lane; i < n4; i += 64) {
+    const float4 v = xr[i], g = wr[i];
+    float4 o = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
+    if (post_scale != 1.0f) { o.x *= post_scale; o.y *= post_scale; o.z *= post_scale; o.w *= post_scale; }
+    orow[i] = o;
+  }
+}
+
+hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
+                          float post_scale) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ embeddings
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                          float* __restrict__ out, int rows, int d, int vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * d);
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
+  for (int i = lane; i < (d >> 2); i += 64) dst[i] = src[i];
+}
+
+hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
+                             hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, out, rows, d, vocab);
+  return hipGetLastError();
+}
+
+// decoder input embedding of position t (reference t5_generative_retriever.py:194-214):
+// position 0 is the constant start_token_embed, position t>=1 is list_decoder_embeds[t-1][token_t].
+__global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict__ start, const float* __restrict__ in_embeds,
+                                                         const uint16_t* __restrict__ tokens, int tok_ld,
+                                                         float* __restrict__ out, int R, int d, int V, int t) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* src = start;
+  if (t > 0) {
+    const int tok = tokens[(size_t)row * tok_ld + (t - 1)];
+    src = in_embeds + ((size_t)(t - 1) * V + tok) * d;
+  }
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
+  for (int i = lane; i < (d >> 2); i += 64) dst[i] = s4[i];
+}
+
+hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
+                            float* out, int R, int d, int V, int t, hipStream_t s) {
+  hipLaunchKernelGGL(dec_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, s, start, in_embeds, tokens, tok_ld, out,
+                     R, d, V, t);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ encoder self-attention
+// One block per (query, head). K and V of the head are staged once in LDS ([Lq][65] padded), every
+// wave then handles query rows i = wave, wave+4, ...: lane j scores keys j, j+64, ...; the q row is
+// broadcast through SGPRs (v_readlane); softmax across the wave; PV with lane = output dim.
+__global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Lq = a.Lq, H = a.H, inner = H * DKV, ld = 3 * inner;
+  const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
+  float* Ks = smem;                    // [Lq][65]
+  float* Vs = smem + (size_t)Lq * 65;  // [Lq][64]
+  float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq] normalised weights per wave
+  float* Bs = Ps + 4 * Lq;             // [buckets<=64] bias of this head
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* base = a.qkv + (size_t)qi * Lq * ld + h * DKV;
+  for (int i = tid; i < Lq * 16; i += 256) {
+    const int j = i >> 4, c = (i & 15) * 4;
+    const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + inner + c);
+    const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * inner + c);
+    float* kd = Ks + j * 65 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+  }
+  if (tid < a.buckets) Bs[tid] = a.rel_bias[tid * H + h];
+  __syncthreads();
+  const int32_t* mrow = a.mask + (size_t)qi * Lq;
+  const int nchunk = (Lq + 63) >> 6;
+  float* P = Ps + wave * Lq;
+  for (int i = wave; i < Lq; i += 4) {
+    const float qv = base[(size_t)i * ld + lane];  // lane d holds q_i[d]
+    float sc[MAX_LQ / 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const int j = c * 64 + lane;
+      const int jc = j < Lq ? j : Lq - 1;
+      const float* kr = Ks + jc * 65;
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < DKV; ++d) {
+        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
+        acc = fmaf(qd, kr[d], acc);
+      }
+      float s = -INFINITY;
+      if (j < Lq && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
+      sc[c] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const float e = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - mx);
+      sc[c] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const int j = c * 64 + lane;
+      if (j < Lq) P[j] = sc[c] / sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int j = 0; j < Lq; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
+    a.out[((size_t)qi * Lq + i) * inner + h * DKV + lane] = o;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+hipError_t init_t5_kernel_attributes() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
+  if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
+  const size_t smem = ((size_t)a.Lq * 65 + (size_t)a.Lq * 64 + 4 * (size_t)a.Lq + 64) * sizeof(float);
+  hipLaunchKernelGGL(enc_attn_kernel, dim3(a.Q * a.H), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ decoder attention
+// One wave per (beam row r, head h). The 64 lanes form 4 groups of 16; a group reads one K (or V)
+// row of the head as 16 x float4 = one coalesced 256-byte segment, so each wave instruction
+// fetches 4 key rows. Scores are reduced inside the 16-lane group, kept in a per-wave LDS strip,
+// normalised, then the same mapping accumulates P.V and the 4 groups are summed with shuffles.
+//
+// Work item order: w = ((q * H + h) * B + b): the B beams of one (query, head) are adjacent and are
+// remapped so that one XCD (one L2) gets a contiguous chunk of work items — beams of a query share
+// most of their ancestors' K/V rows and the encoder K/V rows, which then hit in that XCD's L2.
+template <bool SELF>
+__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qbuf, const float* __restrict__ kbase,
+                                                        const float* __restrict__ vbase, const uint16_t* __restrict__ anc,
+                                                        int anc_ld, const float* __restrict__ rel_bias,
+                                                        const int32_t* __restrict__ bucket, const int32_t* __restrict__ mask,
+                                                        float* __restrict__ out, int Q, int B, int H, int t, int Lq,
+                                                        int xld) {
+  __shared__ float Ss[4][MAX_LQ];
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + k;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = bid * 4 + wave;
+  const int R = Q * B, inner = H * DKV;
+  if (w >= R * H) return;
+  const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
+  const int r = qi * B + b;
+  const int g = lane >> 4, li = lane & 15;
+  float* S = Ss[wave];
+
+  const float4 q4 = *reinterpret_cast<const float4*>(qbuf + (size_t)r * inner + h * DKV + li * 4);
+  const int nkeys = SELF ? (t + 1) : Lq;
+  const uint16_t* ancr = SELF ? (anc + (size_t)r * anc_ld) : nullptr;
+  const int32_t* mrow = SELF ? nullptr : (mask + (size_t)qi * Lq);
+
+  auto row_off = [&](int p) -> size_t {
+    if (SELF) {
+      const int slot = (p == t) ? b : (int)ancr[p];
+      return ((size_t)p * R + (size_t)qi * B + slot) * inner + h * DKV + li * 4;
+    } else {
+      return ((size_t)qi * Lq + p) * (size_t)xld + h * DKV + li * 4;
+    }
+  };
+
+  float mx = -INFINITY;
+  for (int p0 = 0; p0 < nkeys; p0 += 4) {
+    const int p = p0 + g;
+    float s = -INFINITY;
+    bool ok = p < nkeys;
+    if (!SELF && ok) ok = mrow[p] != 0;
+    float d = 0.f;
+    if (ok) {
+      const float4 k4 = *reinterpret_cast<const float4*>(kbase + row_off(p));
+      d = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    }
+    d = group16_sum(d);
+    if (ok) {
+      s = d;
+      if (SELF) s += rel_bias[bucket[t - p] * H + h];
+    }
+    if (li == 0 && p < nkeys) S[p] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  for (int p = lane; p < nkeys; p += 64) {
+    const float s = S[p];
+    const float e = (s == -INFINITY) ? 0.f : expf(s - mx);
+    S[p] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p0 = 0; p0 < nkeys; p0 += 4) {
+    const int p = p0 + g;
+    if (p < nkeys) {
+      const float wgt = S[p] / sum;
+      if (wgt != 0.f) {
+        const float4 v4 = *reinterpret_cast<const float4*>(vbase + row_off(p));
+        acc.x = fmaf(wgt, v4.x, acc.x);
+        acc.y = fmaf(wgt, v4.y, acc.y);
+        acc.z = fmaf(wgt, v4.z, acc.z);
+        acc.w = fmaf(wgt, v4.w, acc.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64);
+    acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64);
+    acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (g == 0) *reinterpret_cast<float4*>(out + (size_t)r * inner + h * DKV + li * 4) = acc;
+}
+
+hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
+  const int items = a.Q * a.B * a.H;
+  hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
+                     a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
+  const int items = a.Q * a.B * a.H;
+  hipLaunchKernelGGL(dec_attn_kernel<false>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.xk, a.xv,
+                     (const uint16_t*)nullptr, 0, (const float*)nullptr, (const int32_t*)nullptr, a.mask, a.out, a.Q,
+                     a.B, a.H, 0, a.Lq, a.xld);
+  return hipGetLastError();
+}
+
+__global__ void mask_lengths_kernel(const int32_t* __restrict__ mask, int32_t* __restrict__ lens, int Q, int Lq) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  int n = 0;
+  for (int j = 0; j < Lq; ++j) n += mask[(size_t)q * Lq + j] != 0;
+  lens[q] = n;
+}
+
+hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s) {
+  hipLaunchKernelGGL(mask_lengths_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, mask, lens, Q, Lq);
+  return hipGetLastError();
+}
+
+}  // namespace rpr

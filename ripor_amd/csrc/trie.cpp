@@ -1,0 +1,83 @@
+// Host side of the device trie: sort the docid code matrix, keep the permutation, (de)serialise.
+//
+// Replaces the reference's per-level dict-of-strings build (t5_pretrainer/evaluate.py:410-424,
+// aq_preprocess/build_list_smtid_to_nextids.py:21-41), its pickle cache (evaluate.py:404-408,
+// 428-432) and the smtid -> docids dict (evaluate.py:439-446): after sorting, every trie node and
+// every smtid is a contiguous row range, and the docids of a range are perm[lo..hi).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "trie.h"
+
+namespace rpr {
+
+struct SortKey {
+  uint64_t key;  // first four codes, 16 bits each (most significant first)
+  int32_t idx;
+};
+
+int sort_codes(const uint16_t* codes, int64_t N, int L, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm) {
+  std::vector<SortKey> keys((size_t)N);
+  const int pk = L < 4 ? L : 4;
+  for (int64_t i = 0; i < N; ++i) {
+    uint64_t k = 0;
+    for (int l = 0; l < 4; ++l) k = (k << 16) | (l < pk ? codes[i * L + l] : 0);
+    keys[(size_t)i] = {k, (int32_t)i};
+  }
+  std::sort(keys.begin(), keys.end(), [codes, L, pk](const SortKey& a, const SortKey& b) {
+    if (a.key != b.key) return a.key < b.key;
+    const uint16_t* ra = codes + (int64_t)a.idx * L;
+    const uint16_t* rb = codes + (int64_t)b.idx * L;
+    for (int l = pk; l < L; ++l)
+      if (ra[l] != rb[l]) return ra[l] < rb[l];
+    return a.idx < b.idx;  // stable: equal smtids keep docid order (evaluate.py:443-446 appends in file order)
+  });
+  sorted.resize((size_t)N * L);
+  perm.resize((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    perm[(size_t)i] = keys[(size_t)i].idx;
+    std::memcpy(&sorted[(size_t)i * L], codes + (int64_t)keys[(size_t)i].idx * L, sizeof(uint16_t) * L);
+  }
+  return 0;
+}
+
+static const char kMagic[8] = {'R', 'P', 'R', 'T', 'R', 'I', 'E', '1'};
+
+int save_trie_file(const char* path, const std::vector<uint16_t>& sorted, const std::vector<int64_t>& perm,
+                   int64_t N, int L, int V) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return -1;
+  int64_t hdr[3] = {N, L, V};
+  bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int64_t), 3, f) == 3 &&
+            std::fwrite(sorted.data(), sizeof(uint16_t), sorted.size(), f) == sorted.size() &&
+            std::fwrite(perm.data(), sizeof(int64_t), perm.size(), f) == perm.size();
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? 0 : -1;
+}
+
+int load_trie_file(const char* path, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm, int64_t& N, int& L,
+                   int& V) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return -1;
+  char magic[8];
+  int64_t hdr[3];
+  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kMagic, 8) == 0 &&
+            std::fread(hdr, sizeof(int64_t), 3, f) == 3;
+  if (ok) {
+    N = hdr[0]; L = (int)hdr[1]; V = (int)hdr[2];
+    ok = N > 0 && L > 0 && L <= 4096 && V > 0 && V <= 65536;
+  }
+  if (ok) {
+    sorted.resize((size_t)N * L);
+    perm.resize((size_t)N);
+    ok = std::fread(sorted.data(), sizeof(uint16_t), sorted.size(), f) == sorted.size() &&
+         std::fread(perm.data(), sizeof(int64_t), perm.size(), f) == perm.size();
+  }
+  std::fclose(f);
+  return ok ? 0 : -1;
+}
+
+}  // namespace rpr

@@ -1,0 +1,289 @@
+"""Thin Python objects over the C ABI: device context, bound model weights, device trie, search.
+
+torch is used only for device memory (tensors own the buffers whose ``data_ptr()`` crosses the
+ABI) and for the current HIP stream handle. All compute happens in ``libripor_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import RiporHipError, check
+
+_contexts: Dict[int, "Context"] = {}
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Context:
+    """One ``rpr_ctx`` per device (workspaces, KV cache and hipGraphs live in it)."""
+
+    def __init__(self, device_index: int):
+        if not torch.cuda.is_available():
+            raise RiporHipError("no HIP device visible to torch: the search path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device_index)
+        h = C.c_void_p()
+        check(self.lib.rpr_init(device_index, C.byref(h)), "rpr_init")
+        self.handle = h
+
+    @staticmethod
+    def get(device=None) -> "Context":
+        if device is None:
+            idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        else:
+            dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            if dev.type != "cuda":
+                raise RiporHipError(f"device {dev} is not a HIP device: the search path has no CPU fallback")
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if idx not in _contexts:
+            _contexts[idx] = Context(idx)
+        return _contexts[idx]
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.rpr_workspace_bytes(self.handle))
+
+    # -- profiling (bench.py roofline leg) --
+    def profile_enable(self, on: bool):
+        check(self.lib.rpr_profile_enable(self.handle, 1 if on else 0), "rpr_profile_enable")
+
+    def profile_reset(self):
+        check(self.lib.rpr_profile_reset(self.handle), "rpr_profile_reset")
+
+    def profile_get(self) -> Dict[str, dict]:
+        out = {}
+        for cls, name in enumerate(_lib.KERNEL_CLASS_NAMES):
+            st = _lib.KernelStats()
+            check(self.lib.rpr_profile_get(self.handle, cls, C.byref(st)), "rpr_profile_get")
+            out[name] = dict(total_ms=st.total_ms, launches=int(st.launches), flops=st.flops, bytes=st.bytes)
+        return out
+
+    # -- single operators (kernel-level parity tests) --
+    def linear(self, A: torch.Tensor, W: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = False):
+        assert A.is_cuda and W.is_cuda and A.dtype == torch.float32 and W.dtype == torch.float32
+        A, W = A.contiguous(), W.contiguous()
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        res = residual.contiguous() if residual is not None else None
+        check(self.lib.rpr_op_linear(self.handle, A.data_ptr(), W.data_ptr(), res.data_ptr() if res is not None else None,
+                                     out.data_ptr(), M, N, K, 1 if relu else 0, _stream_ptr(A.device)), "rpr_op_linear")
+        return out
+
+    def rmsnorm(self, x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6):
+        x, w = x.contiguous(), w.contiguous()
+        out = torch.empty_like(x)
+        check(self.lib.rpr_op_rmsnorm(self.handle, x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                      eps, _stream_ptr(x.device)), "rpr_op_rmsnorm")
+        return out
+
+
+def rel_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:
+    """Host-only table entry exactly as the library computes it (needs no GPU)."""
+    return int(_lib.load().rpr_rel_bucket(rel, 1 if bidirectional else 0, num_buckets, max_distance))
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+class DeviceModel:
+    """Binds a ``T5ForDocIDGeneration`` state dict (reference checkpoint key names, SURVEY.md §8
+    row a14) to an ``rpr_model``: q/k/v are concatenated, codebooks and cross-attention k/v stacked,
+    everything float32 on the device."""
+
+    def __init__(self, ctx: Context, state_dict: Dict[str, torch.Tensor], cfg):
+        self.ctx, self.cfg = ctx, cfg
+        dev = ctx.device
+
+        def g(name):
+            t = state_dict[name]
+            if isinstance(t, np.ndarray):
+                t = torch.from_numpy(t)
+            return t.to(device=dev, dtype=torch.float32).contiguous()
+
+        L = len(cfg.decoder_vocab_sizes)
+        V = int(cfg.decoder_vocab_sizes[0])
+        if len(set(cfg.decoder_vocab_sizes)) != 1:
+            raise ValueError("not valid decoder_vocab_size")  # reference evaluate.py:433-436
+        shared_embeds = bool(cfg.shared_output_input_embeds)
+        keep: List[torch.Tensor] = []
+
+        def K(t):
+            keep.append(t)
+            return t
+
+        def attn_qkv(prefix):
+            return K(torch.cat([g(prefix + ".q.weight"), g(prefix + ".k.weight"), g(prefix + ".v.weight")], 0).contiguous())
+
+        ne, nd = cfg.num_layers, cfg.num_decoder_layers
+        enc = dict(ln0=[], qkv=[], o=[], ln1=[], wi=[], wo=[])
+        for i in range(ne):
+            p = f"encoder.block.{i}.layer"
+            enc["ln0"].append(K(g(p + ".0.layer_norm.weight")))
+            enc["qkv"].append(attn_qkv(p + ".0.SelfAttention"))
+            enc["o"].append(K(g(p + ".0.SelfAttention.o.weight")))
+            enc["ln1"].append(K(g(p + ".1.layer_norm.weight")))
+            enc["wi"].append(K(g(p + ".1.DenseReluDense.wi.weight")))
+            enc["wo"].append(K(g(p + ".1.DenseReluDense.wo.weight")))
+        dec = dict(ln0=[], qkv=[], o=[], ln1=[], xq=[], xo=[], ln2=[], wi=[], wo=[])
+        xkv = []
+        for i in range(nd):
+            p = f"decoder.block.{i}.layer"
+            dec["ln0"].append(K(g(p + ".0.layer_norm.weight")))
+            dec["qkv"].append(attn_qkv(p + ".0.SelfAttention"))
+            dec["o"].append(K(g(p + ".0.SelfAttention.o.weight")))
+            dec["ln1"].append(K(g(p + ".1.layer_norm.weight")))
+            dec["xq"].append(K(g(p + ".1.EncDecAttention.q.weight")))
+            xkv += [g(p + ".1.EncDecAttention.k.weight"), g(p + ".1.EncDecAttention.v.weight")]
+            dec["xo"].append(K(g(p + ".1.EncDecAttention.o.weight")))
+            dec["ln2"].append(K(g(p + ".2.layer_norm.weight")))
+            dec["wi"].append(K(g(p + ".2.DenseReluDense.wi.weight")))
+            dec["wo"].append(K(g(p + ".2.DenseReluDense.wo.weight")))
+        self.shared = K(g("shared.weight"))
+        self.enc_rel = K(g("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"))
+        self.dec_rel = K(g("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"))
+        self.enc_fln = K(g("encoder.final_layer_norm.weight"))
+        self.dec_fln = K(g("decoder.final_layer_norm.weight"))
+        self.start = K(g("start_token_embed").reshape(-1).contiguous())
+        self.in_embeds = K(torch.stack([g(f"list_decoder_embeds.{i}.weight") for i in range(L)], 0).contiguous())
+        if shared_embeds:
+            self.out_embeds = self.in_embeds
+        else:
+            self.out_embeds = K(torch.stack([g(f"list_output_embeds.{i}.weight") for i in range(L)], 0).contiguous())
+        self.dec_xkv = K(torch.cat(xkv, 0).contiguous())
+        self._keep = keep
+        self._arrays = {}
+        d = _lib.ModelDesc()
+        d.vocab_size, d.d_model, d.d_kv, d.d_ff = cfg.vocab_size, cfg.d_model, cfg.d_kv, cfg.d_ff
+        d.num_heads, d.num_layers, d.num_decoder_layers = cfg.num_heads, ne, nd
+        d.rel_buckets, d.rel_max_distance = cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance
+        d.L, d.V = L, V
+        d.scaleup_output_hidden = 1 if cfg.scaleup_output_hidden else 0
+        d.layer_norm_eps = float(cfg.layer_norm_epsilon)
+        d.shared, d.enc_rel_bias, d.dec_rel_bias = self.shared.data_ptr(), self.enc_rel.data_ptr(), self.dec_rel.data_ptr()
+        d.enc_final_ln, d.dec_final_ln, d.start_embed = self.enc_fln.data_ptr(), self.dec_fln.data_ptr(), self.start.data_ptr()
+        d.in_embeds, d.out_embeds, d.dec_xkv = self.in_embeds.data_ptr(), self.out_embeds.data_ptr(), self.dec_xkv.data_ptr()
+        for k, v in enc.items():
+            self._arrays["enc_" + k] = _ptr_array(v)
+            setattr(d, "enc_" + k, self._arrays["enc_" + k])
+        for k, v in dec.items():
+            self._arrays["dec_" + k] = _ptr_array(v)
+            setattr(d, "dec_" + k, self._arrays["dec_" + k])
+        h = C.c_void_p()
+        torch.cuda.synchronize(dev)
+        check(ctx.lib.rpr_load_model(ctx.handle, C.byref(d), C.byref(h)), "rpr_load_model")
+        self.handle = h
+        self.L, self.V, self.d_model = L, V, cfg.d_model
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.rpr_free_model(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        dev = self.ctx.device
+        ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
+        mask = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        Q, Lq = ids.shape
+        out = torch.empty((Q, Lq, self.d_model), dtype=torch.float32, device=dev)
+        check(self.ctx.lib.rpr_encode(self.ctx.handle, self.handle, ids.data_ptr(), mask.data_ptr(), Q, Lq,
+                                      out.data_ptr(), _stream_ptr(dev)), "rpr_encode")
+        return out
+
+
+class DeviceTrie:
+    """Sorted-code-matrix trie on the device (replaces the reference's dict/CSR structures)."""
+
+    def __init__(self, ctx: Context, handle, L: int, V: int):
+        self.ctx, self.handle, self.L, self.V = ctx, handle, L, V
+        self.N = int(ctx.lib.rpr_trie_num_rows(handle))
+        p = ctx.lib.rpr_trie_perm(handle)
+        self.perm = np.ctypeslib.as_array(p, shape=(self.N,))  # view, valid until free
+
+    @classmethod
+    def from_codes(cls, ctx: Context, codes: np.ndarray, V: int) -> "DeviceTrie":
+        codes = np.ascontiguousarray(codes, dtype=np.uint16)
+        N, L = codes.shape
+        h = C.c_void_p()
+        check(ctx.lib.rpr_build_trie(ctx.handle, codes.ctypes.data_as(C.c_void_p), N, L, V, C.byref(h)), "rpr_build_trie")
+        return cls(ctx, h, L, V)
+
+    @classmethod
+    def load(cls, ctx: Context, path: str, L: int, V: int) -> "DeviceTrie":
+        h = C.c_void_p()
+        check(ctx.lib.rpr_trie_load(ctx.handle, path.encode(), C.byref(h)), "rpr_trie_load")
+        return cls(ctx, h, L, V)
+
+    def save(self, path: str):
+        check(self.ctx.lib.rpr_trie_save(self.handle, path.encode()), "rpr_trie_save")
+
+    def mask(self, prefix: np.ndarray) -> np.ndarray:
+        prefix = np.ascontiguousarray(prefix, dtype=np.int32)
+        R, T = prefix.shape
+        out = np.zeros((R, self.V), dtype=np.uint8)
+        check(self.ctx.lib.rpr_trie_mask(self.ctx.handle, self.handle, prefix.ctypes.data_as(C.c_void_p), R, T,
+                                         out.ctypes.data_as(C.c_void_p)), "rpr_trie_mask")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.perm = None
+                self.ctx.lib.rpr_free_trie(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+@dataclass
+class SearchResult:
+    tokens: torch.Tensor      # int32 [Q, B, L]
+    scores: torch.Tensor      # float32 [Q, B]
+    row_lo: torch.Tensor      # int64 [Q, B]
+    row_hi: torch.Tensor      # int64 [Q, B]
+    taps: Optional[dict] = None
+
+
+def search(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+           num_beams: int, max_new_tokens: int, apply_log_softmax_for_scores: bool = False,
+           use_graph: bool = True, taps: bool = False) -> SearchResult:
+    """One call of the hot path: encoder + L fused decode/select steps. Asynchronous on the
+    current torch stream; results are device tensors."""
+    ctx = model.ctx
+    dev = ctx.device
+    ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
+    mask = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+    Q, Lq = ids.shape
+    B, L = int(num_beams), int(max_new_tokens)
+    tokens = torch.empty((Q, B, L), dtype=torch.int32, device=dev)
+    scores = torch.empty((Q, B), dtype=torch.float32, device=dev)
+    lo = torch.empty((Q, B), dtype=torch.int64, device=dev)
+    hi = torch.empty((Q, B), dtype=torch.int64, device=dev)
+    flags = (_lib.FLAG_LOG_SOFTMAX if apply_log_softmax_for_scores else 0) | (0 if use_graph else _lib.FLAG_NO_GRAPH)
+    tap_struct, tap_out = None, None
+    if taps:
+        tap_out = dict(
+            encoder_out=torch.empty((Q, Lq, model.d_model), dtype=torch.float32, device=dev),
+            step_logits=torch.empty((L, Q * B, model.V), dtype=torch.float32, device=dev),
+            step_scores=torch.empty((L, Q, B), dtype=torch.float64, device=dev),
+            step_tokens=torch.empty((L, Q, B), dtype=torch.int32, device=dev),
+            step_parent=torch.empty((L, Q, B), dtype=torch.int32, device=dev))
+        tap_struct = _lib.DebugTaps(*[tap_out[k].data_ptr() for k in
+                                      ("encoder_out", "step_logits", "step_scores", "step_tokens", "step_parent")])
+    check(ctx.lib.rpr_search(ctx.handle, model.handle, trie.handle, ids.data_ptr(), mask.data_ptr(), Q, Lq, B, L, flags,
+                             tokens.data_ptr(), scores.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                             C.byref(tap_struct) if tap_struct is not None else None, _stream_ptr(dev)), "rpr_search")
+    # ids/mask must stay alive until the async D2D staging copies have been enqueued (they have).
+    return SearchResult(tokens, scores, lo, hi, tap_out)

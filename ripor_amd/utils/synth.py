@@ -1,0 +1,227 @@
+"""Deterministic synthetic inputs for the constrained-beam-search path.
+
+There is no network in the build/bench environment, so checkpoints, the
+MS MARCO ``docid_to_smtid.json`` and the dev queries are replaced by synthetic
+data of the same *shape* (BASELINE.json ``configs``).
+
+Everything here comes from a counter-based integer hash (splitmix64) so that the
+build container, the GPU box and the golden-fixture generator all produce
+bit-identical arrays without depending on any library RNG stream:
+
+    value(name, i) = ((splitmix64(fnv1a64(name) + i) >> 40) - 2**23) / 2**23 * scale
+
+which is exact in float64 and rounds once to float32.
+
+State-dict key names and shapes follow the reference checkpoint layout
+(reference: t5_pretrainer/modeling/t5_generative_retriever.py:84-112, HF ``T5Stack``
+parameter names).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+SEED = 20240928
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def hash_u64(name: str, n: int, seed: int = SEED, offset: int = 0) -> np.ndarray:
+    base = np.uint64((fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        ctr = np.arange(offset, offset + n, dtype=np.uint64) + base
+    return splitmix64(ctr)
+
+
+def uniform_f32(name: str, shape, scale: float, seed: int = SEED) -> np.ndarray:
+    """Uniform in [-scale, scale) with 24-bit resolution; exact & reproducible."""
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    chunk = 1 << 24
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        h = hash_u64(name, e - s, seed, offset=s)
+        v = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)
+        out[s:e] = (v.astype(np.float64) * (scale / float(1 << 23))).astype(np.float32)
+    return out.reshape(shape)
+
+
+def randint(name: str, shape, lo: int, hi: int, seed: int = SEED) -> np.ndarray:
+    """Integers uniform in [lo, hi) (modulo bias is irrelevant for synthetic data)."""
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.int64)
+    chunk = 1 << 24
+    span = np.uint64(hi - lo)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        h = hash_u64(name, e - s, seed, offset=s)
+        out[s:e] = ((h >> np.uint64(11)) % span).astype(np.int64) + lo
+    return out.reshape(shape)
+
+
+# --------------------------------------------------------------------------- model dims
+
+
+@dataclass
+class ModelDims:
+    """Dimensions of a ``T5ForDocIDGeneration`` checkpoint (T5forDocIDConfig fields)."""
+
+    vocab_size: int = 32128
+    d_model: int = 768
+    d_kv: int = 64
+    d_ff: int = 3072
+    num_layers: int = 12
+    num_decoder_layers: int = 12
+    num_heads: int = 12
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+    decoder_vocab_sizes: List[int] = field(default_factory=lambda: [256] * 32)
+    shared_output_input_embeds: bool = False
+    scaleup_output_hidden: bool = False
+
+    @property
+    def inner(self) -> int:
+        return self.num_heads * self.d_kv
+
+
+def t5_base_dims(L: int = 32, V: int = 256, **kw) -> ModelDims:
+    return ModelDims(decoder_vocab_sizes=[V] * L, **kw)
+
+
+def t5_large_dims(L: int = 32, V: int = 256, **kw) -> ModelDims:
+    return ModelDims(d_model=1024, d_kv=64, d_ff=4096, num_layers=24, num_decoder_layers=24,
+                     num_heads=16, decoder_vocab_sizes=[V] * L, **kw)
+
+
+def mini_dims(L: int = 8, V: int = 256, enc_layers: int = 2, d_ff: int = 256,
+              vocab_size: int = 512, **kw) -> ModelDims:
+    """Cheap golden model: the reference ctor forces (12 decoder layers, 12 heads, d=768)
+    (t5_generative_retriever.py:116-121); encoder depth, d_ff and vocab are free."""
+    return ModelDims(vocab_size=vocab_size, d_ff=d_ff, num_layers=enc_layers,
+                     decoder_vocab_sizes=[V] * L, **kw)
+
+
+def make_state_dict(dims: ModelDims, seed: int = SEED, logit_scale: float = 0.35) -> Dict[str, np.ndarray]:
+    """Seeded weights under the reference's state-dict key names (float32 numpy arrays).
+
+    Scales follow HF's T5 init factors so activations stay O(1); layer-norm weights are
+    perturbed around 1 and the relative-bias tables are O(1) so that a kernel that drops
+    either is caught by the parity tests. ``logit_scale`` sets the output-codebook spread
+    (logits come out O(10), like a trained model's dot-product scores).
+    """
+    d, inner, dff = dims.d_model, dims.inner, dims.d_ff
+    sd: Dict[str, np.ndarray] = {}
+    r3 = 3.0 ** 0.5  # uniform[-a,a) has std a/sqrt(3)
+
+    def u(name, shape, std):
+        sd[name] = uniform_f32(name, shape, std * r3, seed)
+
+    def ln(name):
+        sd[name] = (1.0 + uniform_f32(name, (d,), 0.2, seed)).astype(np.float32)
+
+    u("shared.weight", (dims.vocab_size, d), 1.0)
+
+    def attn(prefix, has_bias):
+        u(prefix + ".q.weight", (inner, d), (d * dims.d_kv) ** -0.5)
+        u(prefix + ".k.weight", (inner, d), d ** -0.5)
+        u(prefix + ".v.weight", (inner, d), d ** -0.5)
+        u(prefix + ".o.weight", (d, inner), inner ** -0.5)
+        if has_bias:
+            u(prefix + ".relative_attention_bias.weight",
+              (dims.relative_attention_num_buckets, dims.num_heads), 0.5)
+
+    for i in range(dims.num_layers):
+        p = f"encoder.block.{i}.layer"
+        attn(p + ".0.SelfAttention", i == 0)
+        ln(p + ".0.layer_norm.weight")
+        u(p + ".1.DenseReluDense.wi.weight", (dff, d), d ** -0.5)
+        u(p + ".1.DenseReluDense.wo.weight", (d, dff), dff ** -0.5)
+        ln(p + ".1.layer_norm.weight")
+    ln("encoder.final_layer_norm.weight")
+
+    for i in range(dims.num_decoder_layers):
+        p = f"decoder.block.{i}.layer"
+        attn(p + ".0.SelfAttention", i == 0)
+        ln(p + ".0.layer_norm.weight")
+        attn(p + ".1.EncDecAttention", False)
+        ln(p + ".1.layer_norm.weight")
+        u(p + ".2.DenseReluDense.wi.weight", (dff, d), d ** -0.5)
+        u(p + ".2.DenseReluDense.wo.weight", (d, dff), dff ** -0.5)
+        ln(p + ".2.layer_norm.weight")
+    ln("decoder.final_layer_norm.weight")
+
+    for i, V in enumerate(dims.decoder_vocab_sizes):
+        u(f"list_decoder_embeds.{i}.weight", (V, d), 1.0)
+        if not dims.shared_output_input_embeds:
+            u(f"list_output_embeds.{i}.weight", (V, d), logit_scale)
+    u("start_token_embed", (1, 1, d), 1.0)
+    return sd
+
+
+# --------------------------------------------------------------------------- docid codes
+
+
+def make_codes(N: int, L: int, V: int, seed: int = SEED, skew: bool = False) -> np.ndarray:
+    """Synthetic ``docid_to_smtid`` code matrix ``[N, L]`` (docid = row index), i.i.d. uniform
+    tokens. ``skew`` squares the uniform variate on the first three levels to
+    mimic residual-quantiser code imbalance."""
+    dt = np.uint8 if V <= 256 else np.uint16
+    codes = randint(f"codes/{N}x{L}x{V}", (N, L), 0, V, seed)
+    if skew:
+        lv = min(3, L)
+        u = randint(f"codes_skew/{N}", (N, lv), 0, 1 << 20, seed).astype(np.float64) / float(1 << 20)
+        codes[:, :lv] = np.minimum((u * u * V).astype(np.int64), V - 1)
+    return codes.astype(dt)
+
+
+def codes_to_docid_to_smtid(codes: np.ndarray) -> Dict[str, List[int]]:
+    """The reference's on-disk format: ``{"docid": [-1, c1, ..., cL]}``
+    (aq_preprocess/create_customized_smtid_file.py:47-59)."""
+    return {str(i): [-1] + [int(x) for x in row] for i, row in enumerate(codes)}
+
+
+# --------------------------------------------------------------------------- queries
+
+
+def make_queries(Q: int, vocab_size: int = 32128, seed: int = SEED, mean_len: float = 12.0,
+                 std_len: float = 4.0, min_len: int = 6, max_len: int = 32,
+                 fixed_len: Optional[int] = None):
+    """MSMARCO-dev-shaped tokenised queries: ``input_ids, attention_mask`` ``[Q, Lq]`` int64,
+    padded with 0 to the batch maximum (pad-to-longest like the reference collator,
+    dataset/dataloader.py:62-79). First three ids are fixed ("query", ":", "▁"-like), last
+    valid id is 1 (``</s>``). Lengths ~ clipped N(mean, std) via an Irwin-Hall(12) variate."""
+    if fixed_len is not None:
+        lens = np.full(Q, fixed_len, dtype=np.int64)
+    else:
+        u = randint(f"qlen/{Q}", (Q, 12), 0, 1 << 20, seed).astype(np.float64) / float(1 << 20)
+        z = u.sum(axis=1) - 6.0  # ~N(0,1)
+        lens = np.clip(np.rint(mean_len + std_len * z), min_len, max_len).astype(np.int64)
+    Lq = int(lens.max())
+    ids = randint(f"qtok/{Q}", (Q, Lq), 3, min(32000, vocab_size), seed)
+    fixed = [min(11417, vocab_size - 1), min(10, vocab_size - 1), min(3, vocab_size - 1)]
+    ids[:, 0], ids[:, 1], ids[:, 2] = fixed
+    pos = np.arange(Lq)[None, :]
+    mask = (pos < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    ids[np.arange(Q), lens - 1] = 1
+    return ids, mask

@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the *imported* reference (/root/reference) on CPU.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box and the test-suite use
+the committed ``*.npz`` outputs. No reference source is copied: the reference modules are
+imported in place through a compatibility shim (transformers 5.15 here vs the reference's pinned
+4.17.0), and what is stored is data: the seeds/dims needed to regenerate
+the inputs with ripor_amd.utils.synth plus the reference's outputs.
+
+What runs unmodified from the reference:
+  t5_pretrainer.modeling.t5_generative_retriever.T5ForDocIDGeneration (forward, embeds, logits)
+  t5_pretrainer.tasks.generation.beam_search_for_constrained_prefix   (the beam loop)
+  t5_pretrainer.tasks.generation.PrefixConstrainLogitProcessorFastSparse
+  t5_pretrainer.utils.utils.convert_ptsmtids_to_strsmtid
+What is restated here because transformers 4.17 is not installed: BeamSearchScorer (behaviour per
+SURVEY.md Appendix C), stopping criteria / logits-processor containers, and the generate()
+wrapper's prologue (encoder once, repeat_interleave(B), decoder_start ids = 0, MaxLength(L+1)).
+
+Usage:  python tests/golden/make_golden.py [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from ripor_amd.utils import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shim
+def install_shim():
+    import transformers
+    import transformers.pytorch_utils as pu
+    from transformers.modeling_outputs import BaseModelOutput
+    from transformers.utils import ModelOutput
+    import transformers.models.t5.modeling_t5 as mt5
+
+    uj = types.ModuleType("ujson")
+    uj.load, uj.loads, uj.dump, uj.dumps = json.load, json.loads, json.dump, json.dumps
+    sys.modules["ujson"] = uj
+
+    mpu = types.ModuleType("transformers.utils.model_parallel_utils")
+    mpu.assert_device_map = lambda *a, **k: None
+    mpu.get_device_map = lambda *a, **k: None
+    sys.modules["transformers.utils.model_parallel_utils"] = mpu
+
+    pu.torch_int_div = lambda a, b: torch.div(a, b, rounding_mode="floor")
+
+    Orig = mt5.T5Stack
+
+    class T5StackCompat(Orig):
+        def __init__(self, config, embed_tokens=None):
+            super().__init__(config)
+            if embed_tokens is not None:
+                self.embed_tokens = embed_tokens
+
+        def forward(self, *args, head_mask=None, cross_attn_head_mask=None, output_attentions=None,
+                    output_hidden_states=None, return_dict=None, **kw):
+            return super().forward(*args, **kw)
+
+    mt5.T5Stack = T5StackCompat
+
+    # --- transformers.generation_beam_search (HF 4.17 behaviour, restated) ---
+    class BeamHypotheses:
+        def __init__(self, num_beams, length_penalty, early_stopping):
+            self.length_penalty, self.early_stopping, self.num_beams = length_penalty, early_stopping, num_beams
+            self.beams, self.worst_score = [], 1e9
+
+        def __len__(self):
+            return len(self.beams)
+
+        def add(self, hyp, sum_logprobs):
+            score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+            if len(self) < self.num_beams or score > self.worst_score:
+                self.beams.append((score, hyp))
+                if len(self) > self.num_beams:
+                    srt = sorted([(s, i) for i, (s, _) in enumerate(self.beams)])
+                    del self.beams[srt[0][1]]
+                    self.worst_score = srt[1][0]
+                else:
+                    self.worst_score = min(score, self.worst_score)
+
+        def is_done(self, best_sum_logprobs, cur_len):
+            if len(self) < self.num_beams:
+                return False
+            if self.early_stopping:
+                return True
+            return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+    class BeamScorer:
+        pass
+
+    class BeamSearchScorer(BeamScorer):
+        def __init__(self, batch_size, num_beams, device, length_penalty=1.0, do_early_stopping=False,
+                     num_beam_hyps_to_keep=1, num_beam_groups=1, **kw):
+            self.num_beams, self.device = num_beams, device
+            self.length_penalty, self.do_early_stopping = length_penalty, do_early_stopping
+            self.num_beam_hyps_to_keep, self.num_beam_groups = num_beam_hyps_to_keep, num_beam_groups
+            self.group_size = num_beams // num_beam_groups
+            self._beam_hyps = [BeamHypotheses(num_beams, length_penalty, do_early_stopping)
+                               for _ in range(batch_size)]
+            self._done = torch.tensor([False] * batch_size, dtype=torch.bool, device=device)
+            if not isinstance(num_beams, int) or num_beams <= 1:
+                if not ALLOW_SINGLE_BEAM:
+                    raise ValueError("`num_beams` has to be an integer strictly greater than 1")
+
+        @property
+        def is_done(self):
+            return bool(self._done.all())
+
+        def process(self, input_ids, next_scores, next_tokens, next_indices, pad_token_id=None, eos_token_id=None):
+            cur_len = input_ids.shape[-1]
+            batch_size = len(self._beam_hyps)
+            nbs = torch.zeros((batch_size, self.group_size), dtype=next_scores.dtype, device=self.device)
+            nbt = torch.zeros((batch_size, self.group_size), dtype=next_tokens.dtype, device=self.device)
+            nbi = torch.zeros((batch_size, self.group_size), dtype=next_indices.dtype, device=self.device)
+            for b, hyp in enumerate(self._beam_hyps):
+                if self._done[b]:
+                    nbs[b, :], nbt[b, :], nbi[b, :] = 0, pad_token_id, 0
+                    continue
+                k = 0
+                for rank, (tok, sc, idx) in enumerate(zip(next_tokens[b], next_scores[b], next_indices[b])):
+                    bb = b * self.group_size + idx
+                    if (eos_token_id is not None) and (tok.item() == eos_token_id):
+                        if rank >= self.group_size:
+                            continue
+                        hyp.add(input_ids[bb].clone(), sc.item())
+                    else:
+                        nbs[b, k], nbt[b, k], nbi[b, k] = sc, tok, bb
+                        k += 1
+                    if k == self.group_size:
+                        break
+                if k < self.group_size:
+                    raise ValueError("not enough non-eos candidates")
+                self._done[b] = self._done[b] or hyp.is_done(next_scores[b].max().item(), cur_len)
+            return {"next_beam_scores": nbs.view(-1), "next_beam_tokens": nbt.view(-1),
+                    "next_beam_indices": nbi.view(-1)}
+
+        def finalize(self, input_ids, final_beam_scores, final_beam_tokens, final_beam_indices, max_length,
+                     pad_token_id=None, eos_token_id=None):
+            batch_size = len(self._beam_hyps)
+            for b, hyp in enumerate(self._beam_hyps):
+                if self._done[b]:
+                    continue
+                for beam_id in range(self.num_beams):
+                    bb = b * self.num_beams + beam_id
+                    hyp.add(input_ids[bb], final_beam_scores[bb].item())
+            keep = self.num_beam_hyps_to_keep
+            sent_lengths = input_ids.new(batch_size * keep)
+            best, best_scores = [], torch.zeros(batch_size * keep, device=self.device, dtype=torch.float32)
+            for i, hyp in enumerate(self._beam_hyps):
+                srt = sorted(hyp.beams, key=lambda x: x[0])
+                for j in range(keep):
+                    score, h = srt.pop()
+                    sent_lengths[keep * i + j] = len(h)
+                    best.append(h)
+                    best_scores[i * keep + j] = score
+            sent_max_len = min(sent_lengths.max().item() + 1, max_length)
+            decoded = input_ids.new(batch_size * keep, sent_max_len)
+            if sent_lengths.min().item() != sent_lengths.max().item():
+                assert pad_token_id is not None
+                decoded.fill_(pad_token_id)
+            for i, h in enumerate(best):
+                decoded[i, : sent_lengths[i]] = h
+                if sent_lengths[i] < max_length:
+                    decoded[i, sent_lengths[i]] = eos_token_id
+            return {"sequences": decoded, "sequence_scores": best_scores}
+
+    gbs = types.ModuleType("transformers.generation_beam_search")
+    gbs.BeamScorer, gbs.BeamSearchScorer, gbs.ConstrainedBeamSearchScorer = BeamScorer, BeamSearchScorer, object
+    sys.modules["transformers.generation_beam_search"] = gbs
+
+    @dataclass
+    class BeamSearchEncoderDecoderOutput(ModelOutput):
+        sequences: torch.LongTensor = None
+        sequences_scores: Optional[torch.FloatTensor] = None
+        scores: Optional[Tuple[torch.FloatTensor]] = None
+        beam_indices: Optional[Tuple] = None
+        encoder_attentions: Optional[Tuple] = None
+        encoder_hidden_states: Optional[Tuple] = None
+        decoder_attentions: Optional[Tuple] = None
+        cross_attentions: Optional[Tuple] = None
+        decoder_hidden_states: Optional[Tuple] = None
+
+    gu = types.ModuleType("transformers.generation_utils")
+    for nm in ["GreedySearchOutput", "SampleOutput", "BeamSearchOutput", "BeamSampleOutput",
+               "BeamSearchDecoderOnlyOutput", "GreedySearchEncoderDecoderOutput",
+               "GreedySearchDecoderOnlyOutput", "SampleEncoderDecoderOutput", "SampleDecoderOnlyOutput",
+               "BeamSampleEncoderDecoderOutput", "BeamSampleDecoderOnlyOutput"]:
+        setattr(gu, nm, object)
+    gu.BeamSearchEncoderDecoderOutput = BeamSearchEncoderDecoderOutput
+    sys.modules["transformers.generation_utils"] = gu
+
+    class LogitsProcessor:
+        pass
+
+    class LogitsProcessorList(list):
+        def __call__(self, input_ids, scores, **kw):
+            for p in self:
+                scores = p(input_ids, scores)
+            return scores
+
+    glp = types.ModuleType("transformers.generation_logits_process")
+    glp.LogitsProcessor, glp.LogitsProcessorList = LogitsProcessor, LogitsProcessorList
+    for nm in ["EncoderNoRepeatNGramLogitsProcessor", "ExponentialDecayLengthPenalty",
+               "ForcedBOSTokenLogitsProcessor", "ForcedEOSTokenLogitsProcessor", "HammingDiversityLogitsProcessor",
+               "InfNanRemoveLogitsProcessor", "MinLengthLogitsProcessor", "NoBadWordsLogitsProcessor",
+               "NoRepeatNGramLogitsProcessor", "PrefixConstrainedLogitsProcessor",
+               "RepetitionPenaltyLogitsProcessor", "TemperatureLogitsWarper", "TopKLogitsWarper",
+               "TopPLogitsWarper", "TypicalLogitsWarper", "LogitNormalization"]:
+        setattr(glp, nm, object)
+    sys.modules["transformers.generation_logits_process"] = glp
+
+    class MaxLengthCriteria:
+        def __init__(self, max_length):
+            self.max_length = max_length
+
+        def __call__(self, input_ids, scores, **kw):
+            return input_ids.shape[-1] >= self.max_length
+
+    class MaxTimeCriteria:
+        pass
+
+    class StoppingCriteria:
+        pass
+
+    class StoppingCriteriaList(list):
+        def __call__(self, input_ids, scores, **kw):
+            return any(c(input_ids, scores) for c in self)
+
+        @property
+        def max_length(self):
+            for c in self:
+                if isinstance(c, MaxLengthCriteria):
+                    return c.max_length
+            return None
+
+    gsc = types.ModuleType("transformers.generation_stopping_criteria")
+    gsc.MaxLengthCriteria, gsc.MaxTimeCriteria = MaxLengthCriteria, MaxTimeCriteria
+    gsc.StoppingCriteria, gsc.StoppingCriteriaList = StoppingCriteria, StoppingCriteriaList
+    gsc.validate_stopping_criteria = lambda sc, ml: sc
+    sys.modules["transformers.generation_stopping_criteria"] = gsc
+
+    gbc = types.ModuleType("transformers.generation_beam_constraints")
+    gbc.Constraint = object
+    gbc.DisjunctiveConstraint = object
+    gbc.PhrasalConstraint = object
+    sys.modules["transformers.generation_beam_constraints"] = gbc
+    return BaseModelOutput, BeamSearchScorer, StoppingCriteriaList, MaxLengthCriteria
+
+
+ALLOW_SINGLE_BEAM = False
+
+
+def load_reference():
+    shim = install_shim()
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # decoder_start_token_path default is relative (t5_generative_retriever.py:51)
+    import importlib
+    # importing t5_pretrainer.tasks.generation pulls transformers.* names through the shim
+    gen = importlib.import_module("t5_pretrainer.tasks.generation")
+    mod = importlib.import_module("t5_pretrainer.modeling.t5_generative_retriever")
+    utils = importlib.import_module("t5_pretrainer.utils.utils")
+    M = mod.T5ForDocIDGeneration
+    M.adjust_logits_during_generation = lambda self, logits, **kw: logits
+
+    def _upd(self, outputs, model_kwargs, is_encoder_decoder=False):
+        model_kwargs["past"] = None
+        return model_kwargs
+
+    M._update_model_kwargs_for_generation = _upd
+    return gen, mod, utils, shim
+
+
+def build_reference_model(mod, dims: synth.ModelDims, sd_np, which="t5-base"):
+    cfg = mod.T5forDocIDConfig(
+        vocab_size=dims.vocab_size, d_model=dims.d_model, d_kv=dims.d_kv, d_ff=dims.d_ff,
+        num_layers=dims.num_layers, num_decoder_layers=dims.num_decoder_layers, num_heads=dims.num_heads,
+        relative_attention_num_buckets=dims.relative_attention_num_buckets,
+        relative_attention_max_distance=dims.relative_attention_max_distance,
+        decoder_vocab_sizes=list(dims.decoder_vocab_sizes), decoding=True,
+        shared_output_input_embeds=dims.shared_output_input_embeds,
+        scaleup_output_hidden=dims.scaleup_output_hidden,
+        decoder_start_token_path=f"./t5_decoder_start_token_embeds/{which}.npy",
+        feed_forward_proj="relu", dropout_rate=0.0, use_cache=False,
+        decoder_start_token_id=0, pad_token_id=0, eos_token_id=1,
+    )
+    cfg._attn_implementation = "eager"
+    model = mod.T5ForDocIDGeneration(cfg)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "decoder.embed_tokens" not in m]  # 5.x-only unused table
+    assert not missing and not unexpected, (missing, unexpected)
+    model.eval()
+    return model
+
+
+@torch.no_grad()
+def run_reference(gen, utils, shim, model, processor, input_ids, attention_mask, B, L, log_softmax=False):
+    BaseModelOutput, BeamSearchScorer, StoppingCriteriaList, MaxLengthCriteria = shim
+    input_ids = torch.as_tensor(input_ids, dtype=torch.long)
+    attention_mask = torch.as_tensor(attention_mask, dtype=torch.long)
+    Q = input_ids.shape[0]
+    enc = model.encoder(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+    scorer = BeamSearchScorer(batch_size=Q, num_beams=B, device=torch.device("cpu"), length_penalty=1.0,
+                              do_early_stopping=False, num_beam_hyps_to_keep=B)
+    out = gen.beam_search_for_constrained_prefix(
+        model, processor, torch.zeros((Q * B, 1), dtype=torch.long), scorer,
+        stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(L + 1)]),
+        output_scores=True, return_dict_in_generate=True,
+        apply_log_softmax_for_scores=log_softmax,
+        encoder_outputs=BaseModelOutput(last_hidden_state=enc.repeat_interleave(B, 0)),
+        attention_mask=attention_mask.repeat_interleave(B, 0), use_cache=False)
+    strs = utils.convert_ptsmtids_to_strsmtid(out.sequences.view(-1, B, L + 1), L)
+    # per-step processed scores (float64) -> per-step sorted top-(B+1) margins are derived by tests
+    step_scores = np.stack([s.numpy() for s in out.scores])  # [L, Q*B, V] float64 (without beam score)
+    return enc.numpy(), out.sequences.numpy(), out.sequences_scores.numpy(), strs, step_scores
+
+
+def reference_trie(gen, codes):
+    """Build the reference's own structures from the synthetic code matrix, with the reference's
+    dict-building loop restated (evaluate.py:410-424 cannot be imported: top-level `import faiss`)."""
+    d2s = synth.codes_to_docid_to_smtid(codes)
+    L = codes.shape[1]
+    lst = [dict() for _ in range(L)]
+    for _docid, smtids in d2s.items():
+        for i in range(len(smtids) - 1):
+            key = "_".join(str(x) for x in smtids[: i + 1])
+            lst[i].setdefault(key, set()).add(int(smtids[i + 1]))
+    lst = [{k: list(v) for k, v in lvl.items()} for lvl in lst]
+    return d2s, lst
+
+
+# ----------------------------------------------------------------------------- fixtures
+CASES = {
+    # name: (dims factory kwargs, N docs, Q, B, L, V, seed, extras)
+    "g1_mini_b4_l8": dict(kind="mini", N=1000, Q=8, B=4, L=8, V=256, seed=101),
+    "g1_mini_b10_l32": dict(kind="mini", N=1000, Q=6, B=10, L=32, V=256, seed=102),
+    "g1_mini_b2_l4_v1024": dict(kind="mini", N=1000, Q=4, B=2, L=4, V=1024, seed=103),
+    "g1_mini_b10_l8_tiny_trie": dict(kind="mini", N=7, Q=3, B=10, L=8, V=256, seed=104),  # < B leaves
+    "g1_mini_b4_l8_logsoftmax": dict(kind="mini", N=1000, Q=4, B=4, L=8, V=256, seed=105, log_softmax=True),
+    "g1_mini_b4_l8_shared": dict(kind="mini", N=500, Q=4, B=4, L=8, V=256, seed=106, shared=True),
+    "g2_base_b10_l32": dict(kind="base", N=1000, Q=4, B=10, L=32, V=256, seed=201),
+}
+
+
+def make_case(name, spec, gen, mod, utils, shim):
+    kind, N, Q, B, L, V, seed = spec["kind"], spec["N"], spec["Q"], spec["B"], spec["L"], spec["V"], spec["seed"]
+    shared = spec.get("shared", False)
+    if kind == "mini":
+        dims = synth.mini_dims(L=L, V=V, shared_output_input_embeds=shared)
+    elif kind == "base":
+        dims = synth.t5_base_dims(L=L, V=V, vocab_size=2048, shared_output_input_embeds=shared)
+    else:
+        raise ValueError(kind)
+    t0 = time.time()
+    sd = synth.make_state_dict(dims, seed=seed)
+    model = build_reference_model(mod, dims, sd)
+    codes = synth.make_codes(N, L, V, seed=seed)
+    d2s, lst = reference_trie(gen, codes)
+    processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
+    ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=20)
+    enc, seqs, scores, strs, step_scores = run_reference(
+        gen, utils, shim, model, processor, ids, mask, B, L, spec.get("log_softmax", False))
+    # processor-only vectors (G4): valid and invalid prefixes at a few depths
+    pm = {}
+    for T in sorted({1, 2, min(3, L), L}):
+        pref = np.zeros((6, T), dtype=np.int64)
+        for r in range(6):
+            if T > 1:
+                pref[r, 1:] = codes[(r * 131) % N, : T - 1]
+        if T > 1:
+            pref[5, T - 1] = (int(pref[5, T - 1]) + 1) % V  # most likely an unknown prefix
+        m = processor(torch.from_numpy(pref), torch.zeros((6, V)))
+        pm[f"pm_prefix_T{T}"] = pref
+        pm[f"pm_mask_T{T}"] = np.packbits(m.numpy().astype(np.uint8), axis=1)
+    # margins: for each step/query the sorted top-(B+1) cumulative candidates are recomputable only
+    # with beam scores; store the reference's per-step processed scores compactly (float64 -> top 2B
+    # per row is not enough), so store full scores only for small cases.
+    out = dict(
+        spec=json.dumps(dict(spec, name=name, dims=dims.__dict__)),
+        input_ids=ids, attention_mask=mask, codes=codes,
+        encoder_out=enc.astype(np.float32), sequences=seqs.astype(np.int64),
+        sequences_scores=scores.astype(np.float32), smtid_strings=np.array(strs),
+        **pm,
+    )
+    if step_scores.size <= 4_000_000:
+        out["step_scores"] = step_scores
+    else:
+        out["step_scores_first"] = step_scores[:2]
+        out["step_scores_last"] = step_scores[-1:]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: {time.time() - t0:.1f}s -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    gen, mod, utils, shim = load_reference()
+    for name, spec in CASES.items():
+        if args.only and args.only != name:
+            continue
+        make_case(name, spec, gen, mod, utils, shim)
+
+
+if __name__ == "__main__":
+    main()
