@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Bench of the trie-constrained beam-search retrieval path on MI355X.
+
+A "step" is one pass of the hot path (T5 encoder + L fused decode/select steps, rpr_search) over
+one batch of Q synthetic MSMARCO-dev-shaped queries; the workload is BASELINE.json configs[1]:
+t5-base dims, 8 841 823-doc synthetic docid trie (32 x 256 codes), beam = 10, len = 32, fp32.
+Inputs (token ids / masks of every step's batch, weights, trie) are resident in HBM before the
+timed region. value = queries/s over all ranks (weak scaling: every rank runs K steps of Q queries
+on its own shard, model + trie replicated, one RCCL all_gather of the ranked results at the end).
+
+  python bench.py [--gpus N --steps K --warmup W --batch Q --beams B --len L --docs N_DOCS]
+
+Extra legs on rank 0 (outside the timed region):
+  roofline     one eager step with hipEvents around every launch on the launch stream (the library's
+               profile mode); the dominant kernel is the fp32-MFMA linear layer (gemm_f32_kernel).
+  cpu_baseline the oracle "port" of the reference loop (no KV cache, dict+CSR float64 mask, top-2B,
+               Python scorer) on the host cores, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MSMARCO_DOCS = 8_841_823
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_TBS = 8.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes_per_query(dims, Q, B, L, Lq, s_w=4, s_kv=4):
+    """SURVEY.md §8(d) formula (KV-cached algorithm, weights read once per step per batch of Q)."""
+    d, inner, dff = dims.d_model, dims.inner, dims.d_ff
+    ne, nd, V = dims.num_layers, dims.num_decoder_layers, dims.decoder_vocab_sizes[0]
+    w_enc = ne * (4 * d * inner + 2 * d * dff)
+    w_xkv = nd * 2 * d * inner
+    w_dec = nd * (6 * d * inner + 2 * d * dff)
+    kvrow = nd * 2 * inner
+    weights = ((w_enc + w_xkv) * s_w + L * w_dec * s_w + L * V * d * s_w) / Q
+    self_r = B * (L * (L + 1) / 2) * kvrow * s_kv
+    self_w = B * L * kvrow * s_kv
+    cross_r = L * Lq * kvrow * s_kv
+    cross_w = Lq * kvrow * s_kv
+    trie = B * L * 40
+    out = B * (4 * L + 4)
+    return weights + self_r + self_w + cross_r + cross_w + trie + out
+
+
+def algorithmic_flops_per_query(dims, B, L, Lq):
+    d, inner, dff = dims.d_model, dims.inner, dims.d_ff
+    ne, nd, V = dims.num_layers, dims.num_decoder_layers, dims.decoder_vocab_sizes[0]
+    w_enc = ne * (4 * d * inner + 2 * d * dff)
+    w_xkv = nd * 2 * d * inner
+    w_dec = nd * (6 * d * inner + 2 * d * dff)
+    return (2 * w_enc * Lq + 2 * w_xkv * Lq + B * L * 2 * w_dec + B * L * 2 * V * d
+            + 4 * Lq * Lq * inner * ne + 4 * inner * nd * B * L * (L + 1) / 2 + 4 * inner * nd * B * L * Lq)
+
+
+def cpu_baseline(sd, dims, B, L, n_queries=4, trie_docs=10_000):
+    """Reference-faithful CPU loop (oracle 'port') on the host cores; bounded sample.
+
+    The GPU box has far more cores than these small fp32 GEMMs can use (torch CPU gets *slower*
+    beyond a few dozen threads), so the thread count is chosen by timing a short warm-up at
+    8/16/32/64 threads and keeping the fastest; ``cores`` reports the threads actually used."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd.utils import synth
+    host_cores = len(os.sched_getaffinity(0))
+    V = dims.decoder_vocab_sizes[0]
+    codes = synth.make_codes(trie_docs, L, V)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    model = t5_ref.T5Ref(sd, dims)
+    ids, mask = synth.make_queries(n_queries + 1, vocab_size=dims.vocab_size, seed=77)
+    best_t, best_dt = None, None
+    for th in [t for t in (8, 16, 32, 64) if t <= host_cores] or [host_cores]:
+        torch.set_num_threads(th)
+        beam_ref.beam_search_ref(model, pm, ids[:1], mask[:1], B, 2)  # thread-pool spin-up
+        t0 = time.time()
+        beam_ref.beam_search_ref(model, pm, ids[:1], mask[:1], B, min(L, 6))
+        dt = time.time() - t0
+        log(f"[bench] cpu_baseline probe: {th} threads -> {dt:.2f}s (1 query, {min(L, 6)} steps)")
+        if best_dt is None or dt < best_dt:
+            best_t, best_dt = th, dt
+    torch.set_num_threads(best_t)
+    t0 = time.time()
+    beam_ref.beam_search_ref(model, pm, ids[1:], mask[1:], B, L)
+    dt = time.time() - t0
+    log(f"[bench] cpu_baseline: {n_queries} queries in {dt:.1f}s on {best_t} threads")
+    return {"value": n_queries / dt, "unit": "queries/s", "cores": best_t, "kind": "port",
+            "sample": f"{n_queries} queries in one batch, t5-base dims fp32, beams={B}, len={L}, "
+                      f"{trie_docs}-doc dict+CSR trie (the reference's dict structure for 8.8M docs does not fit "
+                      f"host RAM), full-prefix decoder recompute like the reference (no KV cache); "
+                      f"{dt:.1f}s wall on {best_t} threads (fastest of 8/16/32/64; host has {host_cores} cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="queries in flight per step per GPU")
+    ap.add_argument("--beams", type=int, default=10)
+    ap.add_argument("--len", type=int, default=32, dest="L")
+    ap.add_argument("--docs", type=int, default=MSMARCO_DOCS)
+    ap.add_argument("--model", default="t5-base", choices=["t5-base", "t5-large"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from ripor_amd import engine as E
+    from ripor_amd.dataset.sharding import shard_indices
+    from ripor_amd.utils import synth
+
+    Q, B, L, K, W = args.batch, args.beams, args.L, args.steps, args.warmup
+    dims = synth.t5_base_dims(L=L) if args.model == "t5-base" else synth.t5_large_dims(L=L)
+    V = dims.decoder_vocab_sizes[0]
+    t0 = time.time()
+    sd = synth.make_state_dict(dims)
+    ctx = E.Context.get(local_rank)
+    model = E.DeviceModel(ctx, sd, dims)
+    log(f"[bench r{rank}] weights ({sum(v.size for v in sd.values()) / 1e6:.1f} M params) on device in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    codes = synth.make_codes_fast(args.docs, L, V)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    del codes
+    log(f"[bench r{rank}] trie of {trie.N:,} docs built in {time.time() - t0:.1f}s")
+
+    # queries: a pool of MSMARCO-dev size, sharded like DistributedSampler(shuffle=False); every step
+    # takes the next Q queries of this rank's shard (wrapping), padded to the batch maximum.
+    pool_ids, pool_mask = synth.make_queries(6980, vocab_size=dims.vocab_size)
+    shard = shard_indices(6980, world, rank)
+    batches = []
+    for step in range(W + K + 1):
+        sel = [shard[(step * Q + i) % len(shard)] for i in range(Q)]
+        ids, mask = pool_ids[sel], pool_mask[sel]
+        lq = int(mask.sum(1).max())
+        lq = (lq + 7) // 8 * 8  # bucket Lq so the captured graphs are reused across steps
+        ids = np.pad(ids, ((0, 0), (0, max(0, lq - ids.shape[1]))))[:, :lq]
+        mask = np.pad(mask, ((0, 0), (0, max(0, lq - mask.shape[1]))))[:, :lq]
+        batches.append((torch.from_numpy(ids).to(dev, torch.int32), torch.from_numpy(mask).to(dev, torch.int32), lq))
+    mean_len = float(pool_mask.sum(1).mean())
+
+    def run_step(i):
+        ids, mask, _ = batches[i]
+        return E.search(model, trie, ids, mask, B, L, use_graph=not args.no_graph)
+
+    for i in range(W):
+        res = run_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    results = []
+    for i in range(K):
+        results.append(run_step(W + i))
+    if world > 1:  # the path's only collective: gather the ranked results (run.json merge)
+        tok = torch.stack([r.tokens for r in results])
+        sc = torch.stack([r.scores for r in results])
+        tok_all = torch.empty((world,) + tuple(tok.shape), dtype=tok.dtype, device=dev)
+        sc_all = torch.empty((world,) + tuple(sc.shape), dtype=sc.dtype, device=dev)
+        dist.all_gather_into_tensor(tok_all, tok)
+        dist.all_gather_into_tensor(sc_all, sc)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the timed outputs: every returned smtid of the last step is a trie leaf range
+    last = results[-1]
+    n_leaf = int((last.row_hi > last.row_lo).sum().item())
+    if rank == 0:
+        log(f"[bench] last step: {n_leaf}/{Q * B} returned smtids are valid trie leaves; "
+            f"workspace {ctx.workspace_bytes() / 2**30:.2f} GiB")
+
+    out = None
+    if rank == 0:
+        lq_used = batches[W][2]
+        ms_per_step = elapsed / K * 1e3
+        value = world * Q * K / elapsed
+        abytes = algorithmic_bytes_per_query(dims, Q, B, L, lq_used)
+        aflops = algorithmic_flops_per_query(dims, B, L, lq_used)
+        out = {
+            "metric": "queries/sec, t5-base beam=10 len=32 over 8.8M-doc trie (constrained beam search, fp32)",
+            "value": value, "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} dims, {trie.N}-doc synthetic 32x256 docid trie, beams={B}, len={L}, "
+                                   f"{Q} queries/step/GPU (MSMARCO-dev-shaped, mean {mean_len:.1f} tokens, padded to {lq_used})",
+                       "queries_per_step_per_gpu": Q, "beams": B, "len": L, "docs": trie.N, "enc_len_padded": lq_used,
+                       "parallelism": f"query-sharded x{world}, replicated weights+trie, final RCCL all_gather",
+                       "hipgraph": not args.no_graph},
+            "algorithmic": {"bytes_per_query": abytes, "flops_per_query": aflops,
+                            "hbm_frac_whole_step": abytes * Q / (ms_per_step * 1e-3) / (PEAK_HBM_TBS * 1e12),
+                            "mfma_f32_frac_whole_step": aflops * Q / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
+        }
+        log(f"[bench] timed region done: {value:.1f} queries/s, {ms_per_step:.1f} ms/step")
+        if not args.no_roofline:
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            run_step(W)  # one eager step, hipEvents around every launch on the launch stream
+            torch.cuda.synchronize()
+            stats = ctx.profile_get()
+            ctx.profile_enable(False)
+            log("[bench] roofline leg done")
+            g = stats["gemm_f32"]
+            ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "rpr::gemm_f32_kernel", "bound": "mfma", "achieved": ach,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": None, "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
+                               "launches_per_step": g["launches"],
+                               "flops_per_launch": g["flops"] / max(1, g["launches"])}
+            tot = sum(s["total_ms"] for s in stats.values())
+            out["kernel_breakdown_ms"] = {k: round(s["total_ms"], 3) for k, s in stats.items()}
+            out["kernel_breakdown_ms"]["sum"] = round(tot, 3)
+            sa = stats["dec_self_attn"]
+            if sa["total_ms"] > 0:
+                out["self_attn_hbm"] = {"achieved_GBs": sa["bytes"] / (sa["total_ms"] * 1e-3) / 1e9,
+                                        "frac_of_8TBs": sa["bytes"] / (sa["total_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sd, dims, B, L)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": len(os.sched_getaffinity(0)),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,13 @@ def load() -> C.CDLL:
         raise RiporHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the search path.")
+    # torch ships its own libamdhip64.so.7; the library must share that HIP runtime instance so
+    # torch device pointers / streams are valid inside it. Importing torch first makes the
+    # dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    import torch  # noqa: F401
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

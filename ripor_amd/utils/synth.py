@@ -225,3 +225,19 @@ def make_queries(Q: int, vocab_size: int = 32128, seed: int = SEED, mean_len: fl
     ids = ids * mask
     ids[np.arange(Q), lens - 1] = 1
     return ids, mask
+
+
+def make_codes_fast(N: int, L: int, V: int, seed: int = SEED) -> np.ndarray:
+    """Large-trie variant of :func:`make_codes` (8.8 M x 32): one hash yields four codes
+    (16 bits each, reduced mod V), ~4x fewer hash evaluations. Distribution: i.i.d. uniform."""
+    n = N * L
+    n4 = (n + 3) // 4
+    out = np.empty(n4 * 4, dtype=np.uint16)
+    chunk = 1 << 23
+    for s in range(0, n4, chunk):
+        e = min(n4, s + chunk)
+        h = hash_u64(f"codes_fast/{N}x{L}x{V}", e - s, seed, offset=s)
+        out[4 * s:4 * e] = h.view(np.uint16)
+    if V < 65536:
+        out %= np.uint16(V)
+    return out[:n].reshape(N, L)
