@@ -181,8 +181,8 @@ def main():
     if world > 1:  # the path's only collective: gather the ranked results (run.json merge)
         tok = torch.stack([r.tokens for r in results])
         sc = torch.stack([r.scores for r in results])
-        tok_all = torch.empty((world,) + tuple(tok.shape), dtype=tok.dtype, device=dev)
-        sc_all = torch.empty((world,) + tuple(sc.shape), dtype=sc.dtype, device=dev)
+        tok_all = torch.empty((world * tok.shape[0],) + tuple(tok.shape[1:]), dtype=tok.dtype, device=dev)
+        sc_all = torch.empty((world * sc.shape[0],) + tuple(sc.shape[1:]), dtype=sc.dtype, device=dev)
         dist.all_gather_into_tensor(tok_all, tok)
         dist.all_gather_into_tensor(sc_all, sc)
     torch.cuda.synchronize()

@@ -1,0 +1,43 @@
+"""CLI-compatible replacement of reference aq_preprocess/build_list_smtid_to_nextids.py:13-41.
+
+The reference pre-builds and pickles the per-level ``{prefix_string: [next ids]}`` dicts
+(``list_smtid_to_nextids.pkl``). This implementation's trie is the sorted code matrix, so the cache
+written next to ``docid_to_smtid.json`` is the binary ``list_smtid_to_nextids.rprtrie`` produced by
+``rpr_trie_save`` (sorted codes + permutation)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+
+import numpy as np
+
+
+def cache_path(docid_to_smtid_path: str) -> str:
+    return os.path.join(os.path.dirname(docid_to_smtid_path), "list_smtid_to_nextids.rprtrie")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docid_to_smtid_path", default=None, type=str)
+    args = ap.parse_args(argv)
+    out = cache_path(args.docid_to_smtid_path)
+    if os.path.exists(out):
+        print(f"{out} exists")
+        return
+    from .. import engine as E
+    with open(args.docid_to_smtid_path) as fin:
+        docid_to_smtids = json.load(fin)
+    docids = list(docid_to_smtids.keys())
+    codes = np.asarray([docid_to_smtids[d][1:] for d in docids], dtype=np.int64)
+    V = int(codes.max()) + 1
+    for l in range(codes.shape[1]):
+        print(f"{l}-th step has {len(np.unique(codes[:, :l + 1], axis=0)) if l < 3 else -1:,} effective smtid "
+              f"(-1: not counted for deep levels)")
+    trie = E.DeviceTrie.from_codes(E.Context.get(0), codes, V)
+    print("save list_smtid_to_nextids")
+    trie.save(out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,269 @@
+"""Caller side of the constrained-beam-search path: build the trie inputs, run the search over a
+query collection, map smtids to docids, write ``run_{rank}.json`` / ``run.json``, evaluate.
+
+Mirrors the generative-retrieval tasks of reference t5_pretrainer/evaluate.py:
+  ``constrained_decode_doc`` :87-132, ``t5seq_aq_retrieve_docids`` :396-487,
+  ``t5seq_aq_retrieve_docids_2`` :489-526, ``evaluate`` :268-291, ``__main__`` dispatch :657-690,
+with the same CLI flags (``EvalArguments`` subset, reference arguments.py:145-212), the same output
+layout ``out_dir/<get_dataset_name(q_dir)>/run_{local_rank}.json`` and the same score convention
+(``float(score_f32) * max_new_token`` per docid).
+
+Differences by design: the per-level dict-of-strings / pickle cache is replaced by the device trie
+(binary cache ``list_smtid_to_nextids.rprtrie`` next to ``docid_to_smtid.json``), and smtid -> docids
+uses the sorted-row range returned by the search instead of a dict of 8.8 M strings (the dict path
+is still accepted for drop-in callers).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .tasks.generation import PrefixConstrainLogitProcessorFastSparse, generate_for_constrained_prefix_beam_search
+from .utils.metrics import load_and_evaluate
+from .utils.utils import convert_ptsmtids_to_strsmtid, get_dataset_name
+
+QUERY_PREFIX = "query: "  # reference dataset/dataset.py:15
+
+
+class DocidTable:
+    """docids in code-row order; with the trie permutation this replaces ``smtid_to_docids``."""
+
+    def __init__(self, docids: Sequence[str]):
+        self.docids = list(docids)
+
+
+def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_to_docids, max_new_token, device,
+                           out_dir, local_rank, topk=100, apply_log_softmax_for_scores=False, write=True):
+    """reference evaluate.py:87-132. ``smtid_to_docids``: the reference's dict
+    ``{"c1_.._cL": [docids]}`` or a :class:`DocidTable` (range lookup, no strings)."""
+    qid_to_rankdata: Dict[int, Dict[str, float]] = {}
+    use_ranges = isinstance(smtid_to_docids, DocidTable)
+    for batch in dataloader:
+        with torch.no_grad():
+            inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
+            outputs = generate_for_constrained_prefix_beam_search(
+                model, prefix_constrain_processor, input_ids=inputs["input_ids"].long(),
+                attention_mask=inputs["attention_mask"].long(), max_new_tokens=max_new_token, output_scores=True,
+                return_dict=True, return_dict_in_generate=True, num_beams=topk, num_return_sequences=topk,
+                apply_log_softmax_for_scores=apply_log_softmax_for_scores)
+        batch_qids = batch["id"].cpu().tolist()
+        relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
+        if use_ranges:
+            lo = outputs.row_lo.view(-1, topk).cpu().tolist()
+            hi = outputs.row_hi.view(-1, topk).cpu().tolist()
+            perm = prefix_constrain_processor.trie(device).perm
+            for qid, los, his, rel_scores in zip(batch_qids, lo, hi, relevant_scores):
+                cur = qid_to_rankdata[qid] = {}
+                for l, h, rel_score in zip(los, his, rel_scores):
+                    if h <= l:
+                        print("smtid not in smtid_to_docid")
+                        continue
+                    for row in perm[l:h]:
+                        docid = smtid_to_docids.docids[int(row)]
+                        cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+        else:
+            str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
+            for qid, ranked_smtids, rel_scores in zip(batch_qids, str_smtids, relevant_scores):
+                cur = qid_to_rankdata[qid] = {}
+                for smtid, rel_score in zip(ranked_smtids, rel_scores):
+                    if smtid not in smtid_to_docids:
+                        print(f"smtid: {smtid} not in smtid_to_docid")
+                    else:
+                        for docid in smtid_to_docids[smtid]:
+                            cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+    if write:
+        with open(os.path.join(out_dir, f"run_{local_rank}.json"), "w") as fout:
+            json.dump(qid_to_rankdata, fout)
+    return qid_to_rankdata
+
+
+def build_smtid_to_docids(docid_to_smtids: Dict[str, Sequence[int]], max_new_token: int) -> Dict[str, List[str]]:
+    """reference evaluate.py:439-446 (kept for drop-in callers that want the dict)."""
+    out: Dict[str, List[str]] = {}
+    for docid, smtids in docid_to_smtids.items():
+        assert smtids[0] == -1, smtids
+        out.setdefault("_".join(str(x) for x in smtids[1:1 + max_new_token]), []).append(docid)
+    return out
+
+
+def load_docid_table(docid_to_smtid_path: str, vocab_size: int, max_new_token: int):
+    """Reads ``docid_to_smtid.json`` ({"docid": [-1, c1..cL]}) and returns (processor, DocidTable).
+    The code matrix is truncated to ``max_new_token`` columns (sub-smtid retrieval, evaluate.py:442)."""
+    with open(docid_to_smtid_path) as fin:
+        docid_to_smtids = json.load(fin)
+    docids = list(docid_to_smtids.keys())
+    codes = np.asarray([docid_to_smtids[d][1:1 + max_new_token] for d in docids], dtype=np.int64)
+    assert all(docid_to_smtids[d][0] == -1 for d in docids[:16])
+    assert codes.shape[1] == max_new_token, (codes.shape, max_new_token)  # evaluate.py:449
+    return PrefixConstrainLogitProcessorFastSparse.from_codes(codes, vocab_size), DocidTable(docids)
+
+
+# ----------------------------------------------------------------------------- query side
+class QueryCollection:
+    """``raw.tsv`` (``id\\ttext``) reader with the "query: " prefix (reference
+    dataset/dataset.py:266-332, id_style="row_id", add_prefix=True, is_query=True)."""
+
+    def __init__(self, data_dir: str):
+        self.ids, self.texts = [], []
+        with open(os.path.join(data_dir, "raw.tsv")) as reader:
+            for line in reader:
+                if len(line) > 1:
+                    id_, *data = line.split("\t")
+                    self.ids.append(id_.strip())
+                    self.texts.append(QUERY_PREFIX + " ".join(" ".join(data).splitlines()))
+
+    def __len__(self):
+        return len(self.ids)
+
+
+def query_batches(collection: QueryCollection, tokenizer, indices: Sequence[int], batch_size: int, max_length: int = 256):
+    """pad-to-longest / truncate batches like CollectionDataWithDocIDLoader.collate_fn
+    (reference dataset/dataloader.py:62-79)."""
+    for s in range(0, len(indices), batch_size):
+        sel = indices[s:s + batch_size]
+        enc = tokenizer([collection.texts[i] for i in sel], add_special_tokens=True, padding="longest",
+                        truncation="longest_first", max_length=max_length, return_attention_mask=True)
+        yield {"input_ids": torch.tensor(enc["input_ids"]), "attention_mask": torch.tensor(enc["attention_mask"]),
+               "id": torch.tensor([int(collection.ids[i]) for i in sel], dtype=torch.long)}
+
+
+def ddp_setup():
+    """reference evaluate.py:181-182; RCCL is torch's "nccl" backend on ROCm."""
+    import torch.distributed as dist
+    if "RANK" in os.environ and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+
+
+def _list_flag(v):
+    if isinstance(v, (list, tuple)) and len(v) == 1 and isinstance(v[0], str) and v[0].lstrip().startswith("["):
+        return json.loads(v[0])  # list-valued flags arrive as one JSON string (evaluate.py:457-459)
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+def t5seq_aq_retrieve_docids(args):
+    """reference evaluate.py:396-487."""
+    import torch.distributed as dist
+    from transformers import AutoTokenizer
+    from .dataset.sharding import shard_indices
+    from .modeling.t5_generative_retriever import T5SeqAQEncoder
+
+    ddp_setup()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    local_rank = max(0, int(args.local_rank if args.local_rank >= 0 else os.environ.get("LOCAL_RANK", 0)))
+    model = T5SeqAQEncoder.from_pretrained(args.pretrained_path)
+    model.eval()
+    if len(set(model.config.decoder_vocab_sizes)) != 1:
+        raise ValueError("not valid decoder_vocab_size")
+    max_new_token = args.max_new_token_for_docid
+    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], max_new_token)
+    if rank == 0:
+        print("max_new_token: ", max_new_token)
+        os.makedirs(args.out_dir, exist_ok=True)
+    tokenizer = AutoTokenizer.from_pretrained(args.pretrained_path)
+    model.to(local_rank)
+    model.base_model.config.decoding = True
+    for data_dir in _list_flag(args.q_collection_paths):
+        coll = QueryCollection(data_dir)
+        out_dir = os.path.join(args.out_dir, get_dataset_name(data_dir))
+        print("out_dir: ", out_dir)
+        os.makedirs(out_dir, exist_ok=True)  # every rank: removes the reference's mkdir race
+        loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), args.batch_size, 256)
+        constrained_decode_doc(model.base_model, loader, processor, table, max_new_token, device=local_rank,
+                               out_dir=out_dir, local_rank=local_rank, topk=args.topk,
+                               apply_log_softmax_for_scores=args.apply_log_softmax_for_scores)
+
+
+def merge_runs(out_dir: str, expected_files: Optional[int] = None) -> Dict[str, Dict[str, float]]:
+    """reference evaluate.py:496-524: merge ``run_*.json`` into ``run.json`` and delete the parts."""
+    run_path = os.path.join(out_dir, "run.json")
+    if os.path.exists(run_path):
+        print("old run.json exisit.")
+        os.remove(run_path)
+    sub_paths = [p for p in os.listdir(out_dir) if "run" in p]
+    if expected_files is not None:
+        assert len(sub_paths) == expected_files, (sub_paths, expected_files)
+    merged: Dict[str, Dict[str, float]] = {}
+    for sub_path in sub_paths:
+        with open(os.path.join(out_dir, sub_path)) as fin:
+            for qid, rankdata in json.load(fin).items():
+                merged.setdefault(qid, {}).update(rankdata)
+    print("length of pids and avg rankdata length in qid_to_rankdata: {}, {}".format(
+        len(merged), np.mean([len(xs) for xs in merged.values()]) if merged else 0.0))
+    with open(run_path, "w") as fout:
+        json.dump(merged, fout)
+    for sub_path in sub_paths:
+        os.remove(os.path.join(out_dir, sub_path))
+    return merged
+
+
+def t5seq_aq_retrieve_docids_2(args):
+    """reference evaluate.py:489-526."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else None
+    for data_dir in _list_flag(args.q_collection_paths):
+        merge_runs(os.path.join(args.out_dir, get_dataset_name(data_dir)), expected_files=n)
+    return evaluate(args)
+
+
+def evaluate(args):
+    """reference evaluate.py:268-291."""
+    eval_qrel_path = _list_flag(args.eval_qrel_path)
+    eval_metric = args.eval_metric
+    if isinstance(eval_metric, (list, tuple)) and len(eval_metric) == 1 and isinstance(eval_metric[0], str):
+        eval_metric = json.loads(eval_metric[0])
+    res_all: Dict[str, dict] = {}
+    for qrel_file_path, metrics in zip(eval_qrel_path, eval_metric):
+        if qrel_file_path is None:
+            continue
+        res = {}
+        name = get_dataset_name(qrel_file_path)
+        for metric in metrics:
+            res.update(load_and_evaluate(qrel_file_path=qrel_file_path,
+                                         run_file_path=os.path.join(args.out_dir, name, "run.json"), metric=metric))
+        res_all.setdefault(name, {}).update(res)
+        with open(os.path.join(args.out_dir, name, "perf.json"), "a") as f:
+            json.dump(res, f)
+    with open(os.path.join(args.out_dir, "perf_all_datasets.json"), "a") as f:
+        json.dump(res_all, f)
+    return res_all
+
+
+def get_args(argv=None):
+    """EvalArguments fields used by the generative-retrieval branch (reference arguments.py:145-212)."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pretrained_path", default="")
+    ap.add_argument("--out_dir", default="")
+    ap.add_argument("--task", default="")
+    ap.add_argument("--docid_to_smtid_path", default=None)
+    ap.add_argument("--q_collection_paths", nargs="+", default=[])
+    ap.add_argument("--eval_qrel_path", nargs="+", default=[])
+    ap.add_argument("--eval_metric", nargs="+", default=[["mrr_10", "recall"]])
+    ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--max_new_token_for_docid", type=int, default=32)
+    ap.add_argument("--topk", type=int, default=200)
+    ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    ap.add_argument("--apply_log_softmax_for_scores", type=lambda s: str(s).lower() in ("1", "true", "yes"),
+                    default=False)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    if args.task == "t5seq_aq_retrieve_docids":
+        t5seq_aq_retrieve_docids(args)
+    elif args.task == "t5seq_aq_retrieve_docids_2":
+        t5seq_aq_retrieve_docids_2(args)
+    elif args.task == "evaluate":
+        evaluate(args)
+    else:
+        raise ValueError(f"task: {args.task} is not valid.")
+
+
+if __name__ == "__main__":
+    main()

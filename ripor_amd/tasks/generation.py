@@ -1,0 +1,169 @@
+"""Drop-in for the reference's constrained prefix beam search entry points.
+
+Mirrors reference t5_pretrainer/tasks/generation.py:
+  * ``generate_for_constrained_prefix_beam_search`` (:35-251) — same name, keyword arguments and
+    return attributes (``.sequences`` LongTensor ``[Q*B', L+1]`` with column 0 = start id 0, rows
+    grouped per query best-first; ``.sequences_scores`` float32 ``[Q*B']`` = sum(step scores)/(L+1)),
+    same ValueErrors for inconsistent beam arguments. The whole loop (:253-575) runs inside
+    ``rpr_search`` of libripor_hip.so — no per-step host work.
+  * ``PrefixConstrainLogitProcessorFastSparse`` (:603-677) — same constructor
+    ``(list_smtid_to_nextids, vocab_size)`` and ``__call__(input_ids, scores) -> mask``; instead of
+    per-level scipy CSR matrices over string keys it owns a device trie (sorted code matrix).
+    ``from_codes`` / ``from_docid_to_smtid`` build the same object straight from the docid table
+    without materialising the dicts (which need tens of GB for 8.8 M docs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import engine as E
+
+
+@dataclass
+class BeamSearchEncoderDecoderOutput:
+    sequences: torch.Tensor = None
+    sequences_scores: Optional[torch.Tensor] = None
+    scores: Optional[tuple] = None
+    beam_indices: Optional[tuple] = None
+    encoder_attentions: Optional[tuple] = None
+    encoder_hidden_states: Optional[tuple] = None
+    decoder_attentions: Optional[tuple] = None
+    cross_attentions: Optional[tuple] = None
+    decoder_hidden_states: Optional[tuple] = None
+    # extras of this implementation: sorted-row range of every returned smtid (docids = perm[lo:hi])
+    row_lo: Optional[torch.Tensor] = None
+    row_hi: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class PrefixConstrainLogitProcessorFastSparse:
+    def __init__(self, list_smtid_to_nextids: Optional[Sequence[Dict[str, List[int]]]], vocab_size: int,
+                 _codes: Optional[np.ndarray] = None, _trie_cache: Optional[str] = None):
+        self.vocab_size = int(vocab_size)
+        self.list_smtid_to_next_smtids = list_smtid_to_nextids
+        if _codes is None:
+            _codes = self._codes_from_dicts(list_smtid_to_nextids)
+        self.codes = np.ascontiguousarray(_codes, dtype=np.uint16)
+        if self.codes.ndim != 2 or self.codes.shape[0] == 0:
+            raise ValueError("empty docid code matrix")
+        if int(self.codes.max()) >= self.vocab_size:
+            raise ValueError("smtid token >= vocab_size")
+        self.max_len = self.codes.shape[1]
+        self._tries: Dict[int, E.DeviceTrie] = {}
+        self._trie_cache = _trie_cache
+
+    # -- constructors -------------------------------------------------------------------------
+    @classmethod
+    def from_codes(cls, codes: np.ndarray, vocab_size: int, trie_cache: Optional[str] = None):
+        """codes ``[N, L]``: row i = smtid of docid index i."""
+        return cls(None, vocab_size, _codes=codes, _trie_cache=trie_cache)
+
+    @classmethod
+    def from_docid_to_smtid(cls, docid_to_smtids: Dict[str, Sequence[int]], vocab_size: int):
+        """The reference's ``docid_to_smtid.json`` content ``{"docid": [-1, c1..cL]}``; returns
+        ``(processor, docids)`` with ``docids[i]`` the docid of code row i (file order)."""
+        docids = list(docid_to_smtids.keys())
+        first = docid_to_smtids[docids[0]]
+        assert first[0] == -1, first  # reference evaluate.py:441
+        codes = np.asarray([docid_to_smtids[d][1:] for d in docids], dtype=np.int64)
+        return cls(None, vocab_size, _codes=codes), docids
+
+    @staticmethod
+    def _codes_from_dicts(levels) -> np.ndarray:
+        """Enumerate the root-to-leaf paths of the reference's per-level dicts
+        (``levels[l]["-1_c1_.._cl"] = [next ids]``, reference evaluate.py:410-424)."""
+        if not levels:
+            raise ValueError("list_smtid_to_nextids is empty")
+        L = len(levels)
+        paths: List[List[int]] = []
+        stack = [("-1", [])]
+        while stack:
+            key, pref = stack.pop()
+            depth = len(pref)
+            if depth == L:
+                paths.append(pref)
+                continue
+            for nid in levels[depth].get(key, []):
+                stack.append((key + "_" + str(int(nid)), pref + [int(nid)]))
+        if not paths:
+            raise ValueError("list_smtid_to_nextids has no complete smtid")
+        return np.asarray(paths, dtype=np.int64)
+
+    # -- device trie ----------------------------------------------------------------------------
+    def trie(self, device) -> "E.DeviceTrie":
+        ctx = E.Context.get(device)
+        idx = ctx.device.index
+        if idx not in self._tries:
+            self._tries[idx] = E.DeviceTrie.from_codes(ctx, self.codes, self.vocab_size)
+        return self._tries[idx]
+
+    def docid_rows(self, device, lo: int, hi: int) -> np.ndarray:
+        """Original code-row indices (docid indices) under the sorted range [lo, hi)."""
+        return self.trie(device).perm[lo:hi]
+
+    def __call__(self, input_ids: torch.Tensor, next_token_scores: torch.Tensor = None) -> torch.Tensor:
+        """valid_mask ``[R, vocab_size]`` float64 (reference :666-677), computed by the device kernel."""
+        dev = input_ids.device if input_ids.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        mask = self.trie(dev).mask(input_ids.detach().cpu().numpy())
+        return torch.from_numpy(mask.astype(np.float64)).to(input_ids.device)
+
+
+def generate_for_constrained_prefix_beam_search(
+        model, valid_smtids, inputs: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
+        min_length=None, do_sample=None, early_stopping=None, num_beams: Optional[int] = None, temperature=None,
+        top_k=None, top_p=None, typical_p=None, repetition_penalty=None, bad_words_ids=None, bos_token_id=None,
+        pad_token_id=None, eos_token_id=None, length_penalty=None, no_repeat_ngram_size=None,
+        encoder_no_repeat_ngram_size=None, num_return_sequences: Optional[int] = None, max_time=None,
+        max_new_tokens: Optional[int] = None, decoder_start_token_id=None, use_cache=None, num_beam_groups=None,
+        diversity_penalty=None, prefix_allowed_tokens_fn=None, logits_processor=None, stopping_criteria=None,
+        constraints=None, output_attentions=None, output_hidden_states=None, output_scores=None,
+        return_dict_in_generate=None, forced_bos_token_id=None, forced_eos_token_id=None,
+        remove_invalid_values=None, synced_gpus: Optional[bool] = False,
+        apply_log_softmax_for_scores: Optional[bool] = False, apply_prefix_tree: Optional[bool] = False,
+        **model_kwargs):
+    model.eval()
+    input_ids = model_kwargs.pop("input_ids", inputs)
+    attention_mask = model_kwargs.pop("attention_mask", None)
+    if input_ids is None:
+        raise ValueError("`input_ids` has to be defined.")
+    if attention_mask is None:  # HF _prepare_attention_mask_for_generation with pad_token_id = 0
+        attention_mask = (input_ids != 0).long()
+    num_beams = 1 if num_beams is None else int(num_beams)
+    num_return_sequences = 1 if num_return_sequences is None else int(num_return_sequences)
+    num_beam_groups = 1 if num_beam_groups is None else int(num_beam_groups)
+    if num_beam_groups > num_beams:
+        raise ValueError("`num_beam_groups` has to be smaller or equal to `num_beams`")
+    if num_beam_groups != 1 or do_sample or constraints is not None:
+        raise ValueError("only plain beam search (num_beam_groups=1, do_sample=False, no constraints) is supported")
+    if num_return_sequences > num_beams:
+        raise ValueError("`num_return_sequences` has to be smaller or equal to `num_beams`.")
+    # decoder prompt is the single start id, so max_length = max_new_tokens + 1 (reference :153-154)
+    if max_length is None and max_new_tokens is not None:
+        max_length = int(max_new_tokens) + 1
+    if max_length is None:
+        raise ValueError("`max_length` needs to be a stopping_criteria for now.")
+    L = int(max_length) - 1
+    if L < 1:
+        raise ValueError(f"max_new_tokens must be >= 1, got {L}")
+    if not isinstance(valid_smtids, PrefixConstrainLogitProcessorFastSparse):
+        raise TypeError("valid_smtids must be a PrefixConstrainLogitProcessorFastSparse")
+
+    em = model.engine_model()
+    trie = valid_smtids.trie(model.device)
+    res = E.search(em, trie, input_ids, attention_mask, num_beams, L,
+                   apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
+    Q, B, K = input_ids.shape[0], num_beams, num_return_sequences
+    tok = res.tokens[:, :K, :].to(torch.long)
+    seqs = torch.cat([torch.zeros((Q, K, 1), dtype=torch.long, device=tok.device), tok], dim=2).reshape(Q * K, L + 1)
+    if not return_dict_in_generate:
+        return seqs
+    return BeamSearchEncoderDecoderOutput(
+        sequences=seqs,
+        sequences_scores=res.scores[:, :K].reshape(Q * K) if output_scores else None,
+        row_lo=res.row_lo[:, :K].reshape(Q * K), row_hi=res.row_hi[:, :K].reshape(Q * K))

@@ -1,0 +1,1 @@
+"""alias package, see t5_pretrainer/__init__.py"""

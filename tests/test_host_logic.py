@@ -1,0 +1,185 @@
+"""not-gpu: host-side logic of the path — sharding, dataset naming, smtid strings, the
+smtid->docid fan-out of constrained_decode_doc (reference evaluate.py:115-128), run merging,
+metrics, config / checkpoint round trips, dict -> code-matrix reconstruction."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beam_ref
+from ripor_amd import evaluate as EV
+from ripor_amd.dataset.sharding import shard_indices
+from ripor_amd.modeling.t5_generative_retriever import (T5forDocIDConfig, T5ForDocIDGeneration, T5SeqAQEncoder,
+                                                        expected_keys)
+from ripor_amd.tasks import generation as GEN
+from ripor_amd.utils import metrics, synth
+from ripor_amd.utils.utils import convert_ptsmtids_to_strsmtid, get_dataset_name
+
+
+def test_shard_indices_equals_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+
+    class D:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for n in (1, 2, 3, 7, 64, 6980):
+        for w in (1, 2, 4, 8):
+            for r in range(w):
+                ref = list(DistributedSampler(D(n), num_replicas=w, rank=r, shuffle=False))
+                assert shard_indices(n, w, r) == ref, (n, w, r)
+    assert shard_indices(0, 4, 1) == []
+    with pytest.raises(ValueError):
+        shard_indices(10, 2, 2)
+
+
+def test_get_dataset_name_rules():
+    cases = {"/d/msmarco/TREC_DL_2019/queries_2019/": "TREC_DL_2019", "/d/msmarco/trec2020/q": "TREC_DL_2020",
+             "/d/msmarco/TREC_DL_2020/q": "TREC_DL_2020", "/d/msmarco/dev_queries/": "MSMARCO",
+             "/d/msmarco/train_queries/x": "MSMARCO_TRAIN", "/d/MSMarco-v2/dev_1/": "MSMARCO_v2_dev1",
+             "/d/MSMarco-v2/dev_2/": "MSMARCO_v2_dev2", "/d/toy/": "TOY", "/d/nq-320k/": "NQ_320K", "/d/x/": "other_dataset"}
+    for p, name in cases.items():
+        assert get_dataset_name(p) == name
+
+
+def test_smtid_strings():
+    seq = torch.tensor([[[0, 3, 4, 5], [0, 255, 0, 1]]])
+    assert convert_ptsmtids_to_strsmtid(seq, 3) == [["3_4_5", "255_0_1"]]
+    assert convert_ptsmtids_to_strsmtid(seq, 3) == beam_ref.smtid_strings(seq.view(-1, 4), 2, 3)
+    with pytest.raises(AssertionError):
+        convert_ptsmtids_to_strsmtid(seq, 4)
+
+
+def _fake_generate(outputs_by_call):
+    calls = iter(outputs_by_call)
+
+    def fn(model, processor, **kw):
+        return next(calls)
+    return fn
+
+
+def test_constrained_decode_doc_fanout_dict_and_range_paths(monkeypatch, tmp_path):
+    """G5: same run dict from (a) the reference-style smtid_to_docids dict, (b) the sorted-row
+    range path, (c) the oracle's restatement — incl. several docids per smtid and a missing smtid."""
+    L, B = 4, 3
+    codes = np.array([[1, 2, 3, 4], [1, 2, 3, 4], [5, 6, 7, 8], [9, 9, 9, 9], [1, 2, 3, 5]], dtype=np.uint16)
+    docids = ["10", "11", "12", "13", "14"]
+    d2s = {d: [-1] + [int(x) for x in row] for d, row in zip(docids, codes)}
+    smtid_to_docids = EV.build_smtid_to_docids(d2s, L)
+    assert smtid_to_docids == beam_ref.build_smtid_to_docids(d2s, L)
+    assert smtid_to_docids["1_2_3_4"] == ["10", "11"]
+    order = np.lexsort(codes.T[::-1])  # sorted-row order as the library builds it (stable)
+    sorted_codes = codes[order]
+
+    def rng(tok):
+        hit = [i for i, r in enumerate(sorted_codes) if (r == tok).all()]
+        return (hit[0], hit[-1] + 1) if hit else (0, 0)
+
+    seqs = torch.tensor([[0, 1, 2, 3, 4], [0, 9, 9, 9, 9], [0, 7, 7, 7, 7],      # query 0: last smtid unknown
+                         [0, 5, 6, 7, 8], [0, 1, 2, 3, 5], [0, 1, 2, 3, 4]])     # query 1
+    scores = torch.tensor([0.5, 0.25, 0.125, 1.5, 1.25, -0.75], dtype=torch.float32)
+    lo = torch.tensor([rng(s[1:].numpy())[0] for s in seqs])
+    hi = torch.tensor([rng(s[1:].numpy())[1] for s in seqs])
+    out = GEN.BeamSearchEncoderDecoderOutput(sequences=seqs, sequences_scores=scores, row_lo=lo, row_hi=hi)
+    batch = {"input_ids": torch.ones((2, 3), dtype=torch.long), "attention_mask": torch.ones((2, 3), dtype=torch.long),
+             "id": torch.tensor([7, 8])}
+
+    class FakeTrie:
+        perm = order.astype(np.int64)
+
+    class FakeProc:
+        def trie(self, device):
+            return FakeTrie()
+
+    monkeypatch.setattr(EV, "generate_for_constrained_prefix_beam_search", _fake_generate([out, out]))
+    run_dict = EV.constrained_decode_doc(None, [batch], None, smtid_to_docids, L, "cpu", str(tmp_path), 0, topk=B)
+    run_rng = EV.constrained_decode_doc(None, [batch], FakeProc(), EV.DocidTable(docids), L, "cpu", str(tmp_path), 1, topk=B)
+    ref = beam_ref.constrained_decode_doc_ref([7, 8], seqs, scores, smtid_to_docids, B, L)
+    assert run_dict == run_rng == ref
+    assert run_dict[7] == {"10": 0.5 * L, "11": 0.5 * L, "13": 0.25 * L}
+    assert run_dict[8]["10"] == -0.75 * L  # a later (worse) beam overwrites, like the reference's dict assignment
+    assert json.load(open(tmp_path / "run_0.json")) == {str(k): v for k, v in run_dict.items()}
+    merged = EV.merge_runs(str(tmp_path), expected_files=2)
+    assert set(merged) == {"7", "8"} and not os.path.exists(tmp_path / "run_0.json")
+    assert json.load(open(tmp_path / "run.json")) == merged
+
+
+def test_metrics_against_hand_computed(tmp_path):
+    run = {"q1": {"a": 3.0, "b": 2.0, "c": 1.0}, "q2": {"a": 1.0, "b": 1.0, "c": 0.5}, "q3": {"z": 1.0}}
+    qrel = {"q1": {"b": 1}, "q2": {"a": 1, "x": 1}, "q3": {"y": 1}}
+    assert metrics.mrr_k(run, qrel, 10) == pytest.approx((1 / 2 + 1 / 2 + 0) / 3)  # q2 tie: docid desc -> b before a
+    rec = metrics.evaluate(run, qrel, "recall")
+    assert rec["recall_5"] == pytest.approx((1 + 0.5 + 0) / 3)
+    nd = metrics.evaluate({"q": {"a": 2.0, "b": 1.0}}, {"q": {"b": 2, "a": 0}}, "ndcg_cut")
+    assert nd["ndcg_cut_5"] == pytest.approx((2 / np.log2(3)) / 2)
+    assert list(metrics.truncate_run(run, 2)["q1"]) == ["a", "b"]
+    (tmp_path / "qrel.json").write_text(json.dumps(qrel))
+    (tmp_path / "run.json").write_text(json.dumps(run))
+    assert metrics.load_and_evaluate(str(tmp_path / "qrel.json"), str(tmp_path / "run.json"), "mrr_10")["mrr_10"] == \
+        pytest.approx(1 / 3)
+
+
+def test_config_and_checkpoint_round_trip(tmp_path):
+    dims = synth.mini_dims(L=4, enc_layers=1, d_ff=64, vocab_size=64)
+    enc = T5SeqAQEncoder.from_synthetic(dims, seed=3)
+    enc.save_pretrained(str(tmp_path))
+    cfg = T5forDocIDConfig.from_pretrained(str(tmp_path))
+    assert cfg.decoder_vocab_sizes == [256] * 4 and cfg.d_ff == 64 and cfg.shared_output_input_embeds is False
+    again = T5SeqAQEncoder.from_pretrained(str(tmp_path))
+    a, b = enc.base_model.state_dict(), again.base_model.state_dict()
+    assert set(a) == set(b) == set(expected_keys(cfg))
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert again.config.decoding is False and again.base_model.device.type == "cpu"
+    with pytest.raises(RuntimeError):
+        T5ForDocIDGeneration(cfg, {k: v for k, v in a.items() if k != "start_token_embed"})
+    with pytest.raises(ValueError):
+        T5ForDocIDGeneration(T5forDocIDConfig(num_layers=6, num_heads=8))
+
+
+def test_processor_from_reference_dicts_reconstructs_codes():
+    codes = synth.make_codes(300, 5, 256, seed=9)
+    d2s = synth.codes_to_docid_to_smtid(codes)
+    levels = beam_ref.build_list_smtid_to_nextids(d2s)
+    proc = GEN.PrefixConstrainLogitProcessorFastSparse(levels, 256)
+    got = {tuple(r) for r in proc.codes.tolist()}
+    assert got == {tuple(r) for r in codes.tolist()}
+    proc2, docids = GEN.PrefixConstrainLogitProcessorFastSparse.from_docid_to_smtid(d2s, 256)
+    assert (proc2.codes == codes).all() and docids == [str(i) for i in range(300)]
+    with pytest.raises(ValueError):
+        GEN.PrefixConstrainLogitProcessorFastSparse.from_codes(codes, 16)
+
+
+def test_generate_argument_errors():
+    dims = synth.mini_dims(L=4, enc_layers=1, d_ff=64, vocab_size=64)
+    model = T5SeqAQEncoder.from_synthetic(dims).base_model
+    proc = GEN.PrefixConstrainLogitProcessorFastSparse.from_codes(synth.make_codes(10, 4, 256), 256)
+    ids = torch.ones((1, 4), dtype=torch.long)
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        GEN.generate_for_constrained_prefix_beam_search(model, proc, input_ids=ids, max_new_tokens=4, num_beams=2,
+                                                        num_return_sequences=3)
+    with pytest.raises(ValueError, match="num_beam_groups"):
+        GEN.generate_for_constrained_prefix_beam_search(model, proc, input_ids=ids, max_new_tokens=4, num_beams=2,
+                                                        num_beam_groups=3, num_return_sequences=1)
+    with pytest.raises(ValueError, match="max_length"):
+        GEN.generate_for_constrained_prefix_beam_search(model, proc, input_ids=ids, num_beams=2, num_return_sequences=2)
+    with pytest.raises(TypeError):
+        GEN.generate_for_constrained_prefix_beam_search(model, object(), input_ids=ids, max_new_tokens=4, num_beams=2,
+                                                        num_return_sequences=2)
+
+
+def test_synth_generators_are_stable():
+    """The fixtures depend on these exact values; a drift here invalidates every golden file."""
+    w = synth.uniform_f32("probe", (4,), 1.0, seed=1)
+    assert w.dtype == np.float32 and np.all(np.abs(w) <= 1.0)
+    assert synth.uniform_f32("probe", (4,), 1.0, seed=1).tolist() == w.tolist()
+    ids, mask = synth.make_queries(16, vocab_size=512, seed=5, max_len=20)
+    lens = mask.sum(1)
+    assert ids.shape == mask.shape and lens.min() >= 6 and lens.max() <= 20
+    assert all(ids[i, lens[i] - 1] == 1 for i in range(16)) and (ids * (1 - mask) == 0).all()
+    c = synth.make_codes_fast(1000, 32, 256)
+    assert c.shape == (1000, 32) and c.dtype == np.uint16 and c.max() < 256
