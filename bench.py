@@ -67,7 +67,7 @@ def algorithmic_flops_per_query(dims, B, L, Lq):
             + 4 * Lq * Lq * inner * ne + 4 * inner * nd * B * L * (L + 1) / 2 + 4 * inner * nd * B * L * Lq)
 
 
-def cpu_baseline(sd, dims, B, L, n_queries=4, trie_docs=10_000):
+def cpu_baseline(sd, dims, B, L, n_queries=12, trie_docs=10_000):
     """Reference-faithful CPU loop (oracle 'port') on the host cores; bounded sample.
 
     The GPU box has far more cores than these small fp32 GEMMs can use (torch CPU gets *slower*
