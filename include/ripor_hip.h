@@ -82,6 +82,14 @@ typedef struct {
   const float* const* dec_wo;
 } rpr_model_desc;
 
+/* Arithmetic of the projection GEMMs (everything else — attention, norms, scores — is fp32/fp64):
+ *  RPR_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the numerical reference;
+ *  RPR_PREC_F16X2  every fp32 operand carried as two f16 planes (hi + lo, 22 significant bits), products
+ *                  evaluated as hi*hi + hi*lo + lo*hi with three f16 MFMAs accumulating in fp32:
+ *                  fp32-equivalent to ~2^-22 at 5.3x the fp32-MFMA rate (default). */
+#define RPR_PREC_F32 0
+#define RPR_PREC_F16X2 1
+
 /* rpr_search flags */
 #define RPR_FLAG_LOG_SOFTMAX 1u /* apply_log_softmax_for_scores (generation.py:453-455)           */
 #define RPR_FLAG_NO_GRAPH 2u    /* launch kernels eagerly instead of replaying a hipGraph           */
@@ -113,6 +121,10 @@ void rpr_free_ctx(rpr_ctx* ctx);
 const char* rpr_last_error(void);
 /* Library/ABI version; bumped when a signature changes. */
 int rpr_abi_version(void);
+/* Select the GEMM arithmetic (RPR_PREC_*); default RPR_PREC_F16X2, or RPR_PRECISION=f32|f16x2 in the
+ * environment at rpr_init. Takes effect on the next rpr_search/rpr_encode/rpr_op_linear. */
+int rpr_set_precision(rpr_ctx* ctx, int precision);
+int rpr_get_precision(const rpr_ctx* ctx);
 
 /* Host-only: HF T5Attention._relative_position_bucket evaluated the way the library fills its
  * device lookup tables (float32 log, truncation); rel = key_pos - query_pos. Needs no GPU. */

@@ -13,8 +13,9 @@ LIB_NAME = "libripor_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_COUNT = range(8)
-KERNEL_CLASS_NAMES = ["gemm_f32", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other"]
+KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other"]
 
+PREC_F32, PREC_F16X2 = 0, 1
 FLAG_LOG_SOFTMAX = 1
 FLAG_NO_GRAPH = 2
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "rpr_last_error": (C.c_char_p, []),
     "rpr_abi_version": (C.c_int, []),
     "rpr_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rpr_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "rpr_get_precision": (C.c_int, [C.c_void_p]),
     "rpr_load_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "rpr_free_model": (None, [C.c_void_p]),
     "rpr_build_trie": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -4,6 +4,7 @@
 // hipGraph (no host synchronisation inside the search; the reference syncs >= 1 + 2*B*Q times per
 // step).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -60,6 +61,12 @@ struct rpr_model {
   std::vector<const float*> dec_ln0, dec_qkv, dec_o, dec_ln1, dec_xq, dec_xo, dec_ln2, dec_wi, dec_wo;
   int32_t* enc_bucket = nullptr;  // [2*MAX_LQ-1]
   int32_t* dec_bucket = nullptr;  // [MAX_DEC_LEN]
+  // f16 hi/lo planes of every GEMM weight (split once at load; [2][N][K], plane stride N*K)
+  std::vector<__half*> h_enc_qkv, h_enc_o, h_enc_wi, h_enc_wo;
+  std::vector<__half*> h_dec_qkv, h_dec_o, h_dec_xq, h_dec_xo, h_dec_wi, h_dec_wo;
+  __half* h_dec_xkv = nullptr;
+  __half* h_out_embeds = nullptr;  // [2][L*V][d]
+  std::vector<void*> owned;
   int inner() const { return d.num_heads * d.d_kv; }
 };
 
@@ -88,10 +95,13 @@ struct Workspace {
   DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
   // staged outputs
   DevBuf o_tokens, o_scores, o_lo, o_hi;
+  // f16 hi/lo planes of the GEMM inputs (split-precision mode)
+  DevBuf eh_h, eattn_h, eff_h, enc_out_h, h_h, attn_h, ff_h;
 };
 
 struct rpr_ctx {
   int device;
+  int precision = RPR_PREC_F16X2;
   Workspace ws;
   size_t ws_bytes = 0;
   hipStream_t cap_stream = nullptr;
@@ -152,16 +162,41 @@ struct Launcher {
   }
 };
 
-void gemm(Launcher& L, const float* A, int lda, const float* W, int N, int K, int M, const float* resid,
-          float* out, int ldo, int relu) {
-  GemmArgs g{};
-  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.resid = resid; g.ldr = ldo;
-  g.out[0] = out; g.out[1] = out; g.out[2] = out; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldo;
-  g.split_n = N; g.M = M; g.N = N; g.K = K; g.relu = relu;
-  const double fl = 2.0 * M * (double)N * K;
-  const double by = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (resid ? 2 : 1));
+// One linear layer C = act(A @ W^T) (+ residual). A and W are given in both representations; the
+// ctx precision picks the exact fp32 MFMA kernel or the f16x2 split kernel.
+struct LinIn { const float* f; const __half* h; size_t ps; int ld; };       // activation [M, K]
+struct LinW { const float* f; const __half* h; int N, K; };                  // weight [N, K] (+ planes, stride N*K)
+struct LinOut {                                                              // destination
+  float* f[3]; int ldo[3]; int split_n;                                      //   fp32 (up to 3 column blocks)
+  __half* h; size_t ps; int ldh;                                             //   or f16 planes (next GEMM's input)
+  const float* resid; int relu;
+};
+
+LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
+  LinOut o{};
+  o.f[0] = o.f[1] = o.f[2] = p; o.ldo[0] = o.ldo[1] = o.ldo[2] = ld; o.split_n = N; o.resid = resid; o.relu = relu;
+  return o;
+}
+
+void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) {
+  const double fl = 2.0 * M * (double)W.N * W.K;
+  const double by = 4.0 * ((double)M * W.K + (double)W.N * W.K + (double)M * W.N * (O.resid ? 2 : 1));
   hipStream_t s = L.s;
-  L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
+  if (L.c->precision == RPR_PREC_F16X2) {
+    GemmH2Args g{};
+    g.A = A.h; g.a_ps = A.ps; g.lda = A.ld; g.W = W.h; g.w_ps = (size_t)W.N * W.K; g.ldw = W.K;
+    g.resid = O.resid; g.ldr = O.ldo[0];
+    for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
+    g.split_n = O.split_n; g.out_h = O.h; g.o_ps = O.ps; g.ldoh = O.ldh;
+    g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
+    L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
+  } else {
+    GemmArgs g{};
+    g.A = A.f; g.lda = A.ld; g.W = W.f; g.ldw = W.K; g.resid = O.resid; g.ldr = O.ldo[0];
+    for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
+    g.split_n = O.split_n; g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
+    L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
+  }
 }
 
 int flush_profile(rpr_ctx* c) {
@@ -196,6 +231,9 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
     E(w.tokens[i], R * (size_t)L * 2); E(w.anc[i], R * (size_t)L * 2);
   }
   E(w.o_tokens, R * (size_t)L * 4); E(w.o_scores, R * 4); E(w.o_lo, R * 8); E(w.o_hi, R * 8);
+  const size_t hb = sizeof(__half) * 2;  // two planes
+  E(w.eh_h, T * dm * hb); E(w.eattn_h, T * inner * hb); E(w.eff_h, T * dff * hb); E(w.enc_out_h, T * dm * hb);
+  E(w.h_h, R * dm * hb); E(w.attn_h, R * inner * hb); E(w.ff_h, R * dff * hb);
   return e;
 }
 
@@ -204,25 +242,39 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   const auto& d = m->d;
   Workspace& w = c->ws;
   const int T = Q * Lq, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
+  const bool h2 = c->precision == RPR_PREC_F16X2;
   hipStream_t s = Ln.s;
   float *x = P<float>(w.ex), *h = P<float>(w.eh), *qkv = P<float>(w.eqkv), *attn = P<float>(w.eattn),
         *ff = P<float>(w.eff);
+  __half *h_h = P<__half>(w.eh_h), *attn_h = P<__half>(w.eattn_h), *ff_h = P<__half>(w.eff_h);
+  const size_t ps_d = (size_t)T * dm, ps_i = (size_t)T * inner, ps_f = (size_t)T * dff;
+  const float eps = d.layer_norm_eps;
+  auto norm = [&](const float* wgt, float* of, __half* oh) {
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] {
+      return launch_rmsnorm(x, wgt, h2 ? nullptr : of, T, dm, eps, s, 1.0f, h2 ? oh : nullptr, ps_d);
+    });
+  };
   Ln.run(RPR_K_OTHER, 0, 2.0 * T * dm * 4, [&] {
     return launch_embed_rows(d.shared, P<int32_t>(w.ids), x, T, dm, d.vocab_size, s);
   });
   for (int i = 0; i < d.num_layers; ++i) {
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] { return launch_rmsnorm(x, m->enc_ln0[i], h, T, dm, d.layer_norm_eps, s); });
-    gemm(Ln, h, dm, m->enc_qkv[i], 3 * inner, dm, T, nullptr, qkv, 3 * inner, 0);
-    EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets};
+    norm(m->enc_ln0[i], h, h_h);
+    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_qkv[i], m->h_enc_qkv[i], 3 * inner, dm}, T, out_f32(qkv, 3 * inner, 3 * inner));
+    EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets,
+                  h2 ? attn_h : nullptr, ps_i};
     Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV, 4.0 * T * 4 * inner,
            [&] { return launch_enc_attn(a, s); });
-    gemm(Ln, attn, inner, m->enc_o[i], dm, inner, T, x, x, dm, 0);
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] { return launch_rmsnorm(x, m->enc_ln1[i], h, T, dm, d.layer_norm_eps, s); });
-    gemm(Ln, h, dm, m->enc_wi[i], dff, dm, T, nullptr, ff, dff, 1);
-    gemm(Ln, ff, dff, m->enc_wo[i], dm, dff, T, x, x, dm, 0);
+    linear(Ln, {attn, attn_h, ps_i, inner}, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, out_f32(x, dm, dm, x));
+    norm(m->enc_ln1[i], h, h_h);
+    LinOut o = out_f32(ff, dff, dff, nullptr, 1);
+    if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
+    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o);
+    linear(Ln, {ff, ff_h, ps_f, dff}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x));
   }
+  // final norm: fp32 copy always (taps / rpr_encode), planes for the cross-K/V GEMM in split mode
   Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] {
-    return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, d.layer_norm_eps, s);
+    return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, eps, s, 1.0f,
+                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d);
   });
 }
 
@@ -240,6 +292,8 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   Workspace& w = c->ws;
   const int T = Q * Lq, R = Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
   const int nd = d.num_decoder_layers, V = d.V;
+  const bool h2 = c->precision == RPR_PREC_F16X2;
+  const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
   enqueue_encoder(Ln, c, m, Q, Lq);
   if (taps && taps->encoder_out && !Ln.err) {
@@ -249,14 +303,23 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // cross-attention K/V of every decoder layer in one GEMM (shared by the B beams of a query;
   // the reference recomputes them for every beam at every step)
   const int xld = nd * 2 * inner;
-  gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, xld, dm, T, nullptr, P<float>(w.xkv), xld, 0);
+  linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
+         out_f32(P<float>(w.xkv), xld, xld));
 
   BeamState st0 = beam_state(w, 0, L);
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(st0, Q, B, tr->N, s); });
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
         *logits = P<float>(w.logits);
+  __half *h_h = P<__half>(w.h_h), *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
+  const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
   const size_t layer_stride = (size_t)L * R * inner;
+  auto norm = [&](const float* wgt, float post = 1.0f) {
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] {
+      return launch_rmsnorm(x, wgt, h2 ? nullptr : h, R, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
+    });
+  };
+  const LinIn in_h{h, h_h, ps_d, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff};
   for (int t = 0; t < L; ++t) {
     BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
     Ln.run(RPR_K_OTHER, 0, 2.0 * R * dm * 4, [&] {
@@ -265,41 +328,53 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
     for (int i = 0; i < nd; ++i) {
       float* kc = P<float>(w.kcache) + i * layer_stride;
       float* vc = P<float>(w.vcache) + i * layer_stride;
-      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln0[i], h, R, dm, d.layer_norm_eps, s); });
+      norm(m->dec_ln0[i]);
       {  // q -> qb, k/v -> cache row block of position t
-        GemmArgs g{};
-        g.A = h; g.lda = dm; g.W = m->dec_qkv[i]; g.ldw = dm; g.resid = nullptr; g.ldr = 0;
-        g.out[0] = qb; g.out[1] = kc + (size_t)t * R * inner; g.out[2] = vc + (size_t)t * R * inner;
-        g.ldo[0] = g.ldo[1] = g.ldo[2] = inner; g.split_n = inner; g.M = R; g.N = 3 * inner; g.K = dm; g.relu = 0;
-        Ln.run(RPR_K_GEMM, 2.0 * R * 3.0 * inner * dm, 4.0 * ((double)R * dm + 3.0 * inner * dm + 3.0 * R * inner),
-               [&] { return launch_gemm(g, s); });
+        LinOut o{};
+        o.f[0] = qb; o.f[1] = kc + (size_t)t * R * inner; o.f[2] = vc + (size_t)t * R * inner;
+        o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
+        linear(Ln, in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, o);
       }
       {
-        DecSelfAttnArgs a{qb, kc, vc, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t};
+        DecSelfAttnArgs a{qb, kc, vc, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t,
+                          h2 ? attn_h : nullptr, ps_i};
         Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * R * H * (double)(t + 1) * DKV,
                4.0 * ((double)R * inner * 2 + 2.0 * R * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
       }
-      gemm(Ln, attn, inner, m->dec_o[i], dm, inner, R, x, x, dm, 0);
-      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln1[i], h, R, dm, d.layer_norm_eps, s); });
-      gemm(Ln, h, dm, m->dec_xq[i], inner, dm, R, nullptr, qb, inner, 0);
+      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, R, out_f32(x, dm, dm, x));
+      norm(m->dec_ln1[i]);
+      linear(Ln, in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, R, out_f32(qb, inner, inner));
       {
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
-        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq};
+        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq, h2 ? attn_h : nullptr, ps_i};
         Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * R * H * (double)Lq * DKV,
                4.0 * ((double)R * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
       }
-      gemm(Ln, attn, inner, m->dec_xo[i], dm, inner, R, x, x, dm, 0);
-      Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, m->dec_ln2[i], h, R, dm, d.layer_norm_eps, s); });
-      gemm(Ln, h, dm, m->dec_wi[i], dff, dm, R, nullptr, ff, dff, 1);
-      gemm(Ln, ff, dff, m->dec_wo[i], dm, dff, R, x, x, dm, 0);
+      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, out_f32(x, dm, dm, x));
+      norm(m->dec_ln2[i]);
+      LinOut o = out_f32(ff, dff, dff, nullptr, 1);
+      if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
+      linear(Ln, in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, R, o);
+      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, R, out_f32(x, dm, dm, x));
     }
-    const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] {
-      return launch_rmsnorm(x, d.dec_final_ln, h, R, dm, d.layer_norm_eps, s, post);
-    });
+    norm(d.dec_final_ln, d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f);
     // logits of position t only (the reference computes every position and keeps [-1])
     float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
-    gemm(Ln, h, dm, d.out_embeds + (size_t)t * V * dm, V, dm, R, nullptr, lg, V, 0);
+    {
+      LinW wt{d.out_embeds + (size_t)t * V * dm, nullptr, V, dm};
+      if (h2) {
+        // planes of codebook t inside the stacked [2][L*V][d] buffer: plane stride is L*V*d
+        GemmH2Args g{};
+        g.A = h_h; g.a_ps = ps_d; g.lda = dm;
+        g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
+        g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
+        g.M = R; g.N = V; g.K = dm;
+        Ln.run(RPR_K_GEMM, 2.0 * R * (double)V * dm, 4.0 * ((double)R * dm + (double)V * dm + (double)R * V),
+               [&] { return launch_gemm_h2(g, s); });
+      } else {
+        linear(Ln, in_h, wt, R, out_f32(lg, V, V));
+      }
+    }
     SelectArgs sa{};
     sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
     sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
@@ -341,6 +416,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   RPR_HIP(init_beam_kernel_attributes());
   auto* c = new rpr_ctx();
   c->device = device;
+  if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
   std::memset(c->done, 0, sizeof(c->done));
   hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
@@ -357,7 +433,8 @@ void rpr_free_ctx(rpr_ctx* c) {
   DevBuf* all[] = {&w.ids, &w.mask, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
                    &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
                    &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
-                   &w.o_scores, &w.o_lo, &w.o_hi};
+                   &w.o_scores, &w.o_lo, &w.o_hi, &w.eh_h, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.h_h, &w.attn_h,
+                   &w.ff_h};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -366,6 +443,14 @@ void rpr_free_ctx(rpr_ctx* c) {
 }
 
 int64_t rpr_workspace_bytes(const rpr_ctx* c) { return c ? (int64_t)c->ws_bytes : 0; }
+
+int rpr_set_precision(rpr_ctx* c, int precision) {
+  RPR_REQUIRE(c, "NULL ctx");
+  RPR_REQUIRE(precision == RPR_PREC_F32 || precision == RPR_PREC_F16X2, "unknown precision");
+  c->precision = precision;
+  return RPR_OK;
+}
+int rpr_get_precision(const rpr_ctx* c) { return c ? c->precision : -1; }
 
 int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   RPR_REQUIRE(c && d && out, "NULL argument");
@@ -407,6 +492,32 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   RPR_HIP(hipMalloc(&m->dec_bucket, db.size() * 4));
   RPR_HIP(hipMemcpy(m->enc_bucket, eb.data(), eb.size() * 4, hipMemcpyHostToDevice));
   RPR_HIP(hipMemcpy(m->dec_bucket, db.data(), db.size() * 4, hipMemcpyHostToDevice));
+  // hi/lo f16 planes of every GEMM weight for the split-precision kernels
+  {
+    const size_t inner = (size_t)m->inner(), dm = d->d_model, dff = d->d_ff;
+    int err = 0;
+    auto mk = [&](const float* wf, size_t n, __half** outp) {
+      if (err) return;
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, n * 2 * sizeof(__half));
+      if (e == hipSuccess) { m->owned.push_back(p); e = launch_split_planes(wf, (__half*)p, n, n, nullptr); }
+      if (e != hipSuccess) { err = hip_fail(e, "weight split", __FILE__, __LINE__); return; }
+      *outp = (__half*)p;
+    };
+    auto mkv = [&](const std::vector<const float*>& src, size_t n, std::vector<__half*>& dst) {
+      dst.assign(src.size(), nullptr);
+      for (size_t i = 0; i < src.size(); ++i) mk(src[i], n, &dst[i]);
+    };
+    mkv(m->enc_qkv, 3 * inner * dm, m->h_enc_qkv); mkv(m->enc_o, dm * inner, m->h_enc_o);
+    mkv(m->enc_wi, dff * dm, m->h_enc_wi); mkv(m->enc_wo, dm * dff, m->h_enc_wo);
+    mkv(m->dec_qkv, 3 * inner * dm, m->h_dec_qkv); mkv(m->dec_o, dm * inner, m->h_dec_o);
+    mkv(m->dec_xq, inner * dm, m->h_dec_xq); mkv(m->dec_xo, dm * inner, m->h_dec_xo);
+    mkv(m->dec_wi, dff * dm, m->h_dec_wi); mkv(m->dec_wo, dm * dff, m->h_dec_wo);
+    mk(d->dec_xkv, (size_t)nd * 2 * inner * dm, &m->h_dec_xkv);
+    mk(d->out_embeds, (size_t)d->L * d->V * dm, &m->h_out_embeds);
+    if (!err) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) err = hip_fail(e, "sync", __FILE__, __LINE__); }
+    if (err) { for (void* p : m->owned) (void)hipFree(p); return err; }
+  }
   *out = m.release();
   return RPR_OK;
 }
@@ -421,6 +532,7 @@ void rpr_free_model(rpr_model* m) {
   }
   if (m->enc_bucket) (void)hipFree(m->enc_bucket);
   if (m->dec_bucket) (void)hipFree(m->dec_bucket);
+  for (void* p : m->owned) (void)hipFree(p);
   delete m;
 }
 
@@ -522,7 +634,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps);
     if (Ln.err) return Ln.err;
   } else {
-    GraphKey key{m, tr, Q, Lq, B, L, flags};
+    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -571,8 +683,17 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   RPR_REQUIRE(c && A && W && C, "NULL argument");
   RPR_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0, "bad GEMM shape (K must be a multiple of 32)");
   RPR_HIP(hipSetDevice(c->device));
-  Launcher Ln{c, reinterpret_cast<hipStream_t>(stream)};
-  gemm(Ln, A, K, W, N, K, M, residual, C, N, relu);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Launcher Ln{c, s};
+  __half *Ah = nullptr, *Wh = nullptr;
+  if (c->precision == RPR_PREC_F16X2) {  // test hook: split the operands on the fly
+    RPR_HIP(hipMalloc(&Ah, (size_t)M * K * 2 * sizeof(__half)));
+    RPR_HIP(hipMalloc(&Wh, (size_t)N * K * 2 * sizeof(__half)));
+    RPR_HIP(launch_split_planes(A, Ah, (size_t)M * K, (size_t)M * K, s));
+    RPR_HIP(launch_split_planes(W, Wh, (size_t)N * K, (size_t)N * K, s));
+  }
+  linear(Ln, {A, Ah, (size_t)M * K, K}, {W, Wh, N, K}, M, out_f32(C, N, N, residual, relu));
+  if (Ah) { RPR_HIP(hipStreamSynchronize(s)); RPR_HIP(hipFree(Ah)); RPR_HIP(hipFree(Wh)); }
   return Ln.err;
 }
 

@@ -1,6 +1,7 @@
 // Shared declarations for libripor_hip.so (gfx950 only; wave = 64 lanes everywhere).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string>
 
@@ -30,6 +31,13 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     }                                                                        \
   } while (0)
 
+// x = hi + lo carried as two f16 values (22 significant bits); see gemm_h2.hip
+__device__ __forceinline__ void split_f16(float x, __half& hi, __half& lo) {
+  x = fminf(fmaxf(x, -65504.f), 65504.f);
+  hi = __float2half_rn(x);
+  lo = __float2half_rn(x - __half2float(hi));
+}
+
 // ---- GEMM: C = act(A @ W^T) (+ residual), fp32 MFMA --------------------------------------------
 struct GemmArgs {
   const float* A; int lda;      // [M, K]
@@ -42,10 +50,24 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
+// ---- split-precision GEMM: operands as two f16 planes (hi, lo), 3 f16 MFMAs per product ---------
+struct GemmH2Args {
+  const __half* A; size_t a_ps; int lda;   // planes [2][M][lda], plane stride a_ps elements
+  const __half* W; size_t w_ps; int ldw;   // planes [2][N][ldw]
+  const float* resid; int ldr;
+  float* out[3]; int ldo[3]; int split_n;  // fp32 outputs (used when out_h == nullptr)
+  __half* out_h; size_t o_ps; int ldoh;    // f16-plane output [2][M][ldoh] (feeds the next GEMM)
+  int M, N, K;
+  int relu;
+};
+hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s);
+hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s);
+
 // ---- T5 elementwise / attention kernels -----------------------------------------------------------
 // post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5
+// out (fp32) and/or out_h (two f16 planes, stride o_ps) are written; either may be null
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale = 1.0f);
+                          float post_scale = 1.0f, __half* out_h = nullptr, size_t o_ps = 0);
 hipError_t init_t5_kernel_attributes();
 hipError_t init_beam_kernel_attributes();
 hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
@@ -61,6 +83,7 @@ struct EncAttnArgs {
   const int32_t* bucket;   // [2*MAX_LQ-1]: bucket of rel = key - query, index rel + MAX_LQ-1
   float* out;              // [Q*Lq, inner]
   int Q, Lq, H, buckets;
+  __half* out_h; size_t o_ps;   // when non-null: write f16 planes instead of fp32
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
 
@@ -74,6 +97,7 @@ struct DecSelfAttnArgs {
   const int32_t* bucket;   // [MAX_DEC_LEN]: bucket of rel = -(n), n = t - p
   float* out;              // [R, inner]
   int Q, B, H, t;
+  __half* out_h; size_t o_ps;
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 
@@ -85,6 +109,7 @@ struct DecCrossAttnArgs {
   const int32_t* mask;     // [Q, Lq]
   float* out;              // [R, inner]
   int Q, B, H, Lq;
+  __half* out_h; size_t o_ps;
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 

@@ -1,0 +1,227 @@
+// Split-precision linear layer on the gfx950 matrix cores: C[M,N] = act(A[M,K] @ W[N,K]^T) (+ residual)
+// with fp32-equivalent accuracy from f16 MFMA.
+//
+// Every fp32 operand x is carried as two f16 planes  x = hi + lo,  hi = f16(x), lo = f16(x - hi)
+// (22 significant bits; |x - hi - lo| <= 2^-22 |x|, absolute floor 3e-8 from f16 subnormals), and a
+// product is evaluated as  hi*hi + hi*lo + lo*hi  with three v_mfma_f32_32x32x16_f16 accumulating in
+// fp32 (the dropped lo*lo term is <= 2^-22 |xy|). Measured on the golden models (tools/ +
+// DESIGN.md §5): logits differ from the exact-fp32 path by <= 1.1e-4 (mean 1.8e-5), i.e. ~2.5x the
+// difference between two fp32 summation orders, beam scores by <= 1e-5 — inside the 1e-4 parity bar —
+// while the matrix pipe runs at the f16 rate: 3 MFMAs of 32 cycles instead of 8 fp32 MFMAs of 64
+// cycles per 32x32x16 block = 5.3x the fp32-MFMA roof. The exact fp32 kernel (gemm_f32.hip) stays
+// selectable (RPR_PRECISION=f32) as the numerical reference.
+//
+// Planes are produced where the data is written (RMSNorm, attention and ReLU epilogues emit hi/lo
+// planes; weights are split once at rpr_load_model), so this kernel only moves 16-bit data:
+// operand traffic is 4 B/element, the same as fp32.
+//
+// Tiling (wave64): 128 x BN block tile (BN = 128 or 64), BK = 32, 256 threads = 4 waves (2x2), each
+// wave (64 x BN/2) = TM x TN MFMA 32x32 accumulators. LDS rows hold 32 halves padded to 40 (80 B) so the
+// 16-lane groups of ds_read_b128 hit distinct banks. One LDS buffer + register prefetch of the next
+// K-tile; 41 KB LDS and ~130 VGPRs let three blocks share a CU, which is what hides the global
+// latency at this MFMA rate.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace rpr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HBK = 32, LDH = HBK + 8;  // halves per LDS row
+
+
+template <int BM, int BN, bool FULL>
+__global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int PA = BM / 64, PW = BN / 64;  // staging passes: 64 rows x 4 x 16 B per pass per plane
+  constexpr int ROWS = 2 * (BM + BN);
+  __shared__ __attribute__((aligned(16))) __half smem[ROWS * LDH];
+
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging: thread (row = tid>>2, seg = tid&3) moves 16 B (8 halves) of rows row, row+64, .. of each plane
+  const int srow = tid >> 2, seg8 = (tid & 3) * 8;
+  static_assert(PA == 2 && (PW == 1 || PW == 2), "staging is written out for BM = 128, BN in {64, 128}");
+  // named registers (arrays indexed inside unrolled loops end up in scratch with hipcc 7.2)
+  uint4 a00, a01, a10, a11, w00, w01, w10 = make_uint4(0u, 0u, 0u, 0u), w11 = make_uint4(0u, 0u, 0u, 0u);
+  const __half* Ab = g.A + (size_t)(bm + srow) * g.lda + seg8;
+  const __half* Wb = g.W + (size_t)(bn + srow) * g.ldw + seg8;
+  const size_t a64 = (size_t)64 * g.lda, w64 = (size_t)64 * g.ldw;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const bool aok0 = FULL || (bm + srow < g.M), aok1 = FULL || (bm + srow + 64 < g.M);
+  const bool wok0 = FULL || (bn + srow < g.N), wok1 = FULL || (bn + srow + 64 < g.N);
+#define H2_LD(ptr, ok) ((FULL || (ok)) ? *reinterpret_cast<const uint4*>(ptr) : zero4)
+#define H2_GLOAD(k0)                                              \
+  a00 = H2_LD(Ab + (k0), aok0);                                   \
+  a01 = H2_LD(Ab + g.a_ps + (k0), aok0);                          \
+  a10 = H2_LD(Ab + a64 + (k0), aok1);                             \
+  a11 = H2_LD(Ab + g.a_ps + a64 + (k0), aok1);                    \
+  w00 = H2_LD(Wb + (k0), wok0);                                   \
+  w01 = H2_LD(Wb + g.w_ps + (k0), wok0);                          \
+  if (PW > 1) {                                                   \
+    w10 = H2_LD(Wb + w64 + (k0), wok1);                           \
+    w11 = H2_LD(Wb + g.w_ps + w64 + (k0), wok1);                  \
+  }
+  // LDS rows: A plane p rows [p*BM, p*BM+BM), W plane p rows [2*BM + p*BN, ...)
+#define H2_ST(row, v) *reinterpret_cast<uint4*>(&smem[(row) * LDH + seg8]) = (v)
+#define H2_LSTORE()                                               \
+  H2_ST(srow, a00); H2_ST(BM + srow, a01);                        \
+  H2_ST(srow + 64, a10); H2_ST(BM + srow + 64, a11);              \
+  H2_ST(2 * BM + srow, w00); H2_ST(2 * BM + BN + srow, w01);      \
+  if (PW > 1) { H2_ST(2 * BM + srow + 64, w10); H2_ST(2 * BM + BN + srow + 64, w11); }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment: lane -> row lane&31, halves (lane>>5)*8 .. +7 of each 16-wide k chunk
+  const int frow = lane & 31, fk = (lane >> 5) * 8;
+  const __half* a_frag = smem + (wm * (BM / 2) + frow) * LDH + fk;
+  const __half* w_frag = smem + (2 * BM + wn * (BN / 2) + frow) * LDH + fk;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int c = 0; c < HBK / 16; ++c) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(a_frag + (i * 32) * LDH + c * 16);
+        al[i] = *reinterpret_cast<const f16x8*>(a_frag + (BM + i * 32) * LDH + c * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(w_frag + (j * 32) * LDH + c * 16);
+        bl[j] = *reinterpret_cast<const f16x8*>(w_frag + (BN + j * 32) * LDH + c * 16);
+      }
+      // product-major order: the TM*TN accumulators are independent, so dependent MFMAs on one
+      // accumulator are TM*TN issue slots apart
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkt = g.K / HBK;
+  H2_GLOAD(0)
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    H2_LSTORE()
+    __syncthreads();
+    H2_GLOAD((kt + 1) * HBK)
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it to its use)
+    compute();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  H2_LSTORE()
+  __syncthreads();
+  compute();
+#undef H2_GLOAD
+#undef H2_LSTORE
+#undef H2_LD
+#undef H2_ST
+
+  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn + wn * (BN / 2) + j * 32 + ncol;
+    if (!FULL && n >= g.N) continue;
+    const int oi = n / g.split_n, on = n - oi * g.split_n;
+    float* outp = g.out[oi];
+    const int ldo = g.ldo[oi];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = bm + wm * (BM / 2) + i * 32 + rsub;
+      float res[16];
+      if (g.resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          res[r] = (FULL || m < g.M) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (FULL || m < g.M) {
+          float v = acc[i][j][r];
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.resid) v = res[r] + v;
+          if (g.out_h) {
+            __half hi, lo;
+            split_f16(v, hi, lo);
+            g.out_h[(size_t)m * g.ldoh + n] = hi;
+            g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+          } else {
+            outp[(size_t)m * ldo + on] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const bool full = (a.M % BM == 0) && (a.N % BN == 0);
+  if (full)
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
+  static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  const bool narrow = force ? (force == 64) : (t128 < 512);
+  return narrow ? launch_cfg<128, 64>(a, s) : launch_cfg<128, 128>(a, s);
+}
+
+// fp32 [rows, cols] -> two f16 planes [2][rows][cols] (weights at load time, generic activations)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __half* __restrict__ out,
+                                                            size_t n, size_t plane_stride) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 v = *reinterpret_cast<const float4*>(x + i);
+  __half h[4], l[4];
+  split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+  *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<uint2*>(h);
+  *reinterpret_cast<uint2*>(out + plane_stride + i) = *reinterpret_cast<uint2*>(l);
+}
+
+hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (n & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n, plane_stride);
+  return hipGetLastError();
+}
+
+}  // namespace rpr

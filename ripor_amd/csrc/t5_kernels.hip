@@ -8,9 +8,18 @@
 //   normalised before the PV product.
 // All of these are HBM/L2-bound row kernels: 16-byte per-lane loads, one wave per row / per
 // (beam, head), cross-lane reductions with DPP/shuffles, no LDS staging of data that is read once.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace rpr {
+
+__device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t idx, float4 v) {
+  __half h[4], l[4];
+  split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+  *reinterpret_cast<uint2*>(out_h + idx) = *reinterpret_cast<uint2*>(h);
+  *reinterpret_cast<uint2*>(out_h + o_ps + idx) = *reinterpret_cast<uint2*>(l);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -32,12 +41,12 @@ __device__ __forceinline__ float group16_sum(float v) {
 // one wave per row; d % 4 == 0
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ out, int rows, int d, float eps,
-                                                       float post_scale) {
+                                                       float post_scale, __half* __restrict__ out_h, size_t o_ps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
   const float4* wr = reinterpret_cast<const float4*>(w);
-  float4* orow = reinterpret_cast<float4*>(out + (size_t)row * d);
+  float4* orow = reinterpret_cast<float4*>(out + (size_t)row * d);  // only dereferenced when out != nullptr
   const int n4 = d >> 2;
   float ss = 0.f;
   for (int i = lane; i < n4; i += 64) {
@@ -50,14 +59,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const float4 v = xr[i], g = wr[i];
     float4 o = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
     if (post_scale != 1.0f) { o.x *= post_scale; o.y *= post_scale; o.z *= post_scale; o.w *= post_scale; }
-    orow[i] = o;
+    if (out) orow[i] = o;
+    if (out_h) store_planes4(out_h, o_ps, (size_t)row * d + 4 * (size_t)i, o);
   }
 }
 
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale) {
+                          float post_scale, __half* out_h, size_t o_ps) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale, out_h, o_ps);
   return hipGetLastError();
 }
 
@@ -171,7 +181,15 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     __builtin_amdgcn_wave_barrier();
     float o = 0.f;
     for (int j = 0; j < Lq; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
-    a.out[((size_t)qi * Lq + i) * inner + h * DKV + lane] = o;
+    const size_t oidx = ((size_t)qi * Lq + i) * inner + h * DKV + lane;
+    if (a.out_h) {
+      __half hi, lo;
+      split_f16(o, hi, lo);
+      a.out_h[oidx] = hi;
+      a.out_h[a.o_ps + oidx] = lo;
+    } else {
+      a.out[oidx] = o;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
                                                         int anc_ld, const float* __restrict__ rel_bias,
                                                         const int32_t* __restrict__ bucket, const int32_t* __restrict__ mask,
                                                         float* __restrict__ out, int Q, int B, int H, int t, int Lq,
-                                                        int xld) {
+                                                        int xld, __half* __restrict__ out_h, size_t o_ps) {
   __shared__ float Ss[4][MAX_LQ];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -285,13 +303,17 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     acc.z += __shfl_xor(acc.z, o, 64);
     acc.w += __shfl_xor(acc.w, o, 64);
   }
-  if (g == 0) *reinterpret_cast<float4*>(out + (size_t)r * inner + h * DKV + li * 4) = acc;
+  if (g == 0) {
+    const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
+    if (out_h) store_planes4(out_h, o_ps, oidx, acc);
+    else *reinterpret_cast<float4*>(out + oidx) = acc;
+  }
 }
 
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
   hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
-                     a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0);
+                     a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps);
   return hipGetLastError();
 }
 
@@ -299,7 +321,7 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
   hipLaunchKernelGGL(dec_attn_kernel<false>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.xk, a.xv,
                      (const uint16_t*)nullptr, 0, (const float*)nullptr, (const int32_t*)nullptr, a.mask, a.out, a.Q,
-                     a.B, a.H, 0, a.Lq, a.xld);
+                     a.B, a.H, 0, a.Lq, a.xld, a.out_h, a.o_ps);
   return hipGetLastError();
 }
 

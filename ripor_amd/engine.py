@@ -47,6 +47,14 @@ class Context:
             _contexts[idx] = Context(idx)
         return _contexts[idx]
 
+    def set_precision(self, name: str):
+        """'f32' = exact fp32 MFMA; 'f16x2' = split-precision f16 MFMA (default)."""
+        check(self.lib.rpr_set_precision(self.handle, {"f32": _lib.PREC_F32, "f16x2": _lib.PREC_F16X2}[name]),
+              "rpr_set_precision")
+
+    def get_precision(self) -> str:
+        return {_lib.PREC_F32: "f32", _lib.PREC_F16X2: "f16x2"}[int(self.lib.rpr_get_precision(self.handle))]
+
     def workspace_bytes(self) -> int:
         return int(self.lib.rpr_workspace_bytes(self.handle))
 
