@@ -22,6 +22,8 @@
 // latency at this MFMA rate.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rpr {
@@ -185,10 +187,168 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles
   }
 }
 
+// ---- LDS-DMA variant -------------------------------------------------------------------------------
+// Same math, but the K-tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
+// ds_write pass — the ds_write_b128 of the register-staged kernel cost as many LDS cycles as all the
+// fragment reads and made the LDS co-critical with the matrix pipe). LDS is double-buffered; the DMA
+// of tile t+1 is issued before the MFMAs of tile t and drained by the single barrier that ends the
+// iteration. An LDS-DMA instruction writes wave-uniform base + lane*16 B, so rows are stored
+// unpadded (64 B) and the 16-byte segments of a row are XOR-swizzled with (row>>2)&3 on the SOURCE
+// address and again on the fragment read: the 16-lane groups of ds_read_b128 then hit 16 distinct
+// 4-bank slots.
+template <int BM, int BN, bool FULL>
+__global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int ROWS = 2 * (BM + BN);            // LDS rows of 32 halves (64 B) per buffer
+  constexpr int NINST = ROWS / 16;               // DMA wave-instructions per K-tile (16 rows each)
+  constexpr int PER_WAVE = NINST / 4;
+  static_assert(NINST % 4 == 0, "tile rows must split evenly over the 4 waves");
+  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
+
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // per-instruction source pointers (k0 = 0): instruction j of this wave covers LDS rows
+  // [16*(wave + 4*j), +16); lane -> row (lane>>2), physical segment (lane&3)
+  const __half* src[PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int lrow = 16 * (wave + 4 * j) + (lane >> 2);           // LDS row within the buffer
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);               // logical segment fetched into this slot
+    const __half* base;
+    int trow, limit;
+    size_t ld;
+    if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
+    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    if (!FULL && trow >= limit) trow = limit - 1;                  // ragged tile: duplicate a valid row
+    src[j] = base + (size_t)trow * ld + seg * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      __half* dst = smem + (size_t)buf * ROWS * HBK + 16 * (wave + 4 * j) * HBK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment address: row = tile row, 16-B segment (2c + lane>>5) ^ swizzle(row); all row offsets used
+  // below are multiples of 16, so swizzle(row) = (lane>>2)&3 for every fragment of this lane
+  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
+  const int a_row = wm * (BM / 2) + frow, w_row = 2 * BM + wn * (BN / 2) + frow;
+
+  auto compute = [&](int buf) {
+    const __half* base = smem + (size_t)buf * ROWS * HBK;
+#pragma unroll
+    for (int c = 0; c < HBK / 16; ++c) {
+      const int so = ((2 * c + hf) ^ sw) * 8;
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(base + (a_row + i * 32) * HBK + so);
+        al[i] = *reinterpret_cast<const f16x8*>(base + (BM + a_row + i * 32) * HBK + so);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(base + (w_row + j * 32) * HBK + so);
+        bl[j] = *reinterpret_cast<const f16x8*>(base + (BN + w_row + j * 32) * HBK + so);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkt = g.K / HBK;
+  stage(0, 0);
+  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    stage((kt + 1) & 1, (kt + 1) * HBK);
+    compute(kt & 1);
+    __syncthreads();
+  }
+  compute((nkt - 1) & 1);
+
+  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn + wn * (BN / 2) + j * 32 + ncol;
+    if (!FULL && n >= g.N) continue;
+    const int oi = n / g.split_n, on = n - oi * g.split_n;
+    float* outp = g.out[oi];
+    const int ldo = g.ldo[oi];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = bm + wm * (BM / 2) + i * 32 + rsub;
+      float res[16];
+      if (g.resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          res[r] = (FULL || m < g.M) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (FULL || m < g.M) {
+          float v = acc[i][j][r];
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.resid) v = res[r] + v;
+          if (g.out_h) {
+            __half hi, lo;
+            split_f16(v, hi, lo);
+            g.out_h[(size_t)m * g.ldoh + n] = hi;
+            g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+          } else {
+            outp[(size_t)m * ldo + on] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const bool full = (a.M % BM == 0) && (a.N % BN == 0);
+  static const int variant = [] { const char* e = getenv("RPR_GEMM_H2"); return e ? atoi(e) : 1; }();  // 1 = LDS-DMA
+  if (variant == 1) {
+    if (full)
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (full)
     hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
   else

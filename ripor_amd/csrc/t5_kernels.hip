@@ -194,11 +194,6 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   }
 }
 
-hipError_t init_t5_kernel_attributes() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
   const size_t smem = ((size_t)a.Lq * 65 + (size_t)a.Lq * 64 + 4 * (size_t)a.Lq + 64) * sizeof(float);
@@ -310,18 +305,204 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   }
 }
 
+// Self-attention, fast path (t + 1 <= 4 * SELF_MAXIT keys): same work split as dec_attn_kernel<true>
+// (one wave per (beam, head), 4 groups x 16 lanes x float4 = 4 coalesced 256-B rows per load
+// instruction), but every K and V row of the beam's ancestry is requested up front into registers,
+// so a wave keeps up to 2 * SELF_MAXIT KB in flight instead of one row group at a time — the
+// per-wave-serialised version was latency-bound at ~3.9 TB/s algorithmic. No LDS.
+constexpr int SELF_MAXIT = 9;  // 36 keys: covers L <= 35 (the reference uses L = 32 or 16)
+
+__global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs a) {
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + k;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int B = a.B, H = a.H, t = a.t;
+  const int w = bid * 4 + wave;
+  const int R = a.Q * B, inner = H * DKV;
+  if (w >= R * H) return;
+  const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
+  const int r = qi * B + b;
+  const int g = lane >> 4, li = lane & 15;
+  const int nkeys = t + 1;
+  const uint16_t* ancr = a.anc + (size_t)r * a.anc_ld;
+
+  float4 kreg[SELF_MAXIT], vreg[SELF_MAXIT];
+  size_t off[SELF_MAXIT];
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it) {
+    const int p = it * 4 + g;
+    const int pc = p < nkeys ? p : t;
+    const int slot = (pc == t) ? b : (int)ancr[pc];
+    off[it] = ((size_t)pc * R + (size_t)qi * B + slot) * inner + h * DKV + li * 4;
+  }
+  const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 4);
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it)
+    if (it * 4 < nkeys) kreg[it] = *reinterpret_cast<const float4*>(a.kcache + off[it]);
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it)
+    if (it * 4 < nkeys) vreg[it] = *reinterpret_cast<const float4*>(a.vcache + off[it]);
+
+  float sc[SELF_MAXIT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it) {
+    sc[it] = -INFINITY;
+    if (it * 4 < nkeys) {  // wave-uniform
+      const int p = it * 4 + g;
+      float d = q4.x * kreg[it].x + q4.y * kreg[it].y + q4.z * kreg[it].z + q4.w * kreg[it].w;
+      d = group16_sum(d);
+      if (p < nkeys) sc[it] = d + a.rel_bias[a.bucket[t - p] * H + h];
+      mx = fmaxf(mx, sc[it]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it) {
+    sc[it] = (sc[it] == -INFINITY) ? 0.f : expf(sc[it] - mx);
+    sum += sc[it];
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it) {
+    if (it * 4 < nkeys) {
+      const float wgt = sc[it] / sum;
+      if (wgt != 0.f) {  // lanes past nkeys hold a clamped duplicate row with weight 0
+        acc.x = fmaf(wgt, vreg[it].x, acc.x);
+        acc.y = fmaf(wgt, vreg[it].y, acc.y);
+        acc.z = fmaf(wgt, vreg[it].z, acc.z);
+        acc.w = fmaf(wgt, vreg[it].w, acc.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64);
+    acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64);
+    acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (g == 0) {
+    const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
+    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, acc);
+    else *reinterpret_cast<float4*>(a.out + oidx) = acc;
+  }
+}
+
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
+  if (a.t + 1 <= 4 * SELF_MAXIT) {
+    hipLaunchKernelGGL(dec_self_attn_fast_kernel, dim3((items + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
                      a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps);
   return hipGetLastError();
 }
 
+// Cross-attention: one block per (query, head). The encoder K/V rows of the head are staged once in
+// LDS and shared by the query's B beams (the per-beam version re-read them B times through L2);
+// wave w serves beams w, w+4, ...: lane j scores keys j, j+64, ..., the beam's q row is broadcast
+// through SGPRs (v_readlane), softmax across the wave, PV with lane = output dim.
+__global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Lq = a.Lq, H = a.H, B = a.B, inner = H * DKV;
+  const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
+  float* Ks = smem;                    // [Lq][65]
+  float* Vs = smem + (size_t)Lq * 65;  // [Lq][64]
+  float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* mrow = a.mask + (size_t)qi * Lq;
+  const float* kb = a.xk + (size_t)qi * Lq * a.xld + h * DKV;
+  const float* vb = a.xv + (size_t)qi * Lq * a.xld + h * DKV;
+  for (int i = tid; i < Lq * 16; i += 256) {
+    const int j = i >> 4, c = (i & 15) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (mrow[j] != 0) {  // padded keys are never read from HBM; zero rows keep 0 * garbage out of the PV sum
+      kv = *reinterpret_cast<const float4*>(kb + (size_t)j * a.xld + c);
+      vv = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + c);
+    }
+    float* kd = Ks + j * 65 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+  }
+  __syncthreads();
+  const int nchunk = (Lq + 63) >> 6;
+  float* P = Ps + wave * Lq;
+  for (int b = wave; b < B; b += 4) {
+    const int r = qi * B + b;
+    const float qv = a.q[(size_t)r * inner + h * DKV + lane];  // lane d holds q[d]
+    float sc[MAX_LQ / 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const int j = c * 64 + lane;
+      const int jc = j < Lq ? j : Lq - 1;
+      const float* kr = Ks + jc * 65;
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < DKV; ++d) {
+        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
+        acc = fmaf(qd, kr[d], acc);
+      }
+      float sv = -INFINITY;
+      if (j < Lq && mrow[j] != 0) sv = acc;
+      sc[c] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const float e = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - mx);
+      sc[c] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int c = 0; c < MAX_LQ / 64; ++c) {
+      if (c >= nchunk) break;
+      const int j = c * 64 + lane;
+      if (j < Lq) P[j] = sc[c] / sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int j = 0; j < Lq; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
+    const size_t oidx = (size_t)r * inner + h * DKV + lane;
+    if (a.out_h) {
+      __half hi, lo;
+      split_f16(o, hi, lo);
+      a.out_h[oidx] = hi;
+      a.out_h[a.o_ps + oidx] = lo;
+    } else {
+      a.out[oidx] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+hipError_t init_t5_kernel_attributes() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
-  const int items = a.Q * a.B * a.H;
-  hipLaunchKernelGGL(dec_attn_kernel<false>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.xk, a.xv,
-                     (const uint16_t*)nullptr, 0, (const float*)nullptr, (const int32_t*)nullptr, a.mask, a.out, a.Q,
-                     a.B, a.H, 0, a.Lq, a.xld, a.out_h, a.o_ps);
+  if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
+  const size_t smem = ((size_t)a.Lq * 65 + (size_t)a.Lq * 64 + 4 * (size_t)a.Lq) * sizeof(float);
+  hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 
