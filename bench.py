@@ -107,9 +107,9 @@ def cpu_baseline(sd, dims, B, L, n_queries=12, trie_docs=10_000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="queries in flight per step per GPU")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=2048, help="queries in flight per step per GPU")
     ap.add_argument("--beams", type=int, default=10)
     ap.add_argument("--len", type=int, default=32, dest="L")
     ap.add_argument("--docs", type=int, default=MSMARCO_DOCS)

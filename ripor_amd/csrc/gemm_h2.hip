@@ -196,13 +196,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles
 // unpadded (64 B) and the 16-byte segments of a row are XOR-swizzled with (row>>2)&3 on the SOURCE
 // address and again on the fragment read: the 16-lane groups of ds_read_b128 then hit 16 distinct
 // 4-bank slots.
-template <int BM, int BN, bool FULL>
-__global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  constexpr int TM = BM / 64, TN = BN / 64;
+template <int BM, int BN, int WM, int WN, bool FULL, bool ILV = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
+void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int NW = WM * WN;                    // waves per block
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA 32x32 tiles per wave
   constexpr int ROWS = 2 * (BM + BN);            // LDS rows of 32 halves (64 B) per buffer
   constexpr int NINST = ROWS / 16;               // DMA wave-instructions per K-tile (16 rows each)
-  constexpr int PER_WAVE = NINST / 4;
-  static_assert(NINST % 4 == 0, "tile rows must split evenly over the 4 waves");
+  constexpr int PER_WAVE = NINST / NW;
+  static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
 
   const int nt = tiles_m * tiles_n;
@@ -215,14 +217,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int t
   const int bm = tm * BM, bn = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // per-instruction source pointers (k0 = 0): instruction j of this wave covers LDS rows
-  // [16*(wave + 4*j), +16); lane -> row (lane>>2), physical segment (lane&3)
+  // [16*(wave + NW*j), +16); lane -> row (lane>>2), physical segment (lane&3)
   const __half* src[PER_WAVE];
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
-    const int lrow = 16 * (wave + 4 * j) + (lane >> 2);           // LDS row within the buffer
+    const int lrow = 16 * (wave + NW * j) + (lane >> 2);          // LDS row within the buffer
     const int seg = (lane & 3) ^ ((lrow >> 2) & 3);               // logical segment fetched into this slot
     const __half* base;
     int trow, limit;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int t
   auto stage = [&](int buf, int k0) {
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
-      __half* dst = smem + (size_t)buf * ROWS * HBK + 16 * (wave + 4 * j) * HBK;
+      __half* dst = smem + (size_t)buf * ROWS * HBK + 16 * (wave + NW * j) * HBK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int t
   // fragment address: row = tile row, 16-B segment (2c + lane>>5) ^ swizzle(row); all row offsets used
   // below are multiples of 16, so swizzle(row) = (lane>>2)&3 for every fragment of this lane
   const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
-  const int a_row = wm * (BM / 2) + frow, w_row = 2 * BM + wn * (BN / 2) + frow;
+  const int a_row = wm * (BM / WM) + frow, w_row = 2 * BM + wn * (BN / WN) + frow;
 
   auto compute = [&](int buf) {
     const __half* base = smem + (size_t)buf * ROWS * HBK;
@@ -287,12 +289,74 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int t
     }
   };
 
+  // fused form of {stage(next); compute(cur)}: the DMA pieces of the next tile are spread between
+  // the product groups of the current tile's MFMAs, so a wave's DMA issue stalls overlap its own
+  // in-flight MFMAs and the co-resident wave's (both waves of a SIMD run this same stream)
+  auto compute_and_stage = [&](int buf, int nbuf, int k0) {
+    const __half* base = smem + (size_t)buf * ROWS * HBK;
+    constexpr int SLOTS = 3 * (HBK / 16);
+    int piece = 0;
+    auto dma_some = [&](int slot) {
+      // distribute PER_WAVE pieces over SLOTS slots
+      const int upto = (PER_WAVE * (slot + 1) + SLOTS - 1) / SLOTS;
+#pragma unroll
+      for (int j = 0; j < PER_WAVE; ++j) {
+        if (j >= piece && j < upto) {
+          __half* dst = smem + (size_t)nbuf * ROWS * HBK + 16 * (wave + NW * j) * HBK;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      }
+      piece = upto;
+    };
+#pragma unroll
+    for (int c = 0; c < HBK / 16; ++c) {
+      const int so = ((2 * c + hf) ^ sw) * 8;
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(base + (a_row + i * 32) * HBK + so);
+        al[i] = *reinterpret_cast<const f16x8*>(base + (BM + a_row + i * 32) * HBK + so);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(base + (w_row + j * 32) * HBK + so);
+        bl[j] = *reinterpret_cast<const f16x8*>(base + (BN + w_row + j * 32) * HBK + so);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_some(3 * c + 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_some(3 * c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_some(3 * c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   const int nkt = g.K / HBK;
   stage(0, 0);
   __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
   for (int kt = 0; kt + 1 < nkt; ++kt) {
-    stage((kt + 1) & 1, (kt + 1) * HBK);
-    compute(kt & 1);
+    if (ILV) {
+      compute_and_stage(kt & 1, (kt + 1) & 1, (kt + 1) * HBK);
+    } else {
+      stage((kt + 1) & 1, (kt + 1) * HBK);
+      compute(kt & 1);
+    }
     __syncthreads();
   }
   compute((nkt - 1) & 1);
@@ -300,14 +364,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_dma_kernel(GemmH2Args g, int t
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = bn + wn * (BN / 2) + j * 32 + ncol;
+    const int n = bn + wn * (BN / WN) + j * 32 + ncol;
     if (!FULL && n >= g.N) continue;
     const int oi = n / g.split_n, on = n - oi * g.split_n;
     float* outp = g.out[oi];
     const int ldo = g.ldo[oi];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mbase = bm + wm * (BM / 2) + i * 32 + rsub;
+      const int mbase = bm + wm * (BM / WM) + i * 32 + rsub;
       float res[16];
       if (g.resid) {
 #pragma unroll
@@ -344,9 +408,9 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   static const int variant = [] { const char* e = getenv("RPR_GEMM_H2"); return e ? atoi(e) : 1; }();  // 1 = LDS-DMA
   if (variant == 1) {
     if (full)
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
     else
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
     return hipGetLastError();
   }
   if (full)
@@ -356,10 +420,27 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// 256x256 tile, 8 waves (2x4) of 128x64: half the staged bytes per MFMA of the 128x128 tile; needs
+// >= ~200 tiles to fill the chip, i.e. large in-flight batches (M = Q*B >= ~16k rows for N = 768)
+static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
+  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
+  static const int ilv = [] { const char* e = getenv("RPR_GEMM_ILV"); return e ? atoi(e) : 1; }();
+  if (full && ilv)
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, true, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+  else if (full)
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (force == 256 || (force == 0 && t256 >= 200)) return launch_256(a, s);
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool narrow = force ? (force == 64) : (t128 < 512);
   return narrow ? launch_cfg<128, 64>(a, s) : launch_cfg<128, 128>(a, s);
