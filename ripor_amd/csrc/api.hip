@@ -88,7 +88,7 @@ struct GraphKey {
 
 struct Workspace {
   // encoder
-  DevBuf ids, mask, ex, eh, eqkv, eattn, eff, enc_out, xkv;
+  DevBuf ids, mask, last, ex, eh, eqkv, eattn, eff, enc_out, xkv;
   // decoder
   DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
   // beam state (2 ping-pong buffers)
@@ -219,7 +219,7 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   Workspace& w = c->ws;
   int e = 0;
   auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = ensure(c, b, bytes); };
-  E(w.ids, T * 4); E(w.mask, T * 4);
+  E(w.ids, T * 4); E(w.mask, T * 4); E(w.last, (size_t)Q * 4);
   E(w.ex, T * dm * f); E(w.eh, T * dm * f); E(w.eqkv, T * 3 * inner * f); E(w.eattn, T * inner * f);
   E(w.eff, T * dff * f); E(w.enc_out, T * dm * f); E(w.xkv, T * nd * 2 * inner * f);
   E(w.x, R * dm * f); E(w.h, R * dm * f); E(w.q, R * inner * f); E(w.attn, R * inner * f);
@@ -308,6 +308,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
 
   BeamState st0 = beam_state(w, 0, L);
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(st0, Q, B, tr->N, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s); });
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
         *logits = P<float>(w.logits);
@@ -346,7 +347,8 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       linear(Ln, in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, R, out_f32(qb, inner, inner));
       {
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
-        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq, h2 ? attn_h : nullptr, ps_i};
+        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq, h2 ? attn_h : nullptr, ps_i,
+                           P<int32_t>(w.last)};
         Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * R * H * (double)Lq * DKV,
                4.0 * ((double)R * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
       }
@@ -430,7 +432,7 @@ void rpr_free_ctx(rpr_ctx* c) {
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   Workspace& w = c->ws;
-  DevBuf* all[] = {&w.ids, &w.mask, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
+  DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
                    &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
                    &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
                    &w.o_scores, &w.o_lo, &w.o_hi, &w.eh_h, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.h_h, &w.attn_h,

@@ -110,6 +110,7 @@ struct DecCrossAttnArgs {
   float* out;              // [R, inner]
   int Q, B, H, Lq;
   __half* out_h; size_t o_ps;
+  const int32_t* last;     // [Q] index of the last attended key + 1 (launch_mask_lengths)
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 

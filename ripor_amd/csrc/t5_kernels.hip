@@ -408,86 +408,105 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Cross-attention: one block per (query, head). The encoder K/V rows of the head are staged once in
-// LDS and shared by the query's B beams (the per-beam version re-read them B times through L2);
-// wave w serves beams w, w+4, ...: lane j scores keys j, j+64, ..., the beam's q row is broadcast
-// through SGPRs (v_readlane), softmax across the wave, PV with lane = output dim.
+// Cross-attention: one block per (query, head). The encoder K/V rows of the head and the q rows of
+// the query's B beams are staged once in LDS (the per-beam version re-read K/V B times through L2);
+// then three block-wide phases: scores — one thread per (beam, key) pair, float4 LDS reads with rows
+// padded to 68 floats (conflict-free); softmax — one wave per beam; P.V — one thread per (beam, 4 dims).
+constexpr int XK_LD = DKV + 4, QS_LD = DKV + 4;
+
 __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Lq = a.Lq, H = a.H, B = a.B, inner = H * DKV;
+  const int H = a.H, B = a.B, inner = H * DKV;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
-  float* Ks = smem;                    // [Lq][65]
-  float* Vs = smem + (size_t)Lq * 65;  // [Lq][64]
-  float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int32_t* mrow = a.mask + (size_t)qi * Lq;
-  const float* kb = a.xk + (size_t)qi * Lq * a.xld + h * DKV;
-  const float* vb = a.xv + (size_t)qi * Lq * a.xld + h * DKV;
-  for (int i = tid; i < Lq * 16; i += 256) {
+  const int SLD = a.Lq + 1;
+  float* Ks = smem;                        // [Lq][68]
+  float* Vs = Ks + (size_t)a.Lq * XK_LD;   // [Lq][64]
+  float* Qs = Vs + (size_t)a.Lq * DKV;     // [B][68]
+  float* S = Qs + (size_t)B * QS_LD;       // [B][Lq+1]
+  const int tid = threadIdx.x;
+  const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
+  const float* kb = a.xk + (size_t)qi * a.Lq * a.xld + h * DKV;
+  const float* vb = a.xv + (size_t)qi * a.Lq * a.xld + h * DKV;
+  // keys at and beyond the last attended position are padding: every loop runs over that prefix only
+  // (queries are padded to the batch maximum, typically 2-3x their own length); a.last[q] is computed
+  // once per search. All global loads of the block are issued back to back before the first wait.
+  const int Lq = max(1, a.last[qi]);
+  constexpr int PF = 2;  // float4 K and V items per thread held in registers (covers Lq <= 32 rows)
+  float4 pk[PF], pv[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int i = tid + u * 256, j = i >> 4, c = (i & 15) * 4;
+    pk[u] = make_float4(0.f, 0.f, 0.f, 0.f); pv[u] = pk[u];
+    if (j < Lq && mrow[j] != 0) {  // padded keys are never read; zero rows keep 0 * garbage out of the PV sum
+      pk[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * a.xld + c);
+      pv[u] = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + c);
+    }
+  }
+  for (int i = tid; i < B * 16; i += 256) {
+    const int b = i >> 4, c = (i & 15) * 4;
+    *reinterpret_cast<float4*>(Qs + b * QS_LD + c) =
+        *reinterpret_cast<const float4*>(a.q + (size_t)(qi * B + b) * inner + h * DKV + c);
+  }
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int i = tid + u * 256, j = i >> 4, c = (i & 15) * 4;
+    if (j < Lq) {
+      *reinterpret_cast<float4*>(Ks + j * XK_LD + c) = pk[u];
+      *reinterpret_cast<float4*>(Vs + j * DKV + c) = pv[u];
+    }
+  }
+  for (int i = tid + PF * 256; i < Lq * 16; i += 256) {  // long queries: remaining rows
     const int j = i >> 4, c = (i & 15) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (mrow[j] != 0) {  // padded keys are never read from HBM; zero rows keep 0 * garbage out of the PV sum
+    if (mrow[j] != 0) {
       kv = *reinterpret_cast<const float4*>(kb + (size_t)j * a.xld + c);
       vv = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + c);
     }
-    float* kd = Ks + j * 65 + c;
-    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+    *reinterpret_cast<float4*>(Ks + j * XK_LD + c) = kv;
+    *reinterpret_cast<float4*>(Vs + j * DKV + c) = vv;
   }
   __syncthreads();
-  const int nchunk = (Lq + 63) >> 6;
-  float* P = Ps + wave * Lq;
-  for (int b = wave; b < B; b += 4) {
-    const int r = qi * B + b;
-    const float qv = a.q[(size_t)r * inner + h * DKV + lane];  // lane d holds q[d]
-    float sc[MAX_LQ / 64];
-    float mx = -INFINITY;
+  // scores: one thread per (beam, key) pair; four partial sums break the dependent FMA chain
+  for (int pair = tid; pair < B * Lq; pair += 256) {
+    const int b = pair / Lq, j = pair - b * Lq;
+    float sv = -INFINITY;
+    if (mrow[j] != 0) {
+      const float4* qr = reinterpret_cast<const float4*>(Qs + b * QS_LD);
+      const float4* kr = reinterpret_cast<const float4*>(Ks + j * XK_LD);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAX_LQ / 64; ++c) {
-      if (c >= nchunk) break;
-      const int j = c * 64 + lane;
-      const int jc = j < Lq ? j : Lq - 1;
-      const float* kr = Ks + jc * 65;
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < DKV; ++d) {
-        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
-        acc = fmaf(qd, kr[d], acc);
+      for (int d = 0; d < DKV / 4; ++d) {
+        const float4 q4 = qr[d], k4 = kr[d];
+        a0 = fmaf(q4.x, k4.x, a0); a1 = fmaf(q4.y, k4.y, a1);
+        a2 = fmaf(q4.z, k4.z, a2); a3 = fmaf(q4.w, k4.w, a3);
       }
-      float sv = -INFINITY;
-      if (j < Lq && mrow[j] != 0) sv = acc;
-      sc[c] = sv;
-      mx = fmaxf(mx, sv);
+      sv = (a0 + a1) + (a2 + a3);
     }
-    mx = wave_max(mx);
+    S[b * SLD + j] = sv;
+  }
+  __syncthreads();
+  // softmax + P.V: one thread per (beam, 4 output dims). Every thread recomputes its beam's max and
+  // exp-sum from the score row (broadcast LDS reads): no cross-lane reductions — the wave-shuffle
+  // softmax was a chain of ~36 dependent ds_bpermute latencies per block and dominated the kernel.
+  for (int item = tid; item < B * 16; item += 256) {
+    const int b = item >> 4, c = (item & 15) * 4;
+    const float* row = S + b * SLD;
+    float mx = -INFINITY;
+    for (int j = 0; j < Lq; ++j) mx = fmaxf(mx, row[j]);
     float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAX_LQ / 64; ++c) {
-      if (c >= nchunk) break;
-      const float e = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - mx);
-      sc[c] = e;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Lq; ++j) {
+      const float sv = row[j];
+      const float e = (sv == -INFINITY) ? 0.f : expf(sv - mx);
       sum += e;
+      const float4 v4 = *reinterpret_cast<const float4*>(Vs + j * DKV + c);
+      o.x = fmaf(e, v4.x, o.x); o.y = fmaf(e, v4.y, o.y); o.z = fmaf(e, v4.z, o.z); o.w = fmaf(e, v4.w, o.w);
     }
-    sum = wave_sum(sum);
-#pragma unroll
-    for (int c = 0; c < MAX_LQ / 64; ++c) {
-      if (c >= nchunk) break;
-      const int j = c * 64 + lane;
-      if (j < Lq) P[j] = sc[c] / sum;
-    }
-    __builtin_amdgcn_wave_barrier();
-    float o = 0.f;
-    for (int j = 0; j < Lq; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
-    const size_t oidx = (size_t)r * inner + h * DKV + lane;
-    if (a.out_h) {
-      __half hi, lo;
-      split_f16(o, hi, lo);
-      a.out_h[oidx] = hi;
-      a.out_h[a.o_ps + oidx] = lo;
-    } else {
-      a.out[oidx] = o;
-    }
-    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+    const size_t oidx = (size_t)(qi * B + b) * inner + h * DKV + c;
+    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, o);
+    else *reinterpret_cast<float4*>(a.out + oidx) = o;
   }
 }
 
@@ -501,7 +520,8 @@ hipError_t init_t5_kernel_attributes() {
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
-  const size_t smem = ((size_t)a.Lq * 65 + (size_t)a.Lq * 64 + 4 * (size_t)a.Lq) * sizeof(float);
+  const size_t smem = ((size_t)a.Lq * (XK_LD + DKV) + (size_t)a.B * (QS_LD + a.Lq + 1) + 4) * sizeof(float);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H), dim3(256), smem, s, a);
   return hipGetLastError();
 }
@@ -509,8 +529,8 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
 __global__ void mask_lengths_kernel(const int32_t* __restrict__ mask, int32_t* __restrict__ lens, int Q, int Lq) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
-  int n = 0;
-  for (int j = 0; j < Lq; ++j) n += mask[(size_t)q * Lq + j] != 0;
+  int n = 0;  // index of the last attended key + 1 (the mask need not be a prefix)
+  for (int j = 0; j < Lq; ++j) if (mask[(size_t)q * Lq + j] != 0) n = j + 1;
   lens[q] = n;
 }
 

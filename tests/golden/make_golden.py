@@ -267,6 +267,12 @@ ALLOW_SINGLE_BEAM = False
 
 def load_reference():
     shim = install_shim()
+    # the reference's t5_pretrainer is a namespace package (no __init__.py); this repo's alias package
+    # of the same name is a regular package and would win regardless of path order, so drop the repo
+    # root from sys.path (ripor_amd.utils.synth is already imported) before importing the reference
+    sys.path[:] = [p_ for p_ in sys.path if os.path.realpath(p_ or ".") != os.path.realpath(REPO)]
+    for k_ in [k_ for k_ in sys.modules if k_ == "t5_pretrainer" or k_.startswith("t5_pretrainer.")]:
+        del sys.modules[k_]
     sys.path.insert(0, REF)
     os.chdir(REF)  # decoder_start_token_path default is relative (t5_generative_retriever.py:51)
     import importlib
@@ -274,6 +280,8 @@ def load_reference():
     gen = importlib.import_module("t5_pretrainer.tasks.generation")
     mod = importlib.import_module("t5_pretrainer.modeling.t5_generative_retriever")
     utils = importlib.import_module("t5_pretrainer.utils.utils")
+    for m_ in (gen, mod, utils):  # the golden vectors must come from the reference, never from this repo
+        assert os.path.realpath(m_.__file__).startswith(REF + os.sep), m_.__file__
     M = mod.T5ForDocIDGeneration
     M.adjust_logits_during_generation = lambda self, logits, **kw: logits
 
@@ -355,6 +363,8 @@ CASES = {
     "g1_mini_b4_l8_logsoftmax": dict(kind="mini", N=1000, Q=4, B=4, L=8, V=256, seed=105, log_softmax=True),
     "g1_mini_b4_l8_shared": dict(kind="mini", N=500, Q=4, B=4, L=8, V=256, seed=106, shared=True),
     "g2_base_b10_l32": dict(kind="base", N=1000, Q=4, B=10, L=32, V=256, seed=201),
+    # t5-large decoder shape (24 layers, 16 heads, d=1024 are forced by the reference ctor), B=100 top-k stress
+    "g3_large_b100_l16": dict(kind="large", N=3000, Q=2, B=100, L=16, V=256, seed=301),
 }
 
 
@@ -365,11 +375,14 @@ def make_case(name, spec, gen, mod, utils, shim):
         dims = synth.mini_dims(L=L, V=V, shared_output_input_embeds=shared)
     elif kind == "base":
         dims = synth.t5_base_dims(L=L, V=V, vocab_size=2048, shared_output_input_embeds=shared)
+    elif kind == "large":
+        dims = synth.ModelDims(vocab_size=512, d_model=1024, d_kv=64, d_ff=512, num_layers=1, num_decoder_layers=24,
+                               num_heads=16, decoder_vocab_sizes=[V] * L, shared_output_input_embeds=shared)
     else:
         raise ValueError(kind)
     t0 = time.time()
     sd = synth.make_state_dict(dims, seed=seed)
-    model = build_reference_model(mod, dims, sd)
+    model = build_reference_model(mod, dims, sd, which="t5-large" if kind == "large" else "t5-base")
     codes = synth.make_codes(N, L, V, seed=seed)
     d2s, lst = reference_trie(gen, codes)
     processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
