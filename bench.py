@@ -241,12 +241,27 @@ def main():
             if args.precision == "f32":
                 kname, peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
             else:
-                kname, peak = "rpr::gemm_h2_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
+                kname, peak = "rpr::gemm_h2_dma_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
                 note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
                         "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3")
+            traffic, traffic_src = None, None
+            pmc_path = os.path.join(REPO, "profiles", "latest_hbm_pmc.json")
+            if os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
+                try:
+                    pmc = json.load(open(pmc_path))
+                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_dma_kernel<256" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                    if key:
+                        # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
+                        traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
+                        traffic_src = ("profiles/latest_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
+                                       "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
+                except Exception:
+                    pass
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach,
                                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "note": note,
-                               "traffic": None, "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
+                               "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
                                "launches_per_step": g["launches"],
                                "flops_per_launch": g["flops"] / max(1, g["launches"])}
             tot = sum(s["total_ms"] for s in stats.values())
