@@ -4,6 +4,7 @@
 // hipGraph (no host synchronisation inside the search; the reference syncs >= 1 + 2*B*Q times per
 // step).
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -102,6 +103,7 @@ struct Workspace {
 struct rpr_ctx {
   int device;
   int precision = RPR_PREC_F16X2;
+  unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
   Workspace ws;
   size_t ws_bytes = 0;
   hipStream_t cap_stream = nullptr;
@@ -189,6 +191,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) 
     for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
     g.split_n = O.split_n; g.out_h = O.h; g.o_ps = O.ps; g.ldoh = O.ldh;
     g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
+    g.trace = L.c->trace_buf;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
   } else {
     GemmArgs g{};
@@ -419,6 +422,10 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   auto* c = new rpr_ctx();
   c->device = device;
   if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
+  if (getenv("RPR_GEMM_TRACE")) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 1 << 20) == hipSuccess) { (void)hipMemset(p, 0, 1 << 20); c->trace_buf = (unsigned long long*)p; }
+  }
   std::memset(c->done, 0, sizeof(c->done));
   hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
@@ -696,6 +703,15 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   }
   linear(Ln, {A, Ah, (size_t)M * K, K}, {W, Wh, N, K}, M, out_f32(C, N, N, residual, relu));
   if (Ah) { RPR_HIP(hipStreamSynchronize(s)); RPR_HIP(hipFree(Ah)); RPR_HIP(hipFree(Wh)); }
+  if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x 6 stamps
+    const size_t n = (size_t)(K / 32) * 8 * 6;
+    std::vector<unsigned long long> hbuf(n);
+    RPR_HIP(hipMemcpy(hbuf.data(), c->trace_buf, n * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(getenv("RPR_GEMM_TRACE"), "w")) {
+      for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", hbuf[i], (i % 6 == 5) ? '\n' : ' ');
+      fclose(f);
+    }
+  }
   return Ln.err;
 }
 

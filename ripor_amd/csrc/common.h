@@ -59,6 +59,7 @@ struct GemmH2Args {
   __half* out_h; size_t o_ps; int ldoh;    // f16-plane output [2][M][ldoh] (feeds the next GEMM)
   int M, N, K;
   int relu;
+  unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
 };
 hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s);
 hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s);

@@ -401,6 +401,193 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   }
 }
 
+// ---- software-pipelined 256x256 variant -----------------------------------------------------------------
+// Same tile/LDS layout as gemm_h2_dma_kernel<256,256,2,4>, but the fragment reads are pipelined by
+// hand: a K-tile is two 16-wide chunks; while the MFMAs of one chunk run, the ds_reads of the next
+// chunk (possibly of the next K-tile) are already in flight into a second fragment register set, and
+// the one barrier per K-tile sits between the two chunks:
+//     F1(t) reads | MFMA chunk0(t) | wait DMA(t+1) + barrier | DMA(t+2) issue | F0(t+1) reads | MFMA chunk1(t)
+// hipcc's own schedule issued each ds_read group right before its MFMAs (~10 exposed LDS latencies per
+// K-tile and wave; both waves of a SIMD stall together because the barrier keeps them in phase).
+template <bool FULL, int WM = 2, int WN = 4, int LW = 8>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, NW = WM * WN, TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int ROWS = 2 * (BM + BN), NINST = ROWS / 16, PER_WAVE = NINST / LW;  // DMA pieces per loader wave per K-tile
+  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
+
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lbm = bm, lbn = bn;
+
+  // LW = number of waves that issue the LDS-DMA (all 8 by default; LW = 4, one loader per SIMD, measured
+  // slower: 283 vs 326 TF/s — the loaders' 16 pieces serialise behind each other)
+  const bool loader = wave < LW;
+  const __half* src[PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int lrow = 16 * ((wave % LW) + LW * j) + (lane >> 2);
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const __half* base;
+    int trow, limit;
+    size_t ld;
+    if (lrow < BM) { base = g.A; trow = lbm + lrow; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = lbm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = lbn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
+    else { base = g.W + g.w_ps; trow = lbn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    if (!FULL && trow >= limit) trow = limit - 1;
+    src[j] = base + (size_t)trow * ld + seg * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    if (!loader) return;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      __half* dst = smem + (size_t)buf * ROWS * HBK + 16 * (wave + LW * j) * HBK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
+  const int a_row = wm * (BM / WM) + frow, w_row = 2 * BM + wn * (BN / WN) + frow;
+  const int so0 = ((0 + hf) ^ sw) * 8, so1 = ((2 + hf) ^ sw) * 8;   // segment offsets of chunk 0 / 1
+
+  struct Frag { f16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto load_frag = [&](Frag& f, int buf, int so) {
+    const __half* base = smem + (size_t)buf * ROWS * HBK;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f.ah[i] = *reinterpret_cast<const f16x8*>(base + (a_row + i * 32) * HBK + so);
+      f.al[i] = *reinterpret_cast<const f16x8*>(base + (BM + a_row + i * 32) * HBK + so);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = *reinterpret_cast<const f16x8*>(base + (w_row + j * 32) * HBK + so);
+      f.bl[j] = *reinterpret_cast<const f16x8*>(base + (BN + w_row + j * 32) * HBK + so);
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+  };
+
+  const int nkt = g.K / HBK;
+  Frag f0, f1;
+  // optional cycle trace of block 0 (diagnostic; g.trace == nullptr in production)
+  const bool tr = g.trace != nullptr && blockIdx.x == 0 && lane == 0;
+#define H2_STAMP(slot) if (tr) g.trace[((size_t)kt * NW + wave) * 6 + (slot)] = __builtin_readcyclecounter()
+  stage(0, 0);
+  __syncthreads();                       // tile 0 landed
+  if (nkt > 1) stage(1, HBK);            // tile 1 in flight
+  load_frag(f0, 0, so0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    H2_STAMP(0);
+    load_frag(f1, cur, so1);             // chunk 1 of this tile, hidden behind chunk 0's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    H2_STAMP(1);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    H2_STAMP(2);
+    __syncthreads();                     // every wave holds tile kt in registers; tile kt+1 has landed (vmcnt(0))
+    H2_STAMP(3);
+    if (kt + 2 < nkt) stage(cur, (kt + 2) * HBK);          // refill the buffer just released
+    if (kt + 1 < nkt) load_frag(f0, cur ^ 1, so0);          // chunk 0 of the next tile, hidden behind chunk 1
+    __builtin_amdgcn_sched_barrier(0);
+    H2_STAMP(4);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    H2_STAMP(5);
+  }
+#undef H2_STAMP
+
+  // ---- epilogue: transpose through LDS, then row-wise 16-byte global accesses ---------------------------
+  // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
+  // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
+  // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
+  // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
+  // operand LDS and streams them out as float4 rows: 16 residual loads in flight per lane, 4x fewer
+  // store instructions, f16 planes written 8 bytes at a time.
+  __syncthreads();                                   // all waves are done reading operand tiles
+  constexpr int SW = TN * 32;                         // staged row width (floats)
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
+  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+  constexpr int LPR = SW / 4, RPI = 64 / LPR;          // lanes per staged row, rows per read instruction
+  const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
+  const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
+  const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
+  const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
+  float* outp = g.out[oi];
+  const int ldo = g.ldo[oi];
+#pragma unroll
+  for (int half = 0; half < TM / 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[half * 2 + ii][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int mrow0 = bm + wm * (BM / WM) + half * 64;
+    constexpr int NK = 64 / RPI;
+    float4 res[NK];
+    if (g.resid) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int m = mrow0 + k * RPI + rrow;
+        res[k] = (ncol_ok && (FULL || m < g.M)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int rl = k * RPI + rrow, m = mrow0 + rl;
+      float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+      if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
+      if (ncol_ok && (FULL || m < g.M)) {
+        if (g.out_h) {
+          __half h[4], l[4];
+          split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+          *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
+        } else {
+          *reinterpret_cast<float4*>(outp + (size_t)m * ldo + on) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
+  }
+}
+
 template <int BM, int BN>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -426,6 +613,14 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
   static const int ilv = [] { const char* e = getenv("RPR_GEMM_ILV"); return e ? atoi(e) : 1; }();
+  static const int pipe = [] { const char* e = getenv("RPR_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+  if (pipe) {
+    if (full)
+      hipLaunchKernelGGL((gemm_h2_pipe_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_h2_pipe_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (full && ilv)
     hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, true, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
   else if (full)
