@@ -2,8 +2,9 @@
 query collection, map smtids to docids, write ``run_{rank}.json`` / ``run.json``, evaluate.
 
 Mirrors the generative-retrieval tasks of reference t5_pretrainer/evaluate.py:
-  ``constrained_decode_doc`` :87-132, ``t5seq_aq_retrieve_docids`` :396-487,
-  ``t5seq_aq_retrieve_docids_2`` :489-526, ``evaluate`` :268-291, ``__main__`` dispatch :657-690,
+  ``constrained_decode`` :45-85, ``constrained_decode_doc`` :87-132, ``constrained_decode_smtid`` :134-178,
+  ``t5seq_aq_retrieve_docids`` :396-487, ``t5seq_aq_retrieve_docids_2`` :489-526,
+  ``t5seq_aq_get_qid_to_smtid_rankdata(_2)`` :528-655, ``evaluate`` :268-291, ``__main__`` dispatch :657-690,
 with the same CLI flags (``EvalArguments`` subset, reference arguments.py:145-212), the same output
 layout ``out_dir/<get_dataset_name(q_dir)>/run_{local_rank}.json`` and the same score convention
 (``float(score_f32) * max_new_token`` per docid).
@@ -80,6 +81,75 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
         with open(os.path.join(out_dir, f"run_{local_rank}.json"), "w") as fout:
             json.dump(qid_to_rankdata, fout)
     return qid_to_rankdata
+
+
+def constrained_decode(model, dataloader, prefix_constrain_processor, smtid_to_docid, max_new_token, device, out_dir,
+                       local_rank, topk=100, write=True):
+    """reference evaluate.py:45-85: ``{qid: {smtid_string: score}}`` -> ``qid_to_smtid_{rank}.json``
+    (scores are the raw ``sequences_scores``, not multiplied by the length)."""
+    qid_to_rankdata: Dict[int, Dict[str, float]] = {}
+    for batch in dataloader:
+        with torch.no_grad():
+            inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
+            outputs = generate_for_constrained_prefix_beam_search(
+                model, prefix_constrain_processor, input_ids=inputs["input_ids"].long(),
+                attention_mask=inputs["attention_mask"].long(), max_new_tokens=max_new_token, output_scores=True,
+                return_dict=True, return_dict_in_generate=True, num_beams=topk, num_return_sequences=topk)
+        batch_qids = batch["id"].cpu().tolist()
+        str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
+        relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
+        lo = outputs.row_lo.view(-1, topk).cpu().tolist()
+        hi = outputs.row_hi.view(-1, topk).cpu().tolist()
+        for qid, ranked, rel, los, his in zip(batch_qids, str_smtids, relevant_scores, lo, hi):
+            cur = qid_to_rankdata[qid] = {}
+            for smtid, rel_score, l, h in zip(ranked, rel, los, his):
+                known = (smtid in smtid_to_docid) if smtid_to_docid is not None else (h > l)
+                if not known:
+                    print(f"smtid: {smtid} not in smtid_to_docid")
+                else:
+                    cur[smtid] = rel_score
+    if write:
+        with open(os.path.join(out_dir, f"qid_to_smtid_{local_rank}.json"), "w") as fout:
+            json.dump(qid_to_rankdata, fout)
+    return qid_to_rankdata
+
+
+def constrained_decode_smtid(model, dataloader, prefix_constrain_processor, smtid_to_docids, max_new_token, device,
+                             out_dir, local_rank, topk=100, apply_log_softmax_for_scores=False, write=True):
+    """reference evaluate.py:134-178: nested ``{qid: {smtid: {docid: score}}}`` for the training-data
+    generation pass (prefix search: max_new_token in {4, 8, 16, 32}, many docids per smtid) ->
+    ``qid_smtid_rankdata_{rank}.json``. ``smtid_to_docids``: the reference's dict or a DocidTable."""
+    out: Dict[int, Dict[str, Dict[str, float]]] = {}
+    use_ranges = isinstance(smtid_to_docids, DocidTable)
+    for batch in dataloader:
+        with torch.no_grad():
+            inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
+            outputs = generate_for_constrained_prefix_beam_search(
+                model, prefix_constrain_processor, input_ids=inputs["input_ids"].long(),
+                attention_mask=inputs["attention_mask"].long(), max_new_tokens=max_new_token, output_scores=True,
+                return_dict=True, return_dict_in_generate=True, num_beams=topk, num_return_sequences=topk,
+                apply_log_softmax_for_scores=apply_log_softmax_for_scores)
+        batch_qids = batch["id"].cpu().tolist()
+        str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
+        relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
+        lo = outputs.row_lo.view(-1, topk).cpu().tolist()
+        hi = outputs.row_hi.view(-1, topk).cpu().tolist()
+        perm = prefix_constrain_processor.trie(device).perm if use_ranges else None
+        for qid, ranked, rel, los, his in zip(batch_qids, str_smtids, relevant_scores, lo, hi):
+            cur = out[qid] = {}
+            for smtid, rel_score, l, h in zip(ranked, rel, los, his):
+                docs = cur[smtid] = {}
+                score = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+                if use_ranges:
+                    for row in perm[l:h]:
+                        docs[smtid_to_docids.docids[int(row)]] = score
+                elif smtid in smtid_to_docids:
+                    for docid in smtid_to_docids[smtid]:
+                        docs[docid] = score
+    if write:
+        with open(os.path.join(out_dir, f"qid_smtid_rankdata_{local_rank}.json"), "w") as fout:
+            json.dump(out, fout)
+    return out
 
 
 def build_smtid_to_docids(docid_to_smtids: Dict[str, Sequence[int]], max_new_token: int) -> Dict[str, List[str]]:
@@ -203,6 +273,67 @@ def merge_runs(out_dir: str, expected_files: Optional[int] = None) -> Dict[str, 
     return merged
 
 
+def t5seq_aq_get_qid_to_smtid_rankdata(args):
+    """reference evaluate.py:528-611 (train-query pass that produces the (query, smtid-prefix, docids)
+    rank data): same search with ``--max_new_token`` in {4, 8, 16, 32} over ``--train_query_dir``."""
+    import torch.distributed as dist
+    from transformers import AutoTokenizer
+    from .dataset.sharding import shard_indices
+    from .modeling.t5_generative_retriever import T5SeqAQEncoder
+
+    ddp_setup()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    local_rank = max(0, int(args.local_rank if args.local_rank >= 0 else os.environ.get("LOCAL_RANK", 0)))
+    model = T5SeqAQEncoder.from_pretrained(args.pretrained_path)
+    model.eval()
+    if len(set(model.config.decoder_vocab_sizes)) != 1:
+        raise ValueError("not valid decoder_vocab_size")
+    assert args.max_new_token in [4, 8, 16, 32], args.max_new_token
+    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], args.max_new_token)
+    os.makedirs(args.out_dir, exist_ok=True)
+    tokenizer = AutoTokenizer.from_pretrained(args.pretrained_path)
+    coll = QueryCollection(args.train_query_dir)
+    model.to(local_rank)
+    model.base_model.config.decoding = True
+    loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), args.batch_size, 256)
+    constrained_decode_smtid(model.base_model, loader, processor, table, args.max_new_token, device=local_rank,
+                             out_dir=args.out_dir, local_rank=local_rank, topk=args.topk,
+                             apply_log_softmax_for_scores=args.apply_log_softmax_for_scores)
+
+
+def merge_qid_smtid_rankdata(out_dir: str, expected_files: Optional[int] = None):
+    """reference evaluate.py:613-655: merge ``qid_smtid_rankdata_*.json`` into ``qid_smtid_rankdata.json``."""
+    final = os.path.join(out_dir, "qid_smtid_rankdata.json")
+    if os.path.exists(final):
+        print("old run.json exisit.")
+        os.remove(final)
+    sub_paths = [p for p in os.listdir(out_dir) if "qid_smtid_rankdata" in p]
+    if expected_files is not None:
+        assert len(sub_paths) == expected_files, (sub_paths, expected_files)
+    merged: Dict[str, Dict[str, Dict[str, float]]] = {}
+    for sub_path in sub_paths:
+        with open(os.path.join(out_dir, sub_path)) as fin:
+            for qid, by_smtid in json.load(fin).items():
+                cur = merged.setdefault(qid, {})
+                for smtid, docs in by_smtid.items():
+                    cur.setdefault(smtid, {}).update(docs)
+    smtid_lengths = [len(v) for v in merged.values()]
+    doc_lengths = [len(d) for v in merged.values() for d in v.values()]
+    qs = [0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0]
+    print("smtid_length per query: ", np.quantile(smtid_lengths, qs) if smtid_lengths else [])
+    print("doc_length per smtid: ", np.quantile(doc_lengths, qs) if doc_lengths else [])
+    with open(final, "w") as fout:
+        json.dump(merged, fout)
+    for sub_path in sub_paths:
+        os.remove(os.path.join(out_dir, sub_path))
+    return merged
+
+
+def t5seq_aq_get_qid_to_smtid_rankdata_2(args):
+    return merge_qid_smtid_rankdata(args.out_dir, torch.cuda.device_count() if torch.cuda.is_available() else None)
+
+
 def t5seq_aq_retrieve_docids_2(args):
     """reference evaluate.py:489-526."""
     n = torch.cuda.device_count() if torch.cuda.is_available() else None
@@ -248,6 +379,8 @@ def get_args(argv=None):
     ap.add_argument("--max_new_token_for_docid", type=int, default=32)
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    ap.add_argument("--max_new_token", type=int, default=None)
+    ap.add_argument("--train_query_dir", default=None)
     ap.add_argument("--apply_log_softmax_for_scores", type=lambda s: str(s).lower() in ("1", "true", "yes"),
                     default=False)
     return ap.parse_args(argv)
@@ -259,6 +392,10 @@ def main(argv=None):
         t5seq_aq_retrieve_docids(args)
     elif args.task == "t5seq_aq_retrieve_docids_2":
         t5seq_aq_retrieve_docids_2(args)
+    elif args.task == "t5seq_aq_get_qid_to_smtid_rankdata":
+        t5seq_aq_get_qid_to_smtid_rankdata(args)
+    elif args.task == "t5seq_aq_get_qid_to_smtid_rankdata_2":
+        t5seq_aq_get_qid_to_smtid_rankdata_2(args)
     elif args.task == "evaluate":
         evaluate(args)
     else:

@@ -90,3 +90,36 @@ def test_trie_save_load_round_trip(golden_cache, tmp_path):
     sc = g.codes[t1.perm].astype(np.int64)
     key = [tuple(r) for r in sc]
     assert key == sorted(key)
+
+
+def test_prefix_search_shorter_than_model_length(golden_cache):
+    """Training-data generation searches prefixes (max_new_token 4/8/16 < the model's 32 positions,
+    reference evaluate.py:134-178,567): L smaller than the decoder length over the codes truncated to L
+    columns, where one smtid covers several docids. Compared with the oracle run the same way."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd import engine as E
+    g = golden_cache("g1_mini_b4_l8")
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, g.state_dict, g.dims)
+    for Lp in (1, 3):
+        codes = g.codes[:, :Lp]
+        trie = E.DeviceTrie.from_codes(ctx, codes, g.V)
+        res = E.search(model, trie, torch.from_numpy(g.input_ids), torch.from_numpy(g.attention_mask), g.B, Lp)
+        torch.cuda.synchronize()
+        d2s = {str(i): [-1] + [int(x) for x in row] for i, row in enumerate(codes)}
+        pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), g.V)
+        seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(g.state_dict, g.dims), pm, g.input_ids,
+                                            g.attention_mask, g.B, Lp, use_kv_cache=True)
+        assert (res.tokens.cpu().numpy() == seqs.numpy().reshape(g.Q, g.B, Lp + 1)[:, :, 1:]).all()
+        np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(g.Q, g.B), atol=1e-4, rtol=0)
+        lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
+        tok = res.tokens.cpu().numpy()
+        sizes = hi - lo
+        assert (sizes >= 1).all()
+        if Lp == 1:
+            assert sizes.max() > 1, "1000 docs over 256 one-token prefixes must share prefixes"
+        for q in range(g.Q):
+            for b in range(g.B):
+                rows = trie.perm[lo[q, b]:hi[q, b]]
+                assert (codes[rows] == tok[q, b][None, :]).all()
+                assert len(rows) == int((codes == tok[q, b][None, :]).all(axis=1).sum())

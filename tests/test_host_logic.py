@@ -183,3 +183,44 @@ def test_synth_generators_are_stable():
     assert all(ids[i, lens[i] - 1] == 1 for i in range(16)) and (ids * (1 - mask) == 0).all()
     c = synth.make_codes_fast(1000, 32, 256)
     assert c.shape == (1000, 32) and c.dtype == np.uint16 and c.max() < 256
+
+
+def test_constrained_decode_smtid_and_merge(monkeypatch, tmp_path):
+    """Nested qid -> smtid -> docid -> score output of the prefix-search pass (reference
+    evaluate.py:134-178) from the dict path and the row-range path, and the _2 merge (:613-655)."""
+    L, B = 2, 2
+    codes = np.array([[1, 2], [1, 2], [1, 3], [4, 4]], dtype=np.uint16)  # prefix (1,2) holds two docids
+    docids = ["a", "b", "c", "d"]
+    d2s = {d: [-1] + [int(x) for x in row] + [9, 9] for d, row in zip(docids, codes)}  # deeper ids, prefix-truncated
+    smtid_to_docids = EV.build_smtid_to_docids(d2s, L)
+    assert smtid_to_docids["1_2"] == ["a", "b"]
+    order = np.lexsort(codes.T[::-1])
+    sc = codes[order]
+
+    def rng(tok):
+        hit = [i for i, r in enumerate(sc) if (r == tok).all()]
+        return (hit[0], hit[-1] + 1) if hit else (0, 0)
+
+    seqs = torch.tensor([[0, 1, 2], [0, 8, 8], [0, 4, 4], [0, 1, 3]])
+    scores = torch.tensor([2.0, 1.0, 0.5, 0.25], dtype=torch.float32)
+    lo = torch.tensor([rng(s[1:].numpy())[0] for s in seqs]); hi = torch.tensor([rng(s[1:].numpy())[1] for s in seqs])
+    out = GEN.BeamSearchEncoderDecoderOutput(sequences=seqs, sequences_scores=scores, row_lo=lo, row_hi=hi)
+    batch = {"input_ids": torch.ones((2, 3), dtype=torch.long), "attention_mask": torch.ones((2, 3), dtype=torch.long),
+             "id": torch.tensor([5, 6])}
+
+    class FakeTrie:
+        perm = order.astype(np.int64)
+
+    class FakeProc:
+        def trie(self, device):
+            return FakeTrie()
+
+    monkeypatch.setattr(EV, "generate_for_constrained_prefix_beam_search", _fake_generate([out, out, out]))
+    a = EV.constrained_decode_smtid(None, [batch], FakeProc(), smtid_to_docids, L, "cpu", str(tmp_path), 0, topk=B)
+    b = EV.constrained_decode_smtid(None, [batch], FakeProc(), EV.DocidTable(docids), L, "cpu", str(tmp_path), 1, topk=B)
+    assert a == b == {5: {"1_2": {"a": 4.0, "b": 4.0}, "8_8": {}}, 6: {"4_4": {"d": 1.0}, "1_3": {"c": 0.5}}}
+    merged = EV.merge_qid_smtid_rankdata(str(tmp_path), expected_files=2)
+    assert merged == {"5": {"1_2": {"a": 4.0, "b": 4.0}, "8_8": {}}, "6": {"4_4": {"d": 1.0}, "1_3": {"c": 0.5}}}
+    assert os.listdir(tmp_path) == ["qid_smtid_rankdata.json"]
+    c = EV.constrained_decode(None, [batch], FakeProc(), None, L, "cpu", str(tmp_path), 0, topk=B)
+    assert c == {5: {"1_2": 2.0}, 6: {"4_4": 0.5, "1_3": 0.25}}
