@@ -1,0 +1,103 @@
+"""-m gpu: edge cases of the search path against the CPU oracle (KV-cached variant, itself pinned to the
+reference by tests/test_oracle_golden.py): greedy B=1 (BASELINE config 1; the reference's HF scorer refuses
+num_beams=1, the oracle treats it as the degenerate case), single query, L=1, long queries (Lq up to 200,
+multi-chunk attention paths), masks that are not a prefix (left padding, holes), ragged batches whose
+row count is not a multiple of any GEMM tile, exact-fp32 precision mode."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import beam_ref, t5_ref
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    L, V, N = 6, 256, 400
+    dims = synth.mini_dims(L=L, V=V, enc_layers=2, d_ff=256, vocab_size=512)
+    sd = synth.make_state_dict(dims, seed=31)
+    codes = synth.make_codes(N, L, V, seed=31)
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+
+    def oracle(ids, mask, B, Lx):
+        m = t5_ref.T5RefCached(sd, dims)
+        seqs, sc = beam_ref.beam_search_ref(m, pm, ids, mask, B, Lx, use_kv_cache=True)
+        Q = ids.shape[0]
+        return seqs.numpy().reshape(Q, B, Lx + 1)[:, :, 1:], sc.numpy().reshape(Q, B)
+
+    def hip(ids, mask, B, Lx, **kw):
+        r = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, Lx, **kw)
+        torch.cuda.synchronize()
+        return r.tokens.cpu().numpy(), r.scores.cpu().numpy()
+
+    yield dict(E=E, ctx=ctx, dims=dims, oracle=oracle, hip=hip, synth=synth, L=L)
+    ctx.set_precision("f16x2")
+
+
+def _check(s, ids, mask, B, Lx, **kw):
+    et, es = s["oracle"](ids, mask, B, Lx)
+    gt, gs = s["hip"](ids, mask, B, Lx, **kw)
+    assert np.array_equal(gt, et), "smtid sequences differ from the oracle"
+    np.testing.assert_allclose(gs, es, atol=1e-4, rtol=0)
+
+
+def test_greedy_single_beam(setup):
+    ids, mask = setup["synth"].make_queries(5, vocab_size=512, seed=3, max_len=14)
+    _check(setup, ids, mask, 1, setup["L"])
+
+
+def test_single_query_and_single_step(setup):
+    ids, mask = setup["synth"].make_queries(1, vocab_size=512, seed=4, max_len=10)
+    _check(setup, ids, mask, 3, setup["L"])
+    _check(setup, ids, mask, 4, 1)
+
+
+def test_ragged_row_counts(setup):
+    # Q*B = 7*9 = 63 rows and Q*Lq tokens not multiples of 32/64/128
+    ids, mask = setup["synth"].make_queries(7, vocab_size=512, seed=5, max_len=13)
+    _check(setup, ids, mask, 9, 4)
+
+
+def test_long_queries_multi_chunk_attention(setup):
+    ids, mask = setup["synth"].make_queries(3, vocab_size=512, seed=6, min_len=70, max_len=200, mean_len=130, std_len=50)
+    assert ids.shape[1] > 64
+    _check(setup, ids, mask, 4, 3)
+
+
+def test_non_prefix_masks(setup):
+    ids, mask = setup["synth"].make_queries(4, vocab_size=512, seed=7, max_len=16)
+    Lq = ids.shape[1]
+    # query 0: left padding (valid tokens moved to the right end); query 1: a hole in the middle
+    n0 = int(mask[0].sum())
+    ids2, mask2 = ids.copy(), mask.copy()
+    ids2[0] = 0; mask2[0] = 0
+    ids2[0, Lq - n0:] = ids[0, :n0]; mask2[0, Lq - n0:] = 1
+    mask2[1, 2] = 0
+    _check(setup, ids2, mask2, 4, 4)
+
+
+def test_exact_fp32_mode_matches_oracle(setup):
+    setup["ctx"].set_precision("f32")
+    try:
+        ids, mask = setup["synth"].make_queries(6, vocab_size=512, seed=8, max_len=15)
+        _check(setup, ids, mask, 5, setup["L"])
+        _check(setup, ids, mask, 5, setup["L"], use_graph=False)
+    finally:
+        setup["ctx"].set_precision("f16x2")
+
+
+def test_argument_errors_cross_the_abi_as_exceptions(setup):
+    E = setup["E"]
+    ids, mask = setup["synth"].make_queries(2, vocab_size=512, seed=9, max_len=10)
+    with pytest.raises(E.RiporHipError, match="exceeds"):
+        setup["hip"](ids, mask, 2, setup["L"] + 1)       # L beyond the model's decoder length / trie depth
+    with pytest.raises(E.RiporHipError, match="out of range|NULL argument"):
+        setup["hip"](ids, mask, 0, 2)                    # B < 1 (empty output buffers)
+    big = np.ones((1, 300), dtype=np.int64)
+    with pytest.raises(E.RiporHipError, match="Lq out of range"):
+        setup["hip"](big, big, 2, 2)
