@@ -310,6 +310,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 // instruction), but every K and V row of the beam's ancestry is requested up front into registers,
 // so a wave keeps up to 2 * SELF_MAXIT KB in flight instead of one row group at a time — the
 // per-wave-serialised version was latency-bound at ~3.9 TB/s algorithmic. No LDS.
+// K/V rows are read exactly once per step and never reused: stream them past the caches (nt)
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 constexpr int SELF_MAXIT = 9;  // 36 keys: covers L <= 35 (the reference uses L = 32 or 16)
 
 __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs a) {
@@ -342,10 +349,10 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 4);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) kreg[it] = *reinterpret_cast<const float4*>(a.kcache + off[it]);
+    if (it * 4 < nkeys) kreg[it] = ld_stream(a.kcache + off[it]);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) vreg[it] = *reinterpret_cast<const float4*>(a.vcache + off[it]);
+    if (it * 4 < nkeys) vreg[it] = ld_stream(a.vcache + off[it]);
 
   float sc[SELF_MAXIT];
   float mx = -INFINITY;
