@@ -241,7 +241,7 @@ def main():
             if args.precision == "f32":
                 kname, peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
             else:
-                kname, peak = "rpr::gemm_h2_dma_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
+                kname, peak = "rpr::gemm_h2_pipe_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
                 note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
                         "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3")
             traffic, traffic_src = None, None
@@ -249,7 +249,7 @@ def main():
             if os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
                 try:
                     pmc = json.load(open(pmc_path))
-                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_dma_kernel<256" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pipe_kernel" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
                     if key:
                         # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
                         traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
