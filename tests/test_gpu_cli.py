@@ -1,0 +1,110 @@
+"""-m gpu: the reference's shell pipeline for this path, end to end on synthetic data
+(full_scripts/full_evaluate_t5seq_aq_encoder.sh:176-205): build_list_smtid_to_nextids ->
+`python -m t5_pretrainer.evaluate --task=t5seq_aq_retrieve_docids` -> `..._2` (merge + evaluate), with a
+checkpoint directory, docid_to_smtid.json, raw.tsv queries, a SentencePiece tokenizer trained offline and
+synthetic qrels. The run.json written by the CLI must equal what the Python API returns for the same
+tokenised queries."""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_world(root):
+    import sentencepiece as spm
+    from ripor_amd.modeling.t5_generative_retriever import T5SeqAQEncoder
+    from ripor_amd.utils import synth
+    L, V, N = 8, 256, 600
+    ckpt = os.path.join(root, "checkpoint")
+    os.makedirs(ckpt)
+    random.seed(0)
+    words = ["what", "is", "the", "how", "to", "of", "in", "a", "best", "price", "weather", "define"] + [f"w{i}" for i in range(200)]
+    corpus = os.path.join(root, "corpus.txt")
+    with open(corpus, "w") as f:
+        for _ in range(2000):
+            f.write(" ".join(random.choice(words) for _ in range(random.randint(3, 12))) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(ckpt, "spiece"), vocab_size=256,
+                                   model_type="unigram", pad_id=0, eos_id=1, unk_id=2, bos_id=-1, pad_piece="<pad>",
+                                   eos_piece="</s>", unk_piece="<unk>", hard_vocab_limit=False, minloglevel=2)
+    json.dump({"tokenizer_class": "T5Tokenizer", "extra_ids": 0, "model_max_length": 512},
+              open(os.path.join(ckpt, "tokenizer_config.json"), "w"))
+    dims = synth.mini_dims(L=L, V=V, enc_layers=2, d_ff=128, vocab_size=512)
+    T5SeqAQEncoder.from_synthetic(dims, seed=77).save_pretrained(ckpt)
+    codes = synth.make_codes(N, L, V, seed=77)
+    data = os.path.join(root, "msmarco_toyset")           # "msmarco" in the path -> dataset name MSMARCO
+    os.makedirs(os.path.join(data, "aq_smtid"))
+    os.makedirs(os.path.join(data, "dev_queries"))
+    d2s_path = os.path.join(data, "aq_smtid", "docid_to_smtid.json")
+    json.dump({str(100 + i): [-1] + [int(x) for x in row] for i, row in enumerate(codes)}, open(d2s_path, "w"))
+    queries = {str(900 + i): " ".join(random.choice(words) for _ in range(random.randint(3, 9))) for i in range(11)}
+    with open(os.path.join(data, "dev_queries", "raw.tsv"), "w") as f:
+        for qid, text in queries.items():
+            f.write(f"{qid}\t{text}\n")
+    return ckpt, d2s_path, os.path.join(data, "dev_queries"), codes, queries, dims
+
+
+def _run(args, env=None):
+    e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    e.update(env or {})
+    p = subprocess.run([sys.executable] + args, cwd=REPO, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    return p.stdout
+
+
+def test_shell_pipeline_end_to_end(tmp_path):
+    ckpt, d2s_path, qdir, codes, queries, dims = _make_world(str(tmp_path))
+    out_dir = os.path.join(str(tmp_path), "out")
+    B, L = 5, 8
+    _run(["-m", "t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids", "--docid_to_smtid_path", d2s_path])
+    assert os.path.exists(os.path.join(os.path.dirname(d2s_path), "list_smtid_to_nextids.rprtrie"))
+    # one process per GPU through torch.distributed.run, like the script's torch.distributed.launch
+    _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+          "--master-port", "29533", "-m", "t5_pretrainer.evaluate", f"--pretrained_path={ckpt}", f"--out_dir={out_dir}",
+          "--task=t5seq_aq_retrieve_docids", f"--docid_to_smtid_path={d2s_path}",
+          "--q_collection_paths=" + json.dumps([qdir]), "--batch_size=4", f"--max_new_token_for_docid={L}", f"--topk={B}"])
+    run_part = os.path.join(out_dir, "MSMARCO", "run_0.json")
+    assert os.path.exists(run_part)
+    run = json.load(open(run_part))
+    assert set(run) == set(queries)
+    # synthetic qrels: the top document of every query is relevant -> MRR@10 must be 1.0
+    qrel = {qid: {max(docs, key=docs.get): 1} for qid, docs in run.items()}
+    qrel_path = os.path.join(str(tmp_path), "msmarco_toyset", "dev_qrel.json")
+    json.dump(qrel, open(qrel_path, "w"))
+    _run(["-m", "t5_pretrainer.evaluate", "--task=t5seq_aq_retrieve_docids_2", f"--out_dir={out_dir}",
+          "--q_collection_paths=" + json.dumps([qdir]), "--eval_qrel_path=" + json.dumps([qrel_path])])
+    merged = json.load(open(os.path.join(out_dir, "MSMARCO", "run.json")))
+    assert merged == run and not os.path.exists(run_part)
+    perf = json.load(open(os.path.join(out_dir, "MSMARCO", "perf.json")))
+    assert perf["mrr_10"] == 1.0 and "recall_10" in perf
+
+    # the CLI result == the Python API on the same tokenised queries
+    from transformers import AutoTokenizer
+    from ripor_amd import engine as E
+    from ripor_amd.evaluate import QueryCollection, query_batches
+    from ripor_amd.modeling.t5_generative_retriever import T5SeqAQEncoder
+    tok = AutoTokenizer.from_pretrained(ckpt)
+    coll = QueryCollection(qdir)
+    model = T5SeqAQEncoder.from_pretrained(ckpt).to(0)
+    ctx = E.Context.get(0)
+    trie = E.DeviceTrie.from_codes(ctx, codes, 256)
+    for batch in query_batches(coll, tok, list(range(len(coll))), 4, 256):
+        res = E.search(model.base_model.engine_model(), trie, batch["input_ids"], batch["attention_mask"], B, L)
+        torch.cuda.synchronize()
+        lo, hi, sc = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy(), res.scores.cpu().numpy()
+        for qi, qid in enumerate(batch["id"].tolist()):
+            expect = {}
+            for b in range(B):
+                for row in trie.perm[lo[qi, b]:hi[qi, b]]:
+                    expect[str(100 + int(row))] = float(sc[qi, b]) * L
+            got = run[str(qid)]
+            assert set(got) == set(expect)
+            for d in expect:
+                assert abs(got[d] - expect[d]) < 1e-3
