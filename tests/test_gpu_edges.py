@@ -101,3 +101,24 @@ def test_argument_errors_cross_the_abi_as_exceptions(setup):
     big = np.ones((1, 300), dtype=np.int64)
     with pytest.raises(E.RiporHipError, match="Lq out of range"):
         setup["hip"](big, big, 2, 2)
+
+
+def test_scaleup_output_hidden_and_1024_codebook(setup):
+    """config.scaleup_output_hidden (reference t5_generative_retriever.py:427-428) and the 16 x 1024 code
+    layout (full_16_1024_scripts): a second model built here, compared with the oracle."""
+    from oracle import beam_ref, t5_ref
+    E, synth = setup["E"], setup["synth"]
+    L, V, N = 5, 1024, 700
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512, scaleup_output_hidden=True)
+    sd = synth.make_state_dict(dims, seed=41, logit_scale=8.0)   # logits are scaled by 768**-0.5: keep them O(10)
+    codes = synth.make_codes(N, L, V, seed=41)
+    ctx = setup["ctx"]
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    ids, mask = synth.make_queries(5, vocab_size=512, seed=42, max_len=12)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, 6, L, use_kv_cache=True)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), 6, L)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(5, 6, L + 1)[:, :, 1:])
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(5, 6), atol=1e-4, rtol=0)
