@@ -172,6 +172,7 @@ struct LinOut {                                                              // 
   float* f[3]; int ldo[3]; int split_n;                                      //   fp32 (up to 3 column blocks)
   __half* h; size_t ps; int ldh;                                             //   or f16 planes (next GEMM's input)
   const float* resid; int relu;
+  int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
 };
 
 LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
@@ -192,12 +193,14 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) 
     g.split_n = O.split_n; g.out_h = O.h; g.o_ps = O.ps; g.ldoh = O.ldh;
     g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
     g.trace = L.c->trace_buf;
+    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
   } else {
     GemmArgs g{};
     g.A = A.f; g.lda = A.ld; g.W = W.f; g.ldw = W.K; g.resid = O.resid; g.ldr = O.ldo[0];
     for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
     g.split_n = O.split_n; g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
+    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
   }
 }
@@ -318,6 +321,18 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   __half *h_h = P<__half>(w.h_h), *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
   const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
   const size_t layer_stride = (size_t)L * R * inner;
+  // KV cache of one layer: [q][head][position][slot][64] — the rows one (query, head) group of beams can
+  // touch are one contiguous L*B*256-B region (80 KB for B=10, L=32) and the B candidate rows of a position
+  // are adjacent, so the 256-B row reads of neighbouring waves fall into the same DRAM pages.
+  // RPR_KV_LAYOUT=pos | query selects [position][q][slot][inner] | [q][position][slot][inner] (diagnostic).
+  static const int kv_layout = [] {
+    const char* e = getenv("RPR_KV_LAYOUT");
+    return !e ? 2 : !strcmp(e, "pos") ? 0 : !strcmp(e, "query") ? 1 : 2;
+  }();
+  size_t kv_q, kv_h, kv_pos, kv_slot;
+  if (kv_layout == 0)      { kv_q = (size_t)B * inner;     kv_h = DKV;                 kv_pos = (size_t)R * inner; kv_slot = inner; }
+  else if (kv_layout == 1) { kv_q = (size_t)L * B * inner; kv_h = DKV;                 kv_pos = (size_t)B * inner; kv_slot = inner; }
+  else                     { kv_q = (size_t)L * B * inner; kv_h = (size_t)L * B * DKV; kv_pos = (size_t)B * DKV;   kv_slot = DKV; }
   auto norm = [&](const float* wgt, float post = 1.0f) {
     Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] {
       return launch_rmsnorm(x, wgt, h2 ? nullptr : h, R, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
@@ -335,12 +350,13 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       norm(m->dec_ln0[i]);
       {  // q -> qb, k/v -> cache row block of position t
         LinOut o{};
-        o.f[0] = qb; o.f[1] = kc + (size_t)t * R * inner; o.f[2] = vc + (size_t)t * R * inner;
+        o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
         o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
+        o.rm_B = B; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
         linear(Ln, in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, o);
       }
       {
-        DecSelfAttnArgs a{qb, kc, vc, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t,
+        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t,
                           h2 ? attn_h : nullptr, ps_i};
         Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * R * H * (double)(t + 1) * DKV,
                4.0 * ((double)R * inner * 2 + 2.0 * R * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });

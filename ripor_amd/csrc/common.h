@@ -47,6 +47,9 @@ struct GemmArgs {
   int split_n;                  // == N when there is a single output
   int M, N, K;
   int relu;
+  // KV-cache element map for the outputs 1 and 2 (rm_B == 0: plain [M, ldo] rows): element (m, n) goes to
+  // out[i] + (m / rm_B) * rm_stride + (m % rm_B) * rm_slot + (n / 64) * rm_head + n % 64   
+  int rm_B; size_t rm_stride, rm_slot, rm_head;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -60,7 +63,18 @@ struct GemmH2Args {
   int M, N, K;
   int relu;
   unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
+  int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
 };
+
+// offset (in floats) of output element (m, on) in output block oi; on..on+3 stay inside one head
+template <class G>
+__device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, int on) {
+  if (g.rm_B && oi) {
+    const int qi = m / g.rm_B;
+    return (size_t)qi * g.rm_stride + (size_t)(m - qi * g.rm_B) * g.rm_slot + (size_t)(on >> 6) * g.rm_head + (on & 63);
+  }
+  return (size_t)m * ldo + on;
+}
 hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s);
 hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s);
 
@@ -90,8 +104,9 @@ hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
 
 struct DecSelfAttnArgs {
   const float* q;          // [R, inner]
-  const float* kcache;     // this layer: [Lmax, R, inner]
-  const float* vcache;
+  const float* kcache;     // this layer: the 64 floats of (q, head, p, slot) start at
+  const float* vcache;     //   q*q_stride + head*h_stride + p*pos_stride + slot*slot_stride
+  size_t q_stride, h_stride, pos_stride, slot_stride;
   const uint16_t* anc;     // [R, anc_ld]: slot (within the query) that produced position p < t
   int anc_ld;
   const float* rel_bias;   // [buckets, H]

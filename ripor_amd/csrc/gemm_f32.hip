@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
           float v = acc[i][j][r];
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.resid) v = res[r] + v;
-          outp[(size_t)m * ldo + on] = v;
+          outp[out_off(g, oi, m, ldo, on)] = v;
         }
       }
     }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
           } else {
-            outp[(size_t)m * ldo + on] = v;
+            outp[out_off(g, oi, m, ldo, on)] = v;
           }
         }
       }
@@ -393,7 +393,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
           } else {
-            outp[(size_t)m * ldo + on] = v;
+            outp[out_off(g, oi, m, ldo, on)] = v;
           }
         }
       }
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kern
           *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
           *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
         } else {
-          *reinterpret_cast<float4*>(outp + (size_t)m * ldo + on) = v;
+          *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
         }
       }
     }

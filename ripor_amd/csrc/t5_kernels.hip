@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
                                                         int anc_ld, const float* __restrict__ rel_bias,
                                                         const int32_t* __restrict__ bucket, const int32_t* __restrict__ mask,
                                                         float* __restrict__ out, int Q, int B, int H, int t, int Lq,
-                                                        int xld, __half* __restrict__ out_h, size_t o_ps) {
+                                                        int xld, __half* __restrict__ out_h, size_t o_ps,
+                                                        size_t q_stride, size_t h_stride, size_t pos_stride,
+                                                        size_t slot_stride) {
   __shared__ float Ss[4][MAX_LQ];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   auto row_off = [&](int p) -> size_t {
     if (SELF) {
       const int slot = (p == t) ? b : (int)ancr[p];
-      return ((size_t)p * R + (size_t)qi * B + slot) * inner + h * DKV + li * 4;
+      return (size_t)qi * q_stride + (size_t)h * h_stride + (size_t)p * pos_stride + (size_t)slot * slot_stride + li * 4;
     } else {
       return ((size_t)qi * Lq + p) * (size_t)xld + h * DKV + li * 4;
     }
@@ -317,8 +319,12 @@ __device__ __forceinline__ float4 ld_stream(const float* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-constexpr int SELF_MAXIT = 9;  // 36 keys: covers L <= 35 (the reference uses L = 32 or 16)
+constexpr int SELF_MAXIT_MAX = 9;  // 36 keys: covers L <= 35 (the reference uses L = 32 or 16)
 
+// SELF_MAXIT = row groups of 4 keys held in registers. Early steps use the small instantiations: fewer
+// VGPRs -> 8 waves per SIMD instead of 4, which is what hides the anc -> K/V dependent-load chain when a
+// wave only has a few hundred bytes to fetch.
+template <int SELF_MAXIT>
 __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs a) {
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
     const int p = it * 4 + g;
     const int pc = p < nkeys ? p : t;
     const int slot = (pc == t) ? b : (int)ancr[pc];
-    off[it] = ((size_t)pc * R + (size_t)qi * B + slot) * inner + h * DKV + li * 4;
+    off[it] = (size_t)qi * a.q_stride + (size_t)h * a.h_stride + (size_t)pc * a.pos_stride + (size_t)slot * a.slot_stride + li * 4;
   }
   const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 4);
 #pragma unroll
@@ -406,12 +412,19 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
 
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
-  if (a.t + 1 <= 4 * SELF_MAXIT) {
-    hipLaunchKernelGGL(dec_self_attn_fast_kernel, dim3((items + 3) / 4), dim3(256), 0, s, a);
+  const dim3 grid((items + 3) / 4), blk(256);
+  const int nk = a.t + 1;
+  if (nk <= 8) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<2>, grid, blk, 0, s, a); return hipGetLastError(); }
+  if (nk <= 16) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<4>, grid, blk, 0, s, a); return hipGetLastError(); }
+  if (nk <= 24) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<6>, grid, blk, 0, s, a); return hipGetLastError(); }
+  if (nk <= 32) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<8>, grid, blk, 0, s, a); return hipGetLastError(); }
+  if (nk <= 4 * SELF_MAXIT_MAX) {
+    hipLaunchKernelGGL(dec_self_attn_fast_kernel<SELF_MAXIT_MAX>, grid, blk, 0, s, a);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
-                     a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps);
+                     a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps,
+                     a.q_stride, a.h_stride, a.pos_stride, a.slot_stride);
   return hipGetLastError();
 }
 
