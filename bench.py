@@ -241,15 +241,17 @@ def main():
             if args.precision == "f32":
                 kname, peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
             else:
-                kname, peak = "rpr::gemm_h2_pipe_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
+                kname, peak = "rpr::gemm_h2_pp_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
                 note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
-                        "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3")
+                        "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3 at the nominal 2.4 GHz; the in-kernel "
+                        "s_memtime/s_memrealtime trace (tools/gemm_trace_pp.py) shows the chip sustaining 1.64-1.76 GHz "
+                        "under this kernel (DVFS), i.e. ~0.6 of the peak at the sustained clock")
             traffic, traffic_src = None, None
             pmc_path = os.path.join(REPO, "profiles", "latest_hbm_pmc.json")
             if os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
                 try:
                     pmc = json.load(open(pmc_path))
-                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pipe_kernel" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
                     if key:
                         # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
                         traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0

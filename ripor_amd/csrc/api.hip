@@ -719,12 +719,14 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   }
   linear(Ln, {A, Ah, (size_t)M * K, K}, {W, Wh, N, K}, M, out_f32(C, N, N, residual, relu));
   if (Ah) { RPR_HIP(hipStreamSynchronize(s)); RPR_HIP(hipFree(Ah)); RPR_HIP(hipFree(Wh)); }
-  if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x 6 stamps
-    const size_t n = (size_t)(K / 32) * 8 * 6;
+  if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x W stamps (6: pipe kernel, 18: ping-pong)
+    const char* we = getenv("RPR_GEMM_TRACE_W");
+    const size_t tw = we ? (size_t)atoi(we) : 6;
+    const size_t n = (size_t)(K / 32) * 8 * tw;
     std::vector<unsigned long long> hbuf(n);
     RPR_HIP(hipMemcpy(hbuf.data(), c->trace_buf, n * 8, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(getenv("RPR_GEMM_TRACE"), "w")) {
-      for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", hbuf[i], (i % 6 == 5) ? '\n' : ' ');
+      for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", hbuf[i], (i % tw == tw - 1) ? '\n' : ' ');
       fclose(f);
     }
   }

@@ -401,6 +401,71 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   }
 }
 
+// ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
+template <bool FULL, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
+                                                int lane, int bm, int bn, int wm, int wn) {
+  constexpr int BM = 256, BN = 256;
+  // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
+  // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
+  // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
+  // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
+  // operand LDS and streams them out as float4 rows: 16 residual loads in flight per lane, 4x fewer
+  // store instructions, f16 planes written 8 bytes at a time.
+  __syncthreads();                                   // all waves are done reading operand tiles
+  constexpr int SW = TN * 32;                         // staged row width (floats)
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
+  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+  constexpr int LPR = SW / 4, RPI = 64 / LPR;          // lanes per staged row, rows per read instruction
+  const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
+  const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
+  const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
+  const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
+  float* outp = g.out[oi];
+  const int ldo = g.ldo[oi];
+#pragma unroll
+  for (int half = 0; half < TM / 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[half * 2 + ii][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int mrow0 = bm + wm * (BM / WM) + half * 64;
+    constexpr int NK = 64 / RPI;
+    float4 res[NK];
+    if (g.resid) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int m = mrow0 + k * RPI + rrow;
+        res[k] = (ncol_ok && (FULL || m < g.M)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int rl = k * RPI + rrow, m = mrow0 + rl;
+      float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+      if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
+      if (ncol_ok && (FULL || m < g.M)) {
+        if (g.out_h) {
+          __half h[4], l[4];
+          split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+          *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
+        } else {
+          *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
+  }
+}
+
 // ---- software-pipelined 256x256 variant -----------------------------------------------------------------
 // Same tile/LDS layout as gemm_h2_dma_kernel<256,256,2,4>, but the fragment reads are pipelined by
 // hand: a K-tile is two 16-wide chunks; while the MFMAs of one chunk run, the ds_reads of the next
@@ -527,65 +592,190 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kern
   }
 #undef H2_STAMP
 
-  // ---- epilogue: transpose through LDS, then row-wise 16-byte global accesses ---------------------------
-  // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
-  // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
-  // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
-  // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
-  // operand LDS and streams them out as float4 rows: 16 residual loads in flight per lane, 4x fewer
-  // store instructions, f16 planes written 8 bytes at a time.
-  __syncthreads();                                   // all waves are done reading operand tiles
-  constexpr int SW = TN * 32;                         // staged row width (floats)
-  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
-  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-  constexpr int LPR = SW / 4, RPI = 64 / LPR;          // lanes per staged row, rows per read instruction
-  const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
-  const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
-  const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
-  const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
-  float* outp = g.out[oi];
-  const int ldo = g.ldo[oi];
-#pragma unroll
-  for (int half = 0; half < TM / 2; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[half * 2 + ii][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-    const int mrow0 = bm + wm * (BM / WM) + half * 64;
-    constexpr int NK = 64 / RPI;
-    float4 res[NK];
-    if (g.resid) {
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int m = mrow0 + k * RPI + rrow;
-        res[k] = (ncol_ok && (FULL || m < g.M)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int rl = k * RPI + rrow, m = mrow0 + rl;
-      float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-      if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
-      if (ncol_ok && (FULL || m < g.M)) {
-        if (g.out_h) {
-          __half h[4], l[4];
-          split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
-          *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
-          *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
-        } else {
-          *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn);
+}
+
+// ---- ping-pong 256x256 variant -------------------------------------------------------------------------
+// Same tile, LDS layout and epilogue as the pipe kernel; different K-loop synchronisation. The 8 waves are
+// two groups of four (wm = 0 / 1), one wave of each group per SIMD. A K-tile is four phases (k-chunk x
+// half of the wave's A rows), each phase = a load segment (fragment ds_reads + LDS-DMA issue) and an MFMA
+// segment (12 MFMAs), separated by raw s_barriers:
+//       L_p | barrier | M_p | barrier | L_p+1 | ...
+// Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA segment while the other
+// issues its loads: the LDS read latency (which the in-phase pipe kernel pays with the MFMA pipe idle) is
+// hidden behind the other group's MFMAs. LDS-DMA of tile t+1 is issued in the MFMA shadows of M_0..M_2 of tile t
+// (a piece costs ~100 issue cycles in a load segment, which made L longer than M), retired by
+// `s_waitcnt vmcnt(0)` at the end of L_3 and first read in L_0 of tile t+1 (one phase after the wait, as
+// the staggered groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's
+// last reads are retired before the other group starts overwriting it.
+template <bool FULL, bool TRACE = false, int DV = 1, bool PRIO = true>
+__global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
+  constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
+  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
+
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
   }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const __half* src[PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int lrow = 16 * (wave + NW * j) + (lane >> 2);
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const __half* base;
+    int trow, limit;
+    size_t ld;
+    if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
+    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    if (!FULL && trow >= limit) trow = limit - 1;
+    src[j] = base + (size_t)trow * ld + seg * 8;
+  }
+#define PP_PIECE(buf, k0, j)                                                                                   \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (k0)),             \
+                                   (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
+                                                                             16 * (wave + NW * (j)) * HBK),     \
+                                   16, 0, 0)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
+  const int a_row = wm * (BM / WM) + frow, w_row = 2 * BM + wn * (BN / WN) + frow;
+  const int so0 = ((0 + hf) ^ sw) * 8, so1 = ((2 + hf) ^ sw) * 8;   // segment offsets of chunk 0 / 1
+
+  f16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+#define PP_LOAD_W(buf, so)                                                                              \
+  {                                                                                                     \
+    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
+    bh0 = *reinterpret_cast<const f16x8*>(base_ + (w_row) * HBK + (so));                                \
+    bh1 = *reinterpret_cast<const f16x8*>(base_ + (w_row + 32) * HBK + (so));                           \
+    bl0 = *reinterpret_cast<const f16x8*>(base_ + (BN + w_row) * HBK + (so));                           \
+    bl1 = *reinterpret_cast<const f16x8*>(base_ + (BN + w_row + 32) * HBK + (so));                      \
+  }
+#define PP_LOAD_A(buf, so, i0)                                                                          \
+  {                                                                                                     \
+    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
+    ah0 = *reinterpret_cast<const f16x8*>(base_ + (a_row + (i0) * 32) * HBK + (so));                    \
+    ah1 = *reinterpret_cast<const f16x8*>(base_ + (a_row + (i0) * 32 + 32) * HBK + (so));               \
+    al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32) * HBK + (so));               \
+    al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32 + 32) * HBK + (so));          \
+  }
+#define PP_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// the 12 MFMAs of a phase in three groups of four (lo*hi, hi*lo, hi*hi); D1..D3 are statements issued in the
+// MFMA shadows after the 2nd, 6th and 10th MFMA (LDS-DMA pieces of the next tile, or nothing)
+#define PP_MMA(i0, D1, D2, D3)                                                                          \
+  {                                                                                                     \
+    PP_MFMA(al0, bh0, acc[(i0)][0]); PP_MFMA(al0, bh1, acc[(i0)][1]);                                   \
+    __builtin_amdgcn_sched_barrier(0); D1; __builtin_amdgcn_sched_barrier(0);                           \
+    PP_MFMA(al1, bh0, acc[(i0) + 1][0]); PP_MFMA(al1, bh1, acc[(i0) + 1][1]);                           \
+    PP_MFMA(ah0, bl0, acc[(i0)][0]); PP_MFMA(ah0, bl1, acc[(i0)][1]);                                   \
+    __builtin_amdgcn_sched_barrier(0); D2; __builtin_amdgcn_sched_barrier(0);                           \
+    PP_MFMA(ah1, bl0, acc[(i0) + 1][0]); PP_MFMA(ah1, bl1, acc[(i0) + 1][1]);                           \
+    PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                   \
+    __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                           \
+    PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                           \
+  }
+#define PP_DMA(j) if (more) PP_PIECE(nxt, k1, j)
+// DV = where the 8 pieces go: 0: L_0/L_1 (4+4)   1: MFMA shadows of M_0/M_1/M_2 (3+3+2)   2: L_0/L_1/L_2 (3+3+2)
+#define PP_DMA_L(v, j) if (DV == (v)) PP_DMA(j)
+#define PP_DMA_M(j) if (DV == 1) PP_DMA(j)
+// end of a load segment: retire this wave's ds_reads (and, with VM, its LDS-DMA), then the segment barrier
+#define PP_L_END(waitimm, ph)                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_waitcnt(waitimm);                                                                  \
+  PP_STAMP((ph) * 4 + 1);                                                                               \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  PP_STAMP((ph) * 4 + 2);                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  if (PRIO) __builtin_amdgcn_s_setprio(1)
+#define PP_M_END(ph)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  if (PRIO) __builtin_amdgcn_s_setprio(0);                                                              \
+  PP_STAMP((ph) * 4 + 3);                                                                               \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  __builtin_amdgcn_sched_barrier(0)
+  constexpr int WAIT_LGKM = 0xc07f, WAIT_ALL = 0x0070;   // lgkmcnt(0) | vmcnt(0) lgkmcnt(0)
+
+  const int nkt = g.K / HBK;
+  // TRACE: block 0 stamps s_memtime (shader cycles) at the 4 segment edges of each phase -> 16 per (K-tile, wave),
+  // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
+  const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
+#define PP_STAMP(slot) if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + (slot)] = __builtin_readcyclecounter(); }
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
+  __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+  __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nkt;
+    const int k1 = (kt + 1) * HBK;
+    // phase 0: chunk 0, A rows 0..63
+    if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + 16] = __builtin_amdgcn_s_memrealtime(); }
+    PP_STAMP(0);
+    PP_LOAD_W(cur, so0);
+    PP_LOAD_A(cur, so0, 0);
+    PP_DMA_L(0, 0); PP_DMA_L(0, 1); PP_DMA_L(0, 2); PP_DMA_L(0, 3);
+    PP_DMA_L(2, 0); PP_DMA_L(2, 1); PP_DMA_L(2, 2);
+    PP_L_END(WAIT_LGKM, 0);
+    PP_MMA(0, PP_DMA_M(0), PP_DMA_M(1), PP_DMA_M(2));
+    PP_M_END(0);
+    // phase 1: chunk 0, A rows 64..127
+    PP_STAMP(4);
+    PP_LOAD_A(cur, so0, 2);
+    PP_DMA_L(0, 4); PP_DMA_L(0, 5); PP_DMA_L(0, 6); PP_DMA_L(0, 7);
+    PP_DMA_L(2, 3); PP_DMA_L(2, 4); PP_DMA_L(2, 5);
+    PP_L_END(WAIT_LGKM, 1);
+    PP_MMA(2, PP_DMA_M(3), PP_DMA_M(4), PP_DMA_M(5));
+    PP_M_END(1);
+    // phase 2: chunk 1, A rows 0..63
+    PP_STAMP(8);
+    PP_LOAD_W(cur, so1);
+    PP_LOAD_A(cur, so1, 0);
+    PP_DMA_L(2, 6); PP_DMA_L(2, 7);
+    PP_L_END(WAIT_LGKM, 2);
+    PP_MMA(0, PP_DMA_M(6), PP_DMA_M(7), (void)0);
+    PP_M_END(2);
+    // phase 3: chunk 1, A rows 64..127; tile kt+1 must have landed before anyone's next L_0
+    PP_STAMP(12);
+    PP_LOAD_A(cur, so1, 2);
+    PP_L_END(WAIT_ALL, 3);
+    PP_MMA(2, (void)0, (void)0, (void)0);
+    PP_M_END(3);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();         // group 0 catches the extra barrier of group 1
+  __builtin_amdgcn_sched_barrier(0);
+#undef PP_PIECE
+#undef PP_LOAD_W
+#undef PP_LOAD_A
+#undef PP_MFMA
+#undef PP_MMA
+#undef PP_DMA
+#undef PP_DMA_L
+#undef PP_DMA_M
+#undef PP_L_END
+#undef PP_M_END
+#undef PP_STAMP
+
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn);
 }
 
 template <int BM, int BN>
@@ -613,7 +803,26 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
   static const int ilv = [] { const char* e = getenv("RPR_GEMM_ILV"); return e ? atoi(e) : 1; }();
-  static const int pipe = [] { const char* e = getenv("RPR_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+  static const int pipe = [] { const char* e = getenv("RPR_GEMM_PIPE"); return e ? atoi(e) : 2; }();  // 2 = ping-pong
+  if (pipe == 2) {
+    if (full && a.trace)
+      hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    else if (full) {
+      static const int var = [] { const char* e = getenv("RPR_GEMM_PP_VAR"); return e ? atoi(e) : 0; }();
+      const dim3 gr(tiles_m * tiles_n), bl(512);
+      switch (var) {
+        case 3: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 0, true>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
+        case 2: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 2, true>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
+        case 10: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 0, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
+        case 11: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 1, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
+        case 12: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 2, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
+        default: hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
+      }
+    }
+    else
+      hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (pipe) {
     if (full)
       hipLaunchKernelGGL((gemm_h2_pipe_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
