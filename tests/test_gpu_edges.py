@@ -122,3 +122,39 @@ def test_scaleup_output_hidden_and_1024_codebook(setup):
     torch.cuda.synchronize()
     assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(5, 6, L + 1)[:, :, 1:])
     np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(5, 6), atol=1e-4, rtol=0)
+
+
+def test_skewed_trie_with_duplicate_smtids(setup):
+    """SURVEY §8d skewed variant: squared-uniform codes on the first three levels (RQ code imbalance) over a
+    short code (L=4, few distinct tokens on the last level), so prefixes are shared by many docs, several docs
+    collide on the full smtid (range sizes > 1) and some nodes have fewer than B children."""
+    from oracle import beam_ref, t5_ref
+    E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
+    L, V, N, B, Q = 4, 256, 3000, 8, 6
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512)
+    sd = synth.make_state_dict(dims, seed=53)
+    codes = synth.make_codes(N, L, V, seed=53, skew=True)
+    codes[:, 0] //= 16; codes[:, 1] %= 6; codes[:, 2] %= 6; codes[:, 3] %= 3  # narrow levels -> many docs per smtid
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    d2s = synth.codes_to_docid_to_smtid(codes)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), V)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=54, max_len=10)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    torch.cuda.synchronize()
+    tok = res.tokens.cpu().numpy()
+    assert np.array_equal(tok, seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:])
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
+    # every returned range is exactly the set of docs carrying that smtid, in docid order (evaluate.py:439-446)
+    s2d = beam_ref.build_smtid_to_docids(d2s, L)
+    perm = trie.perm
+    lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
+    sizes = []
+    for q in range(Q):
+        for b in range(B):
+            key = "_".join(str(int(x)) for x in tok[q, b])
+            docs = [str(int(d)) for d in perm[lo[q, b]:hi[q, b]]]
+            assert docs == s2d[key]
+            sizes.append(len(docs))
+    assert max(sizes) > 1, "the skewed fixture is meant to contain smtids shared by several docs"
