@@ -333,16 +333,25 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   if (kv_layout == 0)      { kv_q = (size_t)B * inner;     kv_h = DKV;                 kv_pos = (size_t)R * inner; kv_slot = inner; }
   else if (kv_layout == 1) { kv_q = (size_t)L * B * inner; kv_h = DKV;                 kv_pos = (size_t)B * inner; kv_slot = inner; }
   else                     { kv_q = (size_t)L * B * inner; kv_h = (size_t)L * B * DKV; kv_pos = (size_t)B * DKV;   kv_slot = DKV; }
+  // Step 0: every beam of a query starts from the same start embedding and the same encoder states, so the
+  // decoder pass is computed once per query (Q rows, "one beam") and select reads the shared logits row; the
+  // position-0 K/V exist in slot 0 only and every beam's ancestry points there. (The reference recomputes
+  // the B identical rows; beams 1..B-1 differ only by their -1e9 initial score, generation.py:418-420.)
+  // Off when debug taps are requested (they expect [Q*B, V] logits per step) or RPR_STEP0_SHARED=0.
+  static const bool step0_env = [] { const char* e = getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
+  const bool shared0 = step0_env && !taps && B > 1;
+  int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
   auto norm = [&](const float* wgt, float post = 1.0f) {
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] {
-      return launch_rmsnorm(x, wgt, h2 ? nullptr : h, R, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Rt * dm * 4, [&] {
+      return launch_rmsnorm(x, wgt, h2 ? nullptr : h, Rt, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
     });
   };
   const LinIn in_h{h, h_h, ps_d, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff};
   for (int t = 0; t < L; ++t) {
     BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
-    Ln.run(RPR_K_OTHER, 0, 2.0 * R * dm * 4, [&] {
-      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, R, dm, V, t, s);
+    Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
+    Ln.run(RPR_K_OTHER, 0, 2.0 * Rt * dm * 4, [&] {
+      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s);
     });
     for (int i = 0; i < nd; ++i) {
       float* kc = P<float>(w.kcache) + i * layer_stride;
@@ -352,31 +361,31 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
         LinOut o{};
         o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
         o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
-        o.rm_B = B; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
-        linear(Ln, in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, o);
+        o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
+        linear(Ln, in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o);
       }
       {
-        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, B, H, t,
+        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
                           h2 ? attn_h : nullptr, ps_i};
-        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * R * H * (double)(t + 1) * DKV,
-               4.0 * ((double)R * inner * 2 + 2.0 * R * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
+        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Rt * H * (double)(t + 1) * DKV,
+               4.0 * ((double)Rt * inner * 2 + 2.0 * Rt * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
       }
-      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, R, out_f32(x, dm, dm, x));
+      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, out_f32(x, dm, dm, x));
       norm(m->dec_ln1[i]);
-      linear(Ln, in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, R, out_f32(qb, inner, inner));
+      linear(Ln, in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, Rt, out_f32(qb, inner, inner));
       {
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
-        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, B, H, Lq, h2 ? attn_h : nullptr, ps_i,
+        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
                            P<int32_t>(w.last)};
-        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * R * H * (double)Lq * DKV,
-               4.0 * ((double)R * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
+        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Rt * H * (double)Lq * DKV,
+               4.0 * ((double)Rt * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
       }
-      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, out_f32(x, dm, dm, x));
+      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, out_f32(x, dm, dm, x));
       norm(m->dec_ln2[i]);
       LinOut o = out_f32(ff, dff, dff, nullptr, 1);
       if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
-      linear(Ln, in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, R, o);
-      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, R, out_f32(x, dm, dm, x));
+      linear(Ln, in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o);
+      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, out_f32(x, dm, dm, x));
     }
     norm(d.dec_final_ln, d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f);
     // logits of position t only (the reference computes every position and keeps [-1])
@@ -389,17 +398,18 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
         g.A = h_h; g.a_ps = ps_d; g.lda = dm;
         g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
         g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
-        g.M = R; g.N = V; g.K = dm;
-        Ln.run(RPR_K_GEMM, 2.0 * R * (double)V * dm, 4.0 * ((double)R * dm + (double)V * dm + (double)R * V),
+        g.M = Rt; g.N = V; g.K = dm;
+        Ln.run(RPR_K_GEMM, 2.0 * Rt * (double)V * dm, 4.0 * ((double)Rt * dm + (double)V * dm + (double)Rt * V),
                [&] { return launch_gemm_h2(g, s); });
       } else {
-        linear(Ln, in_h, wt, R, out_f32(lg, V, V));
+        linear(Ln, in_h, wt, Rt, out_f32(lg, V, V));
       }
     }
     SelectArgs sa{};
     sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
     sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
     sa.log_softmax = (flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
+    sa.shared0 = (Bt != B) ? 1 : 0;
     if (taps) {
       sa.tap_scores = taps->step_scores ? taps->step_scores + (size_t)t * R : nullptr;
       sa.tap_tokens = taps->step_tokens ? taps->step_tokens + (size_t)t * R : nullptr;

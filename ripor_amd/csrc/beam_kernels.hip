@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   __syncthreads();
 
   // ---- phase A: child mask of every beam (64 consecutive tokens of one beam per wave) ----
-  const float* lg_q = a.logits + (size_t)r0 * V;
+  const float* lg_q = a.logits + (a.shared0 ? (size_t)q * V : (size_t)r0 * V);   // shared0: one row per query
   int* lb_q = a.lb_scratch + (size_t)r0 * V;
   for (int item = tid; item < items; item += 256) {
     const int b = item / V, c = item - b * V;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
   if (a.log_softmax) {  // fp32 log_softmax over V (generation.py:453-455): (x - max) - log(sum exp(x - max))
     for (int b = wave; b < B; b += 4) {
-      const float* row = lg_q + (size_t)b * V;
+      const float* row = a.shared0 ? lg_q : lg_q + (size_t)b * V;
       float mx = -INFINITY;
       for (int c = lane; c < V; c += 64) mx = fmaxf(mx, row[c]);
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 
   auto cand_score = [&](int item) -> double {
     const int b = item / V;
-    float lg = lg_q[item];
+    float lg = lg_q[a.shared0 ? item - b * V : item];
     if (a.log_softmax) lg = (lg - lmax[b]) - lsum[b];
     const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
     return ((double)lg + (ok ? 0.0 : -1e9)) + bscore[b];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     a.nxt.lo[r] = nlo;
     a.nxt.hi[r] = nhi;
     a.nxt.tokens[(size_t)r * ld + t] = (uint16_t)c;
-    a.nxt.anc[(size_t)r * ld + t] = (uint16_t)b;
+    a.nxt.anc[(size_t)r * ld + t] = (uint16_t)(a.shared0 ? 0 : b);   // slot holding this position's K/V
     if (a.tap_scores) a.tap_scores[r] = wscore[j];
     if (a.tap_tokens) a.tap_tokens[r] = c;
     if (a.tap_parent) a.tap_parent[r] = b;
