@@ -89,7 +89,7 @@ struct GraphKey {
 
 struct Workspace {
   // encoder
-  DevBuf ids, mask, last, ex, eh, eqkv, eattn, eff, enc_out, xkv;
+  DevBuf ids, mask, last, offs, row_src, ex, eh, eqkv, eattn, eff, enc_out, xkv;
   // decoder
   DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
   // beam state (2 ping-pong buffers)
@@ -106,6 +106,7 @@ struct rpr_ctx {
   unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
   Workspace ws;
   size_t ws_bytes = 0;
+  int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)
   hipStream_t cap_stream = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
   // profiling
@@ -181,9 +182,11 @@ LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu =
   return o;
 }
 
-void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) {
-  const double fl = 2.0 * M * (double)W.N * W.K;
-  const double by = 4.0 * ((double)M * W.K + (double)W.N * W.K + (double)M * W.N * (O.resid ? 2 : 1));
+// m_dev (nullable): device-side live row count (packed encoder); m_acc = rows to account flops/bytes for
+void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, const int* m_dev = nullptr, int m_acc = -1) {
+  const double Ma = m_acc >= 0 ? m_acc : M;
+  const double fl = 2.0 * Ma * (double)W.N * W.K;
+  const double by = 4.0 * (Ma * W.K + (double)W.N * W.K + Ma * W.N * (O.resid ? 2 : 1));
   hipStream_t s = L.s;
   if (L.c->precision == RPR_PREC_F16X2) {
     GemmH2Args g{};
@@ -194,6 +197,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) 
     g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
     g.trace = L.c->trace_buf;
     g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
+    g.m_dev = m_dev;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
   } else {
     GemmArgs g{};
@@ -201,6 +205,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O) 
     for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
     g.split_n = O.split_n; g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
     g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
+    g.m_dev = m_dev;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
   }
 }
@@ -225,7 +230,7 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   Workspace& w = c->ws;
   int e = 0;
   auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = ensure(c, b, bytes); };
-  E(w.ids, T * 4); E(w.mask, T * 4); E(w.last, (size_t)Q * 4);
+  E(w.ids, T * 4); E(w.mask, T * 4); E(w.last, (size_t)Q * 4); E(w.offs, ((size_t)Q + 1) * 4); E(w.row_src, T * 4);
   E(w.ex, T * dm * f); E(w.eh, T * dm * f); E(w.eqkv, T * 3 * inner * f); E(w.eattn, T * inner * f);
   E(w.eff, T * dff * f); E(w.enc_out, T * dm * f); E(w.xkv, T * nd * 2 * inner * f);
   E(w.x, R * dm * f); E(w.h, R * dm * f); E(w.q, R * inner * f); E(w.attn, R * inner * f);
@@ -244,7 +249,12 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
 }
 
 // Encoder forward into ws.enc_out (reference generation.py:132-137 -> model.encoder(...)).
-void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq) {
+// packed = false: rows are [Q, Lq] padded (taps / rpr_encode return that layout).
+// packed = true (the search path): only the positions before each query's last attended token exist, as rows
+//   offs[q] .. offs[q] + last[q] - 1 (ws.offs / ws.last / ws.row_src, launch_pack_rows). The row count is only
+//   known on the device, so every launch keeps its padded grid (hipGraph-safe) and tiles / rows past offs[Q] exit.
+//   Padded positions are exp(-inf) keys and unused query rows in the padded layout, so results are identical.
+void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq, bool packed) {
   const auto& d = m->d;
   Workspace& w = c->ws;
   const int T = Q * Lq, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
@@ -255,33 +265,45 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   __half *h_h = P<__half>(w.eh_h), *attn_h = P<__half>(w.eattn_h), *ff_h = P<__half>(w.eff_h);
   const size_t ps_d = (size_t)T * dm, ps_i = (size_t)T * inner, ps_f = (size_t)T * dff;
   const float eps = d.layer_norm_eps;
+  const int32_t* offs = packed ? P<int32_t>(w.offs) : nullptr;
+  const int* live = packed ? P<int>(w.offs) + Q : nullptr;   // device-side number of live rows
+  int Ta = T;                                                  // rows accounted in the profile (flops / bytes)
+  if (packed) {
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_pack_rows(P<int32_t>(w.last), P<int32_t>(w.offs), P<int32_t>(w.row_src), Q, Lq, s); });
+    if (c->profiling && !Ln.err) {   // eager diagnostic pass: read the live row count back so the accounting is exact
+      int n = T;
+      if (hipMemcpyAsync(&n, live, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) Ta = n;
+    }
+  }
   auto norm = [&](const float* wgt, float* of, __half* oh) {
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] {
-      return launch_rmsnorm(x, wgt, h2 ? nullptr : of, T, dm, eps, s, 1.0f, h2 ? oh : nullptr, ps_d);
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
+      return launch_rmsnorm(x, wgt, h2 ? nullptr : of, T, dm, eps, s, 1.0f, h2 ? oh : nullptr, ps_d, live);
     });
   };
-  Ln.run(RPR_K_OTHER, 0, 2.0 * T * dm * 4, [&] {
-    return launch_embed_rows(d.shared, P<int32_t>(w.ids), x, T, dm, d.vocab_size, s);
+  Ln.run(RPR_K_OTHER, 0, 2.0 * Ta * dm * 4, [&] {
+    return launch_embed_rows(d.shared, P<int32_t>(w.ids), x, T, dm, d.vocab_size, s,
+                             packed ? P<int32_t>(w.row_src) : nullptr, live);
   });
   for (int i = 0; i < d.num_layers; ++i) {
     norm(m->enc_ln0[i], h, h_h);
-    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_qkv[i], m->h_enc_qkv[i], 3 * inner, dm}, T, out_f32(qkv, 3 * inner, 3 * inner));
+    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_qkv[i], m->h_enc_qkv[i], 3 * inner, dm}, T, out_f32(qkv, 3 * inner, 3 * inner), live, Ta);
     EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets,
-                  h2 ? attn_h : nullptr, ps_i};
-    Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV, 4.0 * T * 4 * inner,
+                  h2 ? attn_h : nullptr, ps_i, offs, P<int32_t>(w.last)};
+    Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV * ((double)Ta / T) * ((double)Ta / T), 4.0 * Ta * 4 * inner,
            [&] { return launch_enc_attn(a, s); });
-    linear(Ln, {attn, attn_h, ps_i, inner}, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, out_f32(x, dm, dm, x));
+    linear(Ln, {attn, attn_h, ps_i, inner}, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, out_f32(x, dm, dm, x), live, Ta);
     norm(m->enc_ln1[i], h, h_h);
     LinOut o = out_f32(ff, dff, dff, nullptr, 1);
     if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
-    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o);
-    linear(Ln, {ff, ff_h, ps_f, dff}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x));
+    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o, live, Ta);
+    linear(Ln, {ff, ff_h, ps_f, dff}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x), live, Ta);
   }
   // final norm: fp32 copy always (taps / rpr_encode), planes for the cross-K/V GEMM in split mode
-  Ln.run(RPR_K_RMSNORM, 0, 2.0 * T * dm * 4, [&] {
+  Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
     return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, eps, s, 1.0f,
-                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d);
+                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live);
   });
+  c->enc_rows_accounted = Ta;
 }
 
 BeamState beam_state(Workspace& w, int i, int L) {
@@ -301,7 +323,11 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   const bool h2 = c->precision == RPR_PREC_F16X2;
   const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
-  enqueue_encoder(Ln, c, m, Q, Lq);
+  // index of the last attended key + 1 per query: row packing of the encoder and the cross-attention loop bound
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s); });
+  static const bool packed_env = [] { const char* e = getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
+  const bool packed = packed_env && !taps;   // taps return the padded [Q, Lq, d] encoder output
+  enqueue_encoder(Ln, c, m, Q, Lq, packed);
   if (taps && taps->encoder_out && !Ln.err) {
     hipError_t e = hipMemcpyAsync(taps->encoder_out, w.enc_out.p, (size_t)T * dm * 4, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) { Ln.err = hip_fail(e, "tap copy", __FILE__, __LINE__); return; }
@@ -310,11 +336,10 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // the reference recomputes them for every beam at every step)
   const int xld = nd * 2 * inner;
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
-         out_f32(P<float>(w.xkv), xld, xld));
+         out_f32(P<float>(w.xkv), xld, xld), packed ? P<int>(w.offs) + Q : nullptr, c->enc_rows_accounted);
 
   BeamState st0 = beam_state(w, 0, L);
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(st0, Q, B, tr->N, s); });
-  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s); });
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
         *logits = P<float>(w.logits);
@@ -376,7 +401,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       {
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
         DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
-                           P<int32_t>(w.last)};
+                           P<int32_t>(w.last), packed ? P<int32_t>(w.offs) : nullptr};
         Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Rt * H * (double)Lq * DKV,
                4.0 * ((double)Rt * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
       }
@@ -707,7 +732,7 @@ int rpr_encode(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t
   RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
   RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
   Launcher Ln{c, s};
-  enqueue_encoder(Ln, c, m, Q, Lq);
+  enqueue_encoder(Ln, c, m, Q, Lq, false);
   if (Ln.err) return Ln.err;
   RPR_HIP(hipMemcpyAsync(out, w.enc_out.p, T * m->d.d_model * 4, hipMemcpyDeviceToDevice, s));
   return RPR_OK;

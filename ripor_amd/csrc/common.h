@@ -50,6 +50,7 @@ struct GemmArgs {
   // KV-cache element map for the outputs 1 and 2 (rm_B == 0: plain [M, ldo] rows): element (m, n) goes to
   // out[i] + (m / rm_B) * rm_stride + (m % rm_B) * rm_slot + (n / 64) * rm_head + n % 64   
   int rm_B; size_t rm_stride, rm_slot, rm_head;
+  const int* m_dev;             // nullable: number of live rows on the device (packed encoder); tiles past it exit
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -64,6 +65,7 @@ struct GemmH2Args {
   int relu;
   unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
   int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
+  const int* m_dev;                        // nullable: live row count on the device (see GemmArgs)
 };
 
 // offset (in floats) of output element (m, on) in output block oi; on..on+3 stay inside one head
@@ -81,12 +83,17 @@ hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t pla
 // ---- T5 elementwise / attention kernels -----------------------------------------------------------
 // post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5
 // out (fp32) and/or out_h (two f16 planes, stride o_ps) are written; either may be null
+// rows_dev (nullable): live row count on the device; rows past it are skipped (packed encoder)
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale = 1.0f, __half* out_h = nullptr, size_t o_ps = 0);
+                          float post_scale = 1.0f, __half* out_h = nullptr, size_t o_ps = 0,
+                          const int* rows_dev = nullptr);
 hipError_t init_t5_kernel_attributes();
 hipError_t init_beam_kernel_attributes();
+// row_src (nullable): out row p takes ids[row_src[p]] for p < *rows_dev (packed encoder)
 hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
-                             hipStream_t s);
+                             hipStream_t s, const int32_t* row_src = nullptr, const int* rows_dev = nullptr);
+// Packed encoder rows: offs[q] = sum of lens[<q] (offs[Q] = live rows), row_src[offs[q] + j] = q * Lq + j
+hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src, int Q, int Lq, hipStream_t s);
 // x[r] = t==0 ? start : in_embeds[t-1][tokens[r][t-1]]
 hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
                             float* out, int R, int d, int V, int t, hipStream_t s);
@@ -99,6 +106,8 @@ struct EncAttnArgs {
   float* out;              // [Q*Lq, inner]
   int Q, Lq, H, buckets;
   __half* out_h; size_t o_ps;   // when non-null: write f16 planes instead of fp32
+  const int32_t* offs;     // nullable (packed encoder): rows of query q are offs[q] .. offs[q] + lens[q] - 1
+  const int32_t* lens;     //   instead of q*Lq .. q*Lq + Lq - 1
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
 
@@ -127,6 +136,7 @@ struct DecCrossAttnArgs {
   int Q, B, H, Lq;
   __half* out_h; size_t o_ps;
   const int32_t* last;     // [Q] index of the last attended key + 1 (launch_mask_lengths)
+  const int32_t* offs;     // nullable (packed encoder): K/V row (q, j) is row offs[q] + j instead of q*Lq + j
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 

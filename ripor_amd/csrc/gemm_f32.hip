@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
 
   // XCD-aware tile order: blocks b, b+8, b+16, ... run on the same XCD (same L2); give each XCD a
   // contiguous chunk of the (m-major, n-minor) tile list so neighbours share A row-panels in L2.
-  const int nt = tiles_m * tiles_n;
+  int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
+    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    if (bid >= nt) return;
+  }
   {
     const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;

@@ -41,8 +41,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles
   constexpr int ROWS = 2 * (BM + BN);
   __shared__ __attribute__((aligned(16))) __half smem[ROWS * LDH];
 
-  const int nt = tiles_m * tiles_n;
+  int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
+    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    if (bid >= nt) return;
+  }
   {
     const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
@@ -207,8 +211,12 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
 
-  const int nt = tiles_m * tiles_n;
+  int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
+    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    if (bid >= nt) return;
+  }
   {
     const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
@@ -480,8 +488,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kern
   constexpr int ROWS = 2 * (BM + BN), NINST = ROWS / 16, PER_WAVE = NINST / LW;  // DMA pieces per loader wave per K-tile
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
 
-  const int nt = tiles_m * tiles_n;
+  int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
+    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    if (bid >= nt) return;
+  }
   {
     const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
@@ -614,8 +626,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
 
-  const int nt = tiles_m * tiles_n;
+  int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
+    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    if (bid >= nt) return;
+  }
   {
     const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;

@@ -41,9 +41,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 // one wave per row; d % 4 == 0
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ out, int rows, int d, float eps,
-                                                       float post_scale, __half* __restrict__ out_h, size_t o_ps) {
+                                                       float post_scale, __half* __restrict__ out_h, size_t o_ps,
+                                                       const int* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  if (row >= rows || (rows_dev && row >= *rows_dev)) return;
   const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
   const float4* wr = reinterpret_cast<const float4*>(w);
   float4* orow = reinterpret_cast<float4*>(out + (size_t)row * d);  // only dereferenced when out != nullptr
@@ -65,18 +66,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 }
 
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale, __half* out_h, size_t o_ps) {
+                          float post_scale, __half* out_h, size_t o_ps, const int* rows_dev) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale, out_h, o_ps);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale, out_h, o_ps,
+                     rows_dev);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ embeddings
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
-                                                          float* __restrict__ out, int rows, int d, int vocab) {
+                                                          float* __restrict__ out, int rows, int d, int vocab,
+                                                          const int32_t* __restrict__ row_src,
+                                                          const int* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  int id = ids[row];
+  if (row >= rows || (rows_dev && row >= *rows_dev)) return;
+  int id = ids[row_src ? row_src[row] : row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * d);
   float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
@@ -84,9 +88,51 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 }
 
 hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
-                             hipStream_t s) {
+                             hipStream_t s, const int32_t* row_src, const int* rows_dev) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, out, rows, d, vocab);
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, out, rows, d, vocab, row_src,
+                     rows_dev);
+  return hipGetLastError();
+}
+
+// Packed encoder: exclusive scan of the per-query lengths (one block; Q is at most a few thousand per call,
+// the chunk loop covers any Q) and the packed-row -> (q, j) source index.
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ offs, int Q) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < Q; q0 += 1024) {
+    const int q = q0 + tid;
+    const int v = q < Q ? lens[q] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan
+      const int add = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    if (q < Q) offs[q] = carry + part[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) offs[Q] = carry;
+}
+
+__global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restrict__ lens, const int32_t* __restrict__ offs,
+                                                         int32_t* __restrict__ row_src, int Q, int Lq) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const int n = lens[q], o = offs[q];
+  for (int j = lane; j < n; j += 64) row_src[o + j] = q * Lq + j;
+}
+
+hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src, int Q, int Lq, hipStream_t s) {
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, s, lens, offs, Q);
+  hipLaunchKernelGGL(pack_fill_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, lens, offs, row_src, Q, Lq);
   return hipGetLastError();
 }
 
@@ -127,8 +173,12 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq] normalised weights per wave
   float* Bs = Ps + 4 * Lq;             // [buckets<=64] bias of this head
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* base = a.qkv + (size_t)qi * Lq * ld + h * DKV;
-  for (int i = tid; i < Lq * 16; i += 256) {
+  // packed encoder: the query's rows start at offs[qi] and only its own lens[qi] positions exist (the padded
+  // positions behind them are masked keys and unused query rows in the padded layout)
+  const int nrow = a.offs ? a.lens[qi] : Lq;
+  const size_t row0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * Lq;
+  const float* base = a.qkv + row0 * ld + h * DKV;
+  for (int i = tid; i < nrow * 16; i += 256) {
     const int j = i >> 4, c = (i & 15) * 4;
     const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + inner + c);
     const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * inner + c);
@@ -139,9 +189,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   if (tid < a.buckets) Bs[tid] = a.rel_bias[tid * H + h];
   __syncthreads();
   const int32_t* mrow = a.mask + (size_t)qi * Lq;
-  const int nchunk = (Lq + 63) >> 6;
+  const int nchunk = (nrow + 63) >> 6;
   float* P = Ps + wave * Lq;
-  for (int i = wave; i < Lq; i += 4) {
+  for (int i = wave; i < nrow; i += 4) {
     const float qv = base[(size_t)i * ld + lane];  // lane d holds q_i[d]
     float sc[MAX_LQ / 64];
     float mx = -INFINITY;
@@ -149,7 +199,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     for (int c = 0; c < MAX_LQ / 64; ++c) {
       if (c >= nchunk) break;
       const int j = c * 64 + lane;
-      const int jc = j < Lq ? j : Lq - 1;
+      const int jc = j < nrow ? j : nrow - 1;
       const float* kr = Ks + jc * 65;
       float acc = 0.f;
 #pragma unroll
@@ -158,7 +208,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
         acc = fmaf(qd, kr[d], acc);
       }
       float s = -INFINITY;
-      if (j < Lq && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
+      if (j < nrow && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
       sc[c] = s;
       mx = fmaxf(mx, s);
     }
@@ -176,12 +226,12 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     for (int c = 0; c < MAX_LQ / 64; ++c) {
       if (c >= nchunk) break;
       const int j = c * 64 + lane;
-      if (j < Lq) P[j] = sc[c] / sum;
+      if (j < nrow) P[j] = sc[c] / sum;
     }
     __builtin_amdgcn_wave_barrier();
     float o = 0.f;
-    for (int j = 0; j < Lq; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
-    const size_t oidx = ((size_t)qi * Lq + i) * inner + h * DKV + lane;
+    for (int j = 0; j < nrow; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
+    const size_t oidx = (row0 + i) * inner + h * DKV + lane;
     if (a.out_h) {
       __half hi, lo;
       split_f16(o, hi, lo);
@@ -445,8 +495,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   float* S = Qs + (size_t)B * QS_LD;       // [B][Lq+1]
   const int tid = threadIdx.x;
   const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
-  const float* kb = a.xk + (size_t)qi * a.Lq * a.xld + h * DKV;
-  const float* vb = a.xv + (size_t)qi * a.Lq * a.xld + h * DKV;
+  const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;   // packed or padded encoder rows
+  const float* kb = a.xk + xrow0 * a.xld + h * DKV;
+  const float* vb = a.xv + xrow0 * a.xld + h * DKV;
   // keys at and beyond the last attended position are padding: every loop runs over that prefix only
   // (queries are padded to the batch maximum, typically 2-3x their own length); a.last[q] is computed
   // once per search. All global loads of the block are issued back to back before the first wait.
