@@ -8,6 +8,7 @@ from ripor_amd.utils import synth
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 NCTX = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+GRAPH = (sys.argv[3] != 'eager') if len(sys.argv) > 3 else True
 B, L, V, N = 10, 32, 256, 1_000_000
 dims = synth.t5_base_dims(L=L, V=V)
 sd = synth.make_state_dict(dims, seed=1)
@@ -24,13 +25,13 @@ def run(n_ctx, iters):
     for _ in range(iters):
         for i in range(n_ctx):
             with torch.cuda.stream(streams[i]):
-                E.search(models[i], tries[i], ids, mask, B, L)
+                E.search(models[i], tries[i], ids, mask, B, L, use_graph=GRAPH)
     torch.cuda.synchronize()
     return n_ctx * iters * Q / (time.time() - t0)
 
 for i in range(NCTX):
     with torch.cuda.stream(streams[i]):
-        E.search(models[i], tries[i], ids, mask, B, L)
+        E.search(models[i], tries[i], ids, mask, B, L, use_graph=GRAPH)
 torch.cuda.synchronize()
 print(f"Q={Q} per batch")
 print(f"1 stream : {run(1, 3):8.1f} q/s")
