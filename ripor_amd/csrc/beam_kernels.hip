@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   int* red_i = widx + B;                                                 // [4]
   float* lmax = reinterpret_cast<float*>(red_i + 4);                     // [B]
   float* lsum = lmax + B;                                                // [B] log(sum exp)
+  float* slog = lsum + B;                                                // [B*V] logits of the query (a.lds_logits)
 
   const int r0 = q * B;
   for (int b = tid; b < B; b += 256) {
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       ok = (l < hi) && ((int)a.codes[(size_t)l * Lc + t] == c);
     }
     lb_q[item] = l;
+    // the arg-max rounds rescan a thread's candidates after every win: keep the logits in LDS when they fit
+    // (B = 100: 100 dependent L2 reads per rescan made the kernel 7 % of the step)
+    if (a.lds_logits) slog[item] = lg_q[a.shared0 ? c : item];
     const unsigned long long m = __ballot(ok);
     if (lane == 0) valid[item >> 6] = m;
   }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 
   auto cand_score = [&](int item) -> double {
     const int b = item / V;
-    float lg = lg_q[a.shared0 ? item - b * V : item];
+    float lg = a.lds_logits ? slog[item] : lg_q[a.shared0 ? item - b * V : item];
     if (a.log_softmax) lg = (lg - lmax[b]) - lsum[b];
     const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
     return ((double)lg + (ok ? 0.0 : -1e9)) + bscore[b];
@@ -153,11 +157,25 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       Cand c; c.s = red_s[w]; c.item = red_i[w];
       if (better(c, win)) win = c;
     }
-    const bool owner = (win.item != 0x7fffffff) && ((win.item & 255) == tid);
+    const bool any = win.item != 0x7fffffff;
+    const int owner_tid = win.item & 255;
+    const bool owner = any && owner_tid == tid;
     if (tid == 0) { wscore[j] = win.s; widx[j] = win.item; }
     if (owner) taken[win.item >> 6] |= 1ull << (win.item & 63);  // single writer per round (one winner), fenced by the barriers
     __syncthreads();
-    if (owner) mine = scan_best();
+    // only the winner's thread has a stale local best: its whole wave rescans that thread's candidates
+    // (items owner_tid + 256 k) together — a single thread walking its B*V/256 items made every round cost
+    // ~100 dependent LDS round trips at B = 100
+    if (any && wave == (owner_tid >> 6)) {
+      Cand best; best.s = -INFINITY; best.item = 0x7fffffff;
+      for (int item = owner_tid + 256 * lane; item < items; item += 256 * 64) {
+        if ((taken[item >> 6] >> (item & 63)) & 1ull) continue;
+        Cand c; c.s = cand_score(item); c.item = item;
+        if (better(c, best)) best = c;
+      }
+      best = wave_best(best);
+      if (owner) mine = best;
+    }
   }
   __syncthreads();
 
@@ -201,10 +219,14 @@ hipError_t init_beam_kernel_attributes() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
+hipError_t launch_select(const SelectArgs& a_in, hipStream_t s) {
+  SelectArgs a = a_in;
   if (a.V % 64 != 0) return hipErrorInvalidValue;
-  const size_t smem = select_smem(a.B, a.V);
+  size_t smem = select_smem(a.B, a.V);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
+  const size_t with_logits = smem + (size_t)a.B * a.V * sizeof(float);
+  a.lds_logits = with_logits <= 160 * 1024 ? 1 : 0;
+  if (a.lds_logits) smem = with_logits;
   hipLaunchKernelGGL(select_kernel, dim3(a.Q), dim3(256), smem, s, a);
   return hipGetLastError();
 }

@@ -159,6 +159,7 @@ struct SelectArgs {
   int32_t* lb_scratch;       // [R, V] lower bounds found by the mask phase
   int Q, B, V, t;
   int log_softmax;
+  int lds_logits;            // set by the launcher: stage the query's B*V logits in LDS
   int shared0;               // step 0 computed once per query: logits is [Q, V], position-0 K/V live in slot 0
   // debug taps for step t (nullable)
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
