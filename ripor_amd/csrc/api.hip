@@ -69,6 +69,11 @@ struct rpr_model {
   __half* h_out_embeds = nullptr;  // [2][L*V][d]
   std::vector<void*> owned;
   int inner() const { return d.num_heads * d.d_kv; }
+  ~rpr_model() {   // device memory goes with the object, also on the error paths of rpr_load_model
+    if (enc_bucket) (void)hipFree(enc_bucket);
+    if (dec_bucket) (void)hipFree(dec_bucket);
+    for (void* p : owned) (void)hipFree(p);
+  }
 };
 
 struct rpr_trie {
@@ -78,6 +83,7 @@ struct rpr_trie {
   uint16_t* codes = nullptr;  // [dev] sorted [N, L]
   std::vector<int64_t> perm;
   std::vector<uint16_t> host_sorted;
+  ~rpr_trie() { if (codes) (void)hipFree(codes); }
 };
 
 struct GraphKey {
@@ -137,6 +143,14 @@ int ensure(rpr_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 template <class T> T* P(const DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+// scoped temporary device buffer (test hooks): freed on every return path
+struct DevTmp {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
 
 // Launch wrapper: optional hipEvent timing per kernel class (bench.py roofline leg).
 struct Launcher {
@@ -576,7 +590,7 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
     mk(d->dec_xkv, (size_t)nd * 2 * inner * dm, &m->h_dec_xkv);
     mk(d->out_embeds, (size_t)d->L * d->V * dm, &m->h_out_embeds);
     if (!err) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) err = hip_fail(e, "sync", __FILE__, __LINE__); }
-    if (err) { for (void* p : m->owned) (void)hipFree(p); return err; }
+    if (err) return err;
   }
   *out = m.release();
   return RPR_OK;
@@ -590,9 +604,6 @@ void rpr_free_model(rpr_model* m) {
   for (auto it = m->ctx->graphs.begin(); it != m->ctx->graphs.end();) {
     if (it->first.m == m) { (void)hipGraphExecDestroy(it->second); it = m->ctx->graphs.erase(it); } else ++it;
   }
-  if (m->enc_bucket) (void)hipFree(m->enc_bucket);
-  if (m->dec_bucket) (void)hipFree(m->dec_bucket);
-  for (void* p : m->owned) (void)hipFree(p);
   delete m;
 }
 
@@ -624,7 +635,6 @@ void rpr_free_trie(rpr_trie* t) {
   for (auto it = t->ctx->graphs.begin(); it != t->ctx->graphs.end();) {
     if (it->first.t == t) { (void)hipGraphExecDestroy(it->second); it = t->ctx->graphs.erase(it); } else ++it;
   }
-  if (t->codes) (void)hipFree(t->codes);
   delete t;
 }
 
@@ -658,14 +668,12 @@ int rpr_trie_mask(rpr_ctx* c, const rpr_trie* t, const int32_t* prefix, int32_t 
   RPR_REQUIRE(c && t && prefix && out_mask, "NULL argument");
   RPR_REQUIRE(R >= 1 && T >= 1, "R and T must be >= 1");
   RPR_HIP(hipSetDevice(c->device));
-  int32_t* dp = nullptr; uint8_t* dm = nullptr;
-  RPR_HIP(hipMalloc(&dp, (size_t)R * T * 4));
-  RPR_HIP(hipMalloc(&dm, (size_t)R * t->V));
-  RPR_HIP(hipMemcpy(dp, prefix, (size_t)R * T * 4, hipMemcpyHostToDevice));
-  RPR_HIP(launch_prefix_mask(t->codes, t->L, t->N, dp, R, T, t->V, dm, nullptr));
-  RPR_HIP(hipMemcpy(out_mask, dm, (size_t)R * t->V, hipMemcpyDeviceToHost));
-  RPR_HIP(hipFree(dp));
-  RPR_HIP(hipFree(dm));
+  DevTmp dp, dm;
+  RPR_HIP(dp.alloc((size_t)R * T * 4));
+  RPR_HIP(dm.alloc((size_t)R * t->V));
+  RPR_HIP(hipMemcpy(dp.p, prefix, (size_t)R * T * 4, hipMemcpyHostToDevice));
+  RPR_HIP(launch_prefix_mask(t->codes, t->L, t->N, dp.as<int32_t>(), R, T, t->V, dm.as<uint8_t>(), nullptr));
+  RPR_HIP(hipMemcpy(out_mask, dm.p, (size_t)R * t->V, hipMemcpyDeviceToHost));
   return RPR_OK;
 }
 
@@ -745,15 +753,15 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Launcher Ln{c, s};
-  __half *Ah = nullptr, *Wh = nullptr;
+  DevTmp At, Wt;
   if (c->precision == RPR_PREC_F16X2) {  // test hook: split the operands on the fly
-    RPR_HIP(hipMalloc(&Ah, (size_t)M * K * 2 * sizeof(__half)));
-    RPR_HIP(hipMalloc(&Wh, (size_t)N * K * 2 * sizeof(__half)));
-    RPR_HIP(launch_split_planes(A, Ah, (size_t)M * K, (size_t)M * K, s));
-    RPR_HIP(launch_split_planes(W, Wh, (size_t)N * K, (size_t)N * K, s));
+    RPR_HIP(At.alloc((size_t)M * K * 2 * sizeof(__half)));
+    RPR_HIP(Wt.alloc((size_t)N * K * 2 * sizeof(__half)));
+    RPR_HIP(launch_split_planes(A, At.as<__half>(), (size_t)M * K, (size_t)M * K, s));
+    RPR_HIP(launch_split_planes(W, Wt.as<__half>(), (size_t)N * K, (size_t)N * K, s));
   }
-  linear(Ln, {A, Ah, (size_t)M * K, K}, {W, Wh, N, K}, M, out_f32(C, N, N, residual, relu));
-  if (Ah) { RPR_HIP(hipStreamSynchronize(s)); RPR_HIP(hipFree(Ah)); RPR_HIP(hipFree(Wh)); }
+  linear(Ln, {A, At.as<__half>(), (size_t)M * K, K}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
+  if (At.p) RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
   if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x W stamps (6: pipe kernel, 18: ping-pong)
     const char* we = getenv("RPR_GEMM_TRACE_W");
     const size_t tw = we ? (size_t)atoi(we) : 6;
