@@ -365,6 +365,8 @@ CASES = {
     "g2_base_b10_l32": dict(kind="base", N=1000, Q=4, B=10, L=32, V=256, seed=201),
     # t5-large decoder shape (24 layers, 16 heads, d=1024 are forced by the reference ctor), B=100 top-k stress
     "g3_large_b100_l16": dict(kind="large", N=3000, Q=2, B=100, L=16, V=256, seed=301),
+    # BASELINE config 4 exactly: t5-large decoder, beam 100, len 32 (one query keeps the fixture small)
+    "g3_large_b100_l32": dict(kind="large", N=3000, Q=1, B=100, L=32, V=256, seed=302),
 }
 
 
