@@ -154,6 +154,19 @@ int rpr_trie_load(rpr_ctx* ctx, const char* path, rpr_trie** out_trie);
 int rpr_trie_mask(rpr_ctx* ctx, const rpr_trie* trie, const int32_t* prefix, int32_t R, int32_t T,
                   uint8_t* out_mask);
 
+/* ---- docid_to_smtid.json reader (host only, no ctx) ------------------------------------------------
+ * Replaces `ujson.load(docid_to_smtid_path)` + the list comprehension over 8.8 M Python lists in
+ * evaluate.py:400-402,439-446 and aq_preprocess/build_list_smtid_to_nextids.py:21-27: one streaming pass
+ * over {"docid": [-1, c1, ..., cL], ...} (format: aq_preprocess/create_customized_smtid_file.py:47-59)
+ * into a [N, L] uint16 code matrix in file order plus the docid strings. */
+typedef struct rpr_d2s rpr_d2s;
+int rpr_d2s_open(const char* path, rpr_d2s** out);
+/* N docs, L codes per doc (the leading -1 dropped), key_bytes = length of the '\n'-joined docid strings */
+int rpr_d2s_dims(const rpr_d2s* h, int64_t* N, int32_t* L, int64_t* key_bytes);
+/* codes: [host] [N, L] uint16; keys: [host] key_bytes chars ('\n'-separated, file order). Either may be NULL. */
+int rpr_d2s_copy(const rpr_d2s* h, uint16_t* codes, char* keys);
+void rpr_d2s_close(rpr_d2s* h);
+
 /* ---- the hot path (replaces generate_for_constrained_prefix_beam_search, generation.py:35-251,
  *      -> beam_search_for_constrained_prefix :253-575 incl. BeamSearchScorer.process/finalize) ----
  * input_ids, attention_mask: [dev] int32 [Q, Lq] (pad id 0 / mask 0 on padding, any Lq <= 256).

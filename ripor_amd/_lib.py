@@ -71,6 +71,10 @@ SIGNATURES = {
     "rpr_trie_perm": (C.POINTER(C.c_int64), [C.c_void_p]),
     "rpr_trie_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rpr_trie_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rpr_d2s_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rpr_d2s_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "rpr_d2s_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rpr_d2s_close": (None, [C.c_void_p]),
     "rpr_trie_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rpr_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

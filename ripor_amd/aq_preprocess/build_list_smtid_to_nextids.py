@@ -26,10 +26,13 @@ def main(argv=None):
         print(f"{out} exists")
         return
     from .. import engine as E
-    with open(args.docid_to_smtid_path) as fin:
-        docid_to_smtids = json.load(fin)
-    docids = list(docid_to_smtids.keys())
-    codes = np.asarray([docid_to_smtids[d][1:] for d in docids], dtype=np.int64)
+    try:
+        _, codes = E.read_docid_to_smtid(args.docid_to_smtid_path)   # streaming C++ reader
+    except E.RiporHipError as e:
+        print(f"rpr_d2s reader declined ({e}); falling back to json.load")
+        with open(args.docid_to_smtid_path) as fin:
+            docid_to_smtids = json.load(fin)
+        codes = np.asarray([v[1:] for v in docid_to_smtids.values()], dtype=np.int64)
     V = int(codes.max()) + 1
     for l in range(codes.shape[1]):
         print(f"{l}-th step has {len(np.unique(codes[:, :l + 1], axis=0)) if l < 3 else -1:,} effective smtid "

@@ -86,6 +86,13 @@ struct rpr_trie {
   ~rpr_trie() { if (codes) (void)hipFree(codes); }
 };
 
+struct rpr_d2s {
+  std::vector<uint16_t> codes;
+  std::string keys;
+  int64_t N = 0;
+  int L = 0;
+};
+
 struct GraphKey {
   const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags;
   bool operator<(const GraphKey& o) const {
@@ -663,6 +670,35 @@ int rpr_trie_load(rpr_ctx* c, const char* path, rpr_trie** out) {
   *out = t.release();
   return RPR_OK;
 }
+
+int rpr_d2s_open(const char* path, rpr_d2s** out) {
+  RPR_REQUIRE(path && out, "NULL argument");
+  auto h = std::make_unique<rpr_d2s>();
+  std::string err;
+  if (read_docid_to_smtid(path, h->codes, h->keys, h->N, h->L, err) != 0) {
+    set_error("docid_to_smtid: " + err);
+    return RPR_ERR_INVALID;
+  }
+  *out = h.release();
+  return RPR_OK;
+}
+
+int rpr_d2s_dims(const rpr_d2s* h, int64_t* N, int32_t* L, int64_t* key_bytes) {
+  RPR_REQUIRE(h, "NULL handle");
+  if (N) *N = h->N;
+  if (L) *L = h->L;
+  if (key_bytes) *key_bytes = (int64_t)h->keys.size();
+  return RPR_OK;
+}
+
+int rpr_d2s_copy(const rpr_d2s* h, uint16_t* codes, char* keys) {
+  RPR_REQUIRE(h, "NULL handle");
+  if (codes) std::memcpy(codes, h->codes.data(), h->codes.size() * sizeof(uint16_t));
+  if (keys) std::memcpy(keys, h->keys.data(), h->keys.size());
+  return RPR_OK;
+}
+
+void rpr_d2s_close(rpr_d2s* h) { delete h; }
 
 int rpr_trie_mask(rpr_ctx* c, const rpr_trie* t, const int32_t* prefix, int32_t R, int32_t T, uint8_t* out_mask) {
   RPR_REQUIRE(c && t && prefix && out_mask, "NULL argument");

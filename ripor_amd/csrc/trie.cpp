@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <cstring>
 #include <numeric>
@@ -89,6 +90,79 @@ int sort_codes(const uint16_t* codes, int64_t N, int L, std::vector<uint16_t>& s
     }
     for (auto& th : pool) th.join();
   }
+  return 0;
+}
+
+// ---- docid_to_smtid.json ------------------------------------------------------------------------------------
+// One pass over the file with a 4 MB read buffer; no DOM. The reference loads this file with ujson into a dict of
+// 8.8 M Python lists (minutes and tens of GB, evaluate.py:400-402); here it becomes a uint16 matrix directly.
+namespace {
+struct Reader {
+  FILE* f;
+  std::vector<char> buf;
+  size_t pos = 0, len = 0;
+  explicit Reader(FILE* fp) : f(fp), buf(4 << 20) {}
+  int peek() {
+    if (pos == len) { len = std::fread(buf.data(), 1, buf.size(), f); pos = 0; if (len == 0) return -1; }
+    return (unsigned char)buf[pos];
+  }
+  int get() { const int c = peek(); if (c >= 0) ++pos; return c; }
+  int skip_ws() { int c; while ((c = peek()) == ' ' || c == '\n' || c == '\r' || c == '\t') ++pos; return c; }
+};
+}  // namespace
+
+int read_docid_to_smtid(const char* path, std::vector<uint16_t>& codes, std::string& keys, int64_t& N, int& L,
+                        std::string& err) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { err = std::string("cannot open ") + path; return -1; }
+  Reader r(f);
+  auto fail = [&](const std::string& m) { err = m + " (entry " + std::to_string(N) + ")"; std::fclose(f); return -2; };
+  codes.clear(); keys.clear(); N = 0; L = -1;
+  if (r.skip_ws() != '{') return fail("expected '{'");
+  r.get();
+  if (r.skip_ws() == '}') { std::fclose(f); err = "empty docid_to_smtid"; return -2; }
+  for (;;) {
+    if (r.skip_ws() != '"') return fail("expected a quoted docid");
+    r.get();
+    if (N) keys.push_back('\n');
+    for (int c; (c = r.get()) != '"';) {
+      if (c < 0) return fail("unterminated key");
+      if (c == '\\' || c == '\n') return fail("escaped characters in docids are not supported");
+      keys.push_back((char)c);
+    }
+    if (r.skip_ws() != ':') return fail("expected ':'");
+    r.get();
+    if (r.skip_ws() != '[') return fail("expected '['");
+    r.get();
+    int n = 0;
+    for (;;) {
+      int c = r.skip_ws();
+      bool neg = false;
+      if (c == '-') { neg = true; r.get(); c = r.peek(); }
+      if (c < '0' || c > '9') return fail("expected an integer");
+      long v = 0;
+      while ((c = r.peek()) >= '0' && c <= '9') { v = v * 10 + (c - '0'); r.get(); if (v > 1000000) return fail("code out of range"); }
+      if (n == 0) {
+        if (!(neg && v == 1)) return fail("smtid lists must start with -1");
+      } else {
+        if (neg || v > 65535) return fail("code out of range (0..65535)");
+        codes.push_back((uint16_t)v);
+      }
+      ++n;
+      c = r.skip_ws();
+      if (c == ',') { r.get(); continue; }
+      if (c == ']') { r.get(); break; }
+      return fail("expected ',' or ']'");
+    }
+    if (L < 0) L = n - 1;
+    if (n - 1 != L || L < 1) return fail("ragged or empty smtid list");
+    ++N;
+    const int c = r.skip_ws();
+    if (c == ',') { r.get(); continue; }
+    if (c == '}') break;
+    return fail("expected ',' or '}'");
+  }
+  std::fclose(f);
   return 0;
 }
 

@@ -1,5 +1,6 @@
 #pragma once
 #include <stdint.h>
+#include <string>
 #include <vector>
 
 namespace rpr {
@@ -8,4 +9,9 @@ int save_trie_file(const char* path, const std::vector<uint16_t>& sorted, const 
                    int64_t N, int L, int V);
 int load_trie_file(const char* path, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm, int64_t& N, int& L,
                    int& V);
+// Streaming reader of the reference's docid_to_smtid.json: {"docid": [-1, c1, ..., cL], ...}
+// (aq_preprocess/create_customized_smtid_file.py:47-59). codes: [N, L] row-major in file order (the leading -1 is
+// dropped), keys: the docid strings joined by '\n'. Returns 0, or a negative code with *err set.
+int read_docid_to_smtid(const char* path, std::vector<uint16_t>& codes, std::string& keys, int64_t& N, int& L,
+                        std::string& err);
 }  // namespace rpr

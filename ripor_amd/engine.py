@@ -98,6 +98,26 @@ def rel_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distanc
     return int(_lib.load().rpr_rel_bucket(rel, 1 if bidirectional else 0, num_buckets, max_distance))
 
 
+def read_docid_to_smtid(path: str):
+    """``docid_to_smtid.json`` -> (docids: list[str] in file order, codes: uint16 ``[N, L]`` without the
+    leading -1). Streaming C++ reader (``rpr_d2s_*``); host only, needs no GPU. Replaces the reference's
+    ``ujson.load`` + per-doc list slicing (evaluate.py:400-402, 439-446)."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    check(lib.rpr_d2s_open(path.encode(), C.byref(h)), "rpr_d2s_open")
+    try:
+        N, L, kb = C.c_int64(), C.c_int32(), C.c_int64()
+        check(lib.rpr_d2s_dims(h, C.byref(N), C.byref(L), C.byref(kb)), "rpr_d2s_dims")
+        codes = np.empty((N.value, L.value), dtype=np.uint16)
+        keys = C.create_string_buffer(max(1, kb.value))
+        check(lib.rpr_d2s_copy(h, codes.ctypes.data_as(C.c_void_p), keys), "rpr_d2s_copy")
+        docids = keys.raw[:kb.value].decode("utf-8").split("\n")
+    finally:
+        lib.rpr_d2s_close(h)
+    assert len(docids) == codes.shape[0], (len(docids), codes.shape)
+    return docids, codes
+
+
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr

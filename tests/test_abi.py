@@ -83,3 +83,36 @@ def test_product_path_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_docid_to_smtid_streaming_reader(lib, tmp_path):
+    """rpr_d2s_* (host only): same docids / codes as json.load on the reference's file format
+    (create_customized_smtid_file.py:47-59), whitespace variants included; malformed files are refused."""
+    import json
+    from ripor_amd import engine as E
+    from ripor_amd._lib import RiporHipError
+    from ripor_amd.utils import synth
+    codes = synth.make_codes(500, 8, 1024, seed=5)
+    d2s = {str(1000 + 3 * i): [-1] + [int(x) for x in row] for i, row in enumerate(codes)}
+    for k, text in enumerate((json.dumps(d2s), json.dumps(d2s, indent=2), json.dumps(d2s, separators=(",", ":")))):
+        p = tmp_path / f"d2s_{k}.json"
+        p.write_text(text)
+        docids, got = E.read_docid_to_smtid(str(p))
+        assert docids == list(d2s.keys())
+        assert got.dtype == np.uint16 and np.array_equal(got, codes.astype(np.uint16))
+    bad = {
+        "ragged": '{"1": [-1, 2, 3], "2": [-1, 4]}',
+        "no_minus_one": '{"1": [0, 2, 3]}',
+        "negative_code": '{"1": [-1, -2, 3]}',
+        "too_large": '{"1": [-1, 70000]}',
+        "truncated": '{"1": [-1, 2, 3], "2": [-1, 4',
+        "escaped_key": '{"a\\\\"b": [-1, 2]}',
+        "empty": "{}",
+    }
+    for name, text in bad.items():
+        p = tmp_path / f"bad_{name}.json"
+        p.write_text(text)
+        with pytest.raises(RiporHipError):
+            E.read_docid_to_smtid(str(p))
+    with pytest.raises(RiporHipError):
+        E.read_docid_to_smtid(str(tmp_path / "missing.json"))
