@@ -814,7 +814,7 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 }
 
 // 256x256 tile, 8 waves (2x4) of 128x64: half the staged bytes per MFMA of the 128x128 tile; needs
-// >= ~200 tiles to fill the chip, i.e. large in-flight batches (M = Q*B >= ~16k rows for N = 768)
+// >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
@@ -860,7 +860,7 @@ hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s) {
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (force == 256 || (force == 0 && t256 >= 200)) return launch_256(a, s);
+  if (force == 256 || (force == 0 && t256 >= 112)) return launch_256(a, s);
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool narrow = force ? (force == 64) : (t128 < 512);
   return narrow ? launch_cfg<128, 64>(a, s) : launch_cfg<128, 128>(a, s);
