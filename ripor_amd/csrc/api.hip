@@ -798,9 +798,9 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   }
   linear(Ln, {A, At.as<__half>(), (size_t)M * K, K}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
   if (At.p) RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
-  if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x W stamps (6: pipe kernel, 18: ping-pong)
+  if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x 18 slots (gemm_h2_pp_kernel<.., TRACE>)
     const char* we = getenv("RPR_GEMM_TRACE_W");
-    const size_t tw = we ? (size_t)atoi(we) : 6;
+    const size_t tw = we ? (size_t)atoi(we) : 18;
     const size_t n = (size_t)(K / 32) * 8 * tw;
     std::vector<unsigned long long> hbuf(n);
     RPR_HIP(hipMemcpy(hbuf.data(), c->trace_buf, n * 8, hipMemcpyDeviceToHost));

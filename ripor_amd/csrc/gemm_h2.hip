@@ -15,11 +15,10 @@
 // planes; weights are split once at rpr_load_model), so this kernel only moves 16-bit data:
 // operand traffic is 4 B/element, the same as fp32.
 //
-// Tiling (wave64): 128 x BN block tile (BN = 128 or 64), BK = 32, 256 threads = 4 waves (2x2), each
-// wave (64 x BN/2) = TM x TN MFMA 32x32 accumulators. LDS rows hold 32 halves padded to 40 (80 B) so the
-// 16-lane groups of ds_read_b128 hit distinct banks. One LDS buffer + register prefetch of the next
-// K-tile; 41 KB LDS and ~130 VGPRs let three blocks share a CU, which is what hides the global
-// latency at this MFMA rate.
+// Kernels: gemm_h2_pp_kernel (256x256x32 tiles, 8 waves, ping-pong schedule; the default whenever a launch has
+// >= 112 such tiles) and gemm_h2_dma_kernel (128x128 / 128x64 tiles, 4 waves) for smaller launches; both stage
+// K-tiles with LDS-DMA into unpadded XOR-swizzled rows. Earlier variants (register staging, in-phase software
+// pipelining) are in the history and in DESIGN.md §5 / §8 with their measured numbers.
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
@@ -31,165 +30,8 @@ namespace rpr {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int HBK = 32, LDH = HBK + 8;  // halves per LDS row
+constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 
-
-template <int BM, int BN, bool FULL>
-__global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int PA = BM / 64, PW = BN / 64;  // staging passes: 64 rows x 4 x 16 B per pass per plane
-  constexpr int ROWS = 2 * (BM + BN);
-  __shared__ __attribute__((aligned(16))) __half smem[ROWS * LDH];
-
-  int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
-    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
-    if (bid >= nt) return;
-  }
-  {
-    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int bm = tm * BM, bn = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // staging: thread (row = tid>>2, seg = tid&3) moves 16 B (8 halves) of rows row, row+64, .. of each plane
-  const int srow = tid >> 2, seg8 = (tid & 3) * 8;
-  static_assert(PA == 2 && (PW == 1 || PW == 2), "staging is written out for BM = 128, BN in {64, 128}");
-  // named registers (arrays indexed inside unrolled loops end up in scratch with hipcc 7.2)
-  uint4 a00, a01, a10, a11, w00, w01, w10 = make_uint4(0u, 0u, 0u, 0u), w11 = make_uint4(0u, 0u, 0u, 0u);
-  const __half* Ab = g.A + (size_t)(bm + srow) * g.lda + seg8;
-  const __half* Wb = g.W + (size_t)(bn + srow) * g.ldw + seg8;
-  const size_t a64 = (size_t)64 * g.lda, w64 = (size_t)64 * g.ldw;
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  const bool aok0 = FULL || (bm + srow < g.M), aok1 = FULL || (bm + srow + 64 < g.M);
-  const bool wok0 = FULL || (bn + srow < g.N), wok1 = FULL || (bn + srow + 64 < g.N);
-#define H2_LD(ptr, ok) ((FULL || (ok)) ? *reinterpret_cast<const uint4*>(ptr) : zero4)
-#define H2_GLOAD(k0)                                              \
-  a00 = H2_LD(Ab + (k0), aok0);                                   \
-  a01 = H2_LD(Ab + g.a_ps + (k0), aok0);                          \
-  a10 = H2_LD(Ab + a64 + (k0), aok1);                             \
-  a11 = H2_LD(Ab + g.a_ps + a64 + (k0), aok1);                    \
-  w00 = H2_LD(Wb + (k0), wok0);                                   \
-  w01 = H2_LD(Wb + g.w_ps + (k0), wok0);                          \
-  if (PW > 1) {                                                   \
-    w10 = H2_LD(Wb + w64 + (k0), wok1);                           \
-    w11 = H2_LD(Wb + g.w_ps + w64 + (k0), wok1);                  \
-  }
-  // LDS rows: A plane p rows [p*BM, p*BM+BM), W plane p rows [2*BM + p*BN, ...)
-#define H2_ST(row, v) *reinterpret_cast<uint4*>(&smem[(row) * LDH + seg8]) = (v)
-#define H2_LSTORE()                                               \
-  H2_ST(srow, a00); H2_ST(BM + srow, a01);                        \
-  H2_ST(srow + 64, a10); H2_ST(BM + srow + 64, a11);              \
-  H2_ST(2 * BM + srow, w00); H2_ST(2 * BM + BN + srow, w01);      \
-  if (PW > 1) { H2_ST(2 * BM + srow + 64, w10); H2_ST(2 * BM + BN + srow + 64, w11); }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment: lane -> row lane&31, halves (lane>>5)*8 .. +7 of each 16-wide k chunk
-  const int frow = lane & 31, fk = (lane >> 5) * 8;
-  const __half* a_frag = smem + (wm * (BM / 2) + frow) * LDH + fk;
-  const __half* w_frag = smem + (2 * BM + wn * (BN / 2) + frow) * LDH + fk;
-
-  auto compute = [&]() {
-#pragma unroll
-    for (int c = 0; c < HBK / 16; ++c) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(a_frag + (i * 32) * LDH + c * 16);
-        al[i] = *reinterpret_cast<const f16x8*>(a_frag + (BM + i * 32) * LDH + c * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(w_frag + (j * 32) * LDH + c * 16);
-        bl[j] = *reinterpret_cast<const f16x8*>(w_frag + (BN + j * 32) * LDH + c * 16);
-      }
-      // product-major order: the TM*TN accumulators are independent, so dependent MFMAs on one
-      // accumulator are TM*TN issue slots apart
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nkt = g.K / HBK;
-  H2_GLOAD(0)
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
-    H2_LSTORE()
-    __syncthreads();
-    H2_GLOAD((kt + 1) * HBK)
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it to its use)
-    compute();
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  H2_LSTORE()
-  __syncthreads();
-  compute();
-#undef H2_GLOAD
-#undef H2_LSTORE
-#undef H2_LD
-#undef H2_ST
-
-  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
-  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn + wn * (BN / 2) + j * 32 + ncol;
-    if (!FULL && n >= g.N) continue;
-    const int oi = n / g.split_n, on = n - oi * g.split_n;
-    float* outp = g.out[oi];
-    const int ldo = g.ldo[oi];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mbase = bm + wm * (BM / 2) + i * 32 + rsub;
-      float res[16];
-      if (g.resid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          res[r] = (FULL || m < g.M) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (FULL || m < g.M) {
-          float v = acc[i][j][r];
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.resid) v = res[r] + v;
-          if (g.out_h) {
-            __half hi, lo;
-            split_f16(v, hi, lo);
-            g.out_h[(size_t)m * g.ldoh + n] = hi;
-            g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
-          } else {
-            outp[out_off(g, oi, m, ldo, on)] = v;
-          }
-        }
-      }
-    }
-  }
-}
 
 // ---- LDS-DMA variant -------------------------------------------------------------------------------
 // Same math, but the K-tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
@@ -474,139 +316,6 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   }
 }
 
-// ---- software-pipelined 256x256 variant -----------------------------------------------------------------
-// Same tile/LDS layout as gemm_h2_dma_kernel<256,256,2,4>, but the fragment reads are pipelined by
-// hand: a K-tile is two 16-wide chunks; while the MFMAs of one chunk run, the ds_reads of the next
-// chunk (possibly of the next K-tile) are already in flight into a second fragment register set, and
-// the one barrier per K-tile sits between the two chunks:
-//     F1(t) reads | MFMA chunk0(t) | wait DMA(t+1) + barrier | DMA(t+2) issue | F0(t+1) reads | MFMA chunk1(t)
-// hipcc's own schedule issued each ds_read group right before its MFMAs (~10 exposed LDS latencies per
-// K-tile and wave; both waves of a SIMD stall together because the barrier keeps them in phase).
-template <bool FULL, int WM = 2, int WN = 4, int LW = 8>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  constexpr int BM = 256, BN = 256, NW = WM * WN, TM = BM / (32 * WM), TN = BN / (32 * WN);
-  constexpr int ROWS = 2 * (BM + BN), NINST = ROWS / 16, PER_WAVE = NINST / LW;  // DMA pieces per loader wave per K-tile
-  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
-
-  int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
-    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
-    if (bid >= nt) return;
-  }
-  {
-    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int bm = tm * BM, bn = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int lbm = bm, lbn = bn;
-
-  // LW = number of waves that issue the LDS-DMA (all 8 by default; LW = 4, one loader per SIMD, measured
-  // slower: 283 vs 326 TF/s — the loaders' 16 pieces serialise behind each other)
-  const bool loader = wave < LW;
-  const __half* src[PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int lrow = 16 * ((wave % LW) + LW * j) + (lane >> 2);
-    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
-    const __half* base;
-    int trow, limit;
-    size_t ld;
-    if (lrow < BM) { base = g.A; trow = lbm + lrow; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = lbm + lrow - BM; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM + BN) { base = g.W; trow = lbn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
-    else { base = g.W + g.w_ps; trow = lbn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
-    if (!FULL && trow >= limit) trow = limit - 1;
-    src[j] = base + (size_t)trow * ld + seg * 8;
-  }
-  auto stage = [&](int buf, int k0) {
-    if (!loader) return;
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-      __half* dst = smem + (size_t)buf * ROWS * HBK + 16 * (wave + LW * j) * HBK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
-  const int a_row = wm * (BM / WM) + frow, w_row = 2 * BM + wn * (BN / WN) + frow;
-  const int so0 = ((0 + hf) ^ sw) * 8, so1 = ((2 + hf) ^ sw) * 8;   // segment offsets of chunk 0 / 1
-
-  struct Frag { f16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
-  auto load_frag = [&](Frag& f, int buf, int so) {
-    const __half* base = smem + (size_t)buf * ROWS * HBK;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      f.ah[i] = *reinterpret_cast<const f16x8*>(base + (a_row + i * 32) * HBK + so);
-      f.al[i] = *reinterpret_cast<const f16x8*>(base + (BM + a_row + i * 32) * HBK + so);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      f.bh[j] = *reinterpret_cast<const f16x8*>(base + (w_row + j * 32) * HBK + so);
-      f.bl[j] = *reinterpret_cast<const f16x8*>(base + (BN + w_row + j * 32) * HBK + so);
-    }
-  };
-  auto mma = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-  };
-
-  const int nkt = g.K / HBK;
-  Frag f0, f1;
-  // optional cycle trace of block 0 (diagnostic; g.trace == nullptr in production)
-  const bool tr = g.trace != nullptr && blockIdx.x == 0 && lane == 0;
-#define H2_STAMP(slot) if (tr) g.trace[((size_t)kt * NW + wave) * 6 + (slot)] = __builtin_readcyclecounter()
-  stage(0, 0);
-  __syncthreads();                       // tile 0 landed
-  if (nkt > 1) stage(1, HBK);            // tile 1 in flight
-  load_frag(f0, 0, so0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    H2_STAMP(0);
-    load_frag(f1, cur, so1);             // chunk 1 of this tile, hidden behind chunk 0's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    H2_STAMP(1);
-    mma(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    H2_STAMP(2);
-    __syncthreads();                     // every wave holds tile kt in registers; tile kt+1 has landed (vmcnt(0))
-    H2_STAMP(3);
-    if (kt + 2 < nkt) stage(cur, (kt + 2) * HBK);          // refill the buffer just released
-    if (kt + 1 < nkt) load_frag(f0, cur ^ 1, so0);          // chunk 0 of the next tile, hidden behind chunk 1
-    __builtin_amdgcn_sched_barrier(0);
-    H2_STAMP(4);
-    mma(f1);
-    __builtin_amdgcn_sched_barrier(0);
-    H2_STAMP(5);
-  }
-#undef H2_STAMP
-
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn);
-}
-
 // ---- ping-pong 256x256 variant -------------------------------------------------------------------------
 // Same tile, LDS layout and epilogue as the pipe kernel; different K-loop synchronisation. The 8 waves are
 // two groups of four (wm = 0 / 1), one wave of each group per SIMD. A K-tile is four phases (k-chunk x
@@ -620,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_h2_pipe_kern
 // `s_waitcnt vmcnt(0)` at the end of L_3 and first read in L_0 of tile t+1 (one phase after the wait, as
 // the staggered groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's
 // last reads are retired before the other group starts overwriting it.
-template <bool FULL, bool TRACE = false, int DV = 1, bool PRIO = true>
+template <bool FULL, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
   constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
@@ -707,10 +416,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                           \
     PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                           \
   }
+// the 8 LDS-DMA pieces of the next tile go into the MFMA shadows of M_0 / M_1 / M_2 (3 + 3 + 2); issuing them in
+// the load segments instead (4+4 or 3+3+2), with or without s_setprio, measured the same within 0.5 % (DVFS)
 #define PP_DMA(j) if (more) PP_PIECE(nxt, k1, j)
-// DV = where the 8 pieces go: 0: L_0/L_1 (4+4)   1: MFMA shadows of M_0/M_1/M_2 (3+3+2)   2: L_0/L_1/L_2 (3+3+2)
-#define PP_DMA_L(v, j) if (DV == (v)) PP_DMA(j)
-#define PP_DMA_M(j) if (DV == 1) PP_DMA(j)
+#define PP_DMA_M(j) PP_DMA(j)
 // end of a load segment: retire this wave's ds_reads (and, with VM, its LDS-DMA), then the segment barrier
 #define PP_L_END(waitimm, ph)                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -719,10 +428,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __builtin_amdgcn_s_barrier();                                                                         \
   PP_STAMP((ph) * 4 + 2);                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
-  if (PRIO) __builtin_amdgcn_s_setprio(1)
+  __builtin_amdgcn_s_setprio(1)
 #define PP_M_END(ph)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
-  if (PRIO) __builtin_amdgcn_s_setprio(0);                                                              \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
   PP_STAMP((ph) * 4 + 3);                                                                               \
   __builtin_amdgcn_s_barrier();                                                                         \
   __builtin_amdgcn_sched_barrier(0)
@@ -749,16 +458,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     PP_STAMP(0);
     PP_LOAD_W(cur, so0);
     PP_LOAD_A(cur, so0, 0);
-    PP_DMA_L(0, 0); PP_DMA_L(0, 1); PP_DMA_L(0, 2); PP_DMA_L(0, 3);
-    PP_DMA_L(2, 0); PP_DMA_L(2, 1); PP_DMA_L(2, 2);
     PP_L_END(WAIT_LGKM, 0);
     PP_MMA(0, PP_DMA_M(0), PP_DMA_M(1), PP_DMA_M(2));
     PP_M_END(0);
     // phase 1: chunk 0, A rows 64..127
     PP_STAMP(4);
     PP_LOAD_A(cur, so0, 2);
-    PP_DMA_L(0, 4); PP_DMA_L(0, 5); PP_DMA_L(0, 6); PP_DMA_L(0, 7);
-    PP_DMA_L(2, 3); PP_DMA_L(2, 4); PP_DMA_L(2, 5);
     PP_L_END(WAIT_LGKM, 1);
     PP_MMA(2, PP_DMA_M(3), PP_DMA_M(4), PP_DMA_M(5));
     PP_M_END(1);
@@ -766,7 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     PP_STAMP(8);
     PP_LOAD_W(cur, so1);
     PP_LOAD_A(cur, so1, 0);
-    PP_DMA_L(2, 6); PP_DMA_L(2, 7);
     PP_L_END(WAIT_LGKM, 2);
     PP_MMA(0, PP_DMA_M(6), PP_DMA_M(7), (void)0);
     PP_M_END(2);
@@ -785,7 +489,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 #undef PP_MFMA
 #undef PP_MMA
 #undef PP_DMA
-#undef PP_DMA_L
 #undef PP_DMA_M
 #undef PP_L_END
 #undef PP_M_END
@@ -798,60 +501,25 @@ template <int BM, int BN>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const bool full = (a.M % BM == 0) && (a.N % BN == 0);
-  static const int variant = [] { const char* e = getenv("RPR_GEMM_H2"); return e ? atoi(e) : 1; }();  // 1 = LDS-DMA
-  if (variant == 1) {
-    if (full)
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
-    else
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
-    return hipGetLastError();
-  }
   if (full)
-    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
   return hipGetLastError();
 }
 
-// 256x256 tile, 8 waves (2x4) of 128x64: half the staged bytes per MFMA of the 128x128 tile; needs
+// 256x256 tile, 8 waves (2x4) of 128x64, ping-pong schedule: half the staged bytes per MFMA of the 128x128 tile;
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
-  static const int ilv = [] { const char* e = getenv("RPR_GEMM_ILV"); return e ? atoi(e) : 1; }();
-  static const int pipe = [] { const char* e = getenv("RPR_GEMM_PIPE"); return e ? atoi(e) : 2; }();  // 2 = ping-pong
-  if (pipe == 2) {
-    if (full && a.trace)
-      hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
-    else if (full) {
-      static const int var = [] { const char* e = getenv("RPR_GEMM_PP_VAR"); return e ? atoi(e) : 0; }();
-      const dim3 gr(tiles_m * tiles_n), bl(512);
-      switch (var) {
-        case 3: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 0, true>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
-        case 2: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 2, true>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
-        case 10: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 0, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
-        case 11: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 1, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
-        case 12: hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, 2, false>), gr, bl, 0, s, a, tiles_m, tiles_n); break;
-        default: hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
-      }
-    }
-    else
-      hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
-    return hipGetLastError();
-  }
-  if (pipe) {
-    if (full)
-      hipLaunchKernelGGL((gemm_h2_pipe_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
-    else
-      hipLaunchKernelGGL((gemm_h2_pipe_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
-    return hipGetLastError();
-  }
-  if (full && ilv)
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, true, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+  const dim3 gr(tiles_m * tiles_n), bl(512);
+  if (full && a.trace)
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
   else if (full)
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<256, 256, 2, 4, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n);
   return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 """Cycle trace of the ping-pong GEMM kernel's block 0 (diagnostic; GPU box).
-RPR_GEMM_PIPE=2 RPR_GEMM_TRACE=/tmp/tr.txt RPR_GEMM_TRACE_W=18 python tools/gemm_trace_pp.py"""
+RPR_GEMM_TRACE=/tmp/tr.txt RPR_GEMM_TRACE_W=18 python tools/gemm_trace_pp.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
