@@ -294,6 +294,14 @@ def search(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attent
     ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
     mask = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
     Q, Lq = ids.shape
+    if not taps and Lq % 8 and Lq < 256:
+        # Bucket the padded length to a multiple of 8 (extra columns: id 0, mask 0 — masked keys, identical
+        # results). The encoder runs on packed rows, so the padding is free on the device, and a stream of
+        # batches with different longest queries reuses a handful of captured hipGraphs instead of one per length.
+        pad = min(256, (Lq + 7) // 8 * 8) - Lq
+        ids = torch.nn.functional.pad(ids, (0, pad))
+        mask = torch.nn.functional.pad(mask, (0, pad))
+        Lq += pad
     B, L = int(num_beams), int(max_new_tokens)
     tokens = torch.empty((Q, B, L), dtype=torch.int32, device=dev)
     scores = torch.empty((Q, B), dtype=torch.float32, device=dev)
