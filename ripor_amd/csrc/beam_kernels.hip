@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   int* blo = reinterpret_cast<int*>(taken + words);                      // [B]
   int* bhi = blo + B;                                                    // [B]
   int* widx = bhi + B;                                                   // [B]
-  int* red_i = widx + B;                                                 // [4]
-  float* lmax = reinterpret_cast<float*>(red_i + 4);                     // [B]
+  int* red_i = widx + B;                                                 // [8]
+  float* lmax = reinterpret_cast<float*>(red_i + 8);                     // [B]   (red_i[4] = rescan flag)
   float* lsum = lmax + B;                                                // [B] log(sum exp)
   float* slog = lsum + B;                                                // [B*V] logits of the query (a.lds_logits)
 
@@ -128,25 +128,80 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
   __syncthreads();
 
-  auto cand_score = [&](int item) -> double {
+  auto raw_logit = [&](int item) -> float {
+    if (a.lds_logits) return slog[item];
+    return lg_q[a.shared0 ? item % V : item];
+  };
+  auto cand_score = [&](int item, float lg) -> double {
     const int b = item / V;
-    float lg = a.lds_logits ? slog[item] : lg_q[a.shared0 ? item - b * V : item];
     if (a.log_softmax) lg = (lg - lmax[b]) - lsum[b];
     const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
     return ((double)lg + (ok ? 0.0 : -1e9)) + bscore[b];
   };
-  auto scan_best = [&]() -> Cand {
+  // best untaken candidate among items first, first + stride, ... The logits of four candidates are requested
+  // before any of them is looked at: at B = 1000 they live in global memory (L2), and one dependent read per
+  // candidate made every arg-max round cost ~16 L2 latencies.
+  auto scan_items = [&](int first, int stride) -> Cand {
     Cand best; best.s = -INFINITY; best.item = 0x7fffffff;
-    for (int item = tid; item < items; item += 256) {
-      if ((taken[item >> 6] >> (item & 63)) & 1ull) continue;
-      Cand c; c.s = cand_score(item); c.item = item;
-      if (better(c, best)) best = c;
+    for (int item = first; item < items; item += 4 * stride) {
+      float lg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = item + u * stride;
+        lg[u] = it < items ? raw_logit(it) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = item + u * stride;
+        if (it >= items) break;
+        if ((taken[it >> 6] >> (it & 63)) & 1ull) continue;
+        Cand c; c.s = cand_score(it, lg[u]); c.item = it;
+        if (better(c, best)) best = c;
+      }
     }
     return best;
   };
 
   // ---- phase B/C: B rounds of block-wide argmax ----
-  Cand mine = scan_best();
+  // Every thread owns the candidates tid, tid + 256, ... and keeps its TK best in a sorted register list, built in
+  // one pass. A round = block-wide arg-max over the list heads; the winner's thread pops its list. Only a thread
+  // that has won TK times (and owns more candidates) falls back to a rescan of its candidates, done cooperatively
+  // by its wave. With B*V/256 <= TK (B = 10) there is no rescan at all; at B = 1000 a rescan per round cost ~7 us.
+  constexpr int TK = 8;
+  double ts[TK];
+  int ti[TK];
+#pragma unroll
+  for (int i = 0; i < TK; ++i) { ts[i] = -INFINITY; ti[i] = 0x7fffffff; }
+  int own = 0;   // candidates owned by this thread
+  for (int item = tid; item < items; item += 4 * 256) {
+    float lg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = item + u * 256;
+      lg[u] = it < items ? raw_logit(it) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = item + u * 256;
+      if (it >= items) break;
+      ++own;
+      Cand c; c.s = cand_score(it, lg[u]); c.item = it;
+      Cand last; last.s = ts[TK - 1]; last.item = ti[TK - 1];
+      if (!better(c, last)) continue;
+      ts[TK - 1] = c.s; ti[TK - 1] = c.item;
+#pragma unroll
+      for (int i = TK - 1; i > 0; --i) {   // bubble up (static register indices)
+        Cand lo_; lo_.s = ts[i]; lo_.item = ti[i];
+        Cand hi_; hi_.s = ts[i - 1]; hi_.item = ti[i - 1];
+        if (better(lo_, hi_)) { ts[i] = hi_.s; ti[i] = hi_.item; ts[i - 1] = lo_.s; ti[i - 1] = lo_.item; }
+      }
+    }
+  }
+  int left = own < TK ? own : TK;        // entries of the list not yet consumed
+  const bool more = own > TK;            // candidates beyond the list exist
+  int* resc = red_i + 4;                 // LDS flag: the winner's wave must rescan for it
+  if (tid == 0) *resc = 0;
+  Cand mine; mine.s = ts[0]; mine.item = ti[0];
   for (int j = 0; j < B; ++j) {
     const Cand wb = wave_best(mine);
     if (lane == 0) { red_s[wave] = wb.s; red_i[wave] = wb.item; }
@@ -161,18 +216,20 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     const int owner_tid = win.item & 255;
     const bool owner = any && owner_tid == tid;
     if (tid == 0) { wscore[j] = win.s; widx[j] = win.item; }
-    if (owner) taken[win.item >> 6] |= 1ull << (win.item & 63);  // single writer per round (one winner), fenced by the barriers
-    __syncthreads();
-    // only the winner's thread has a stale local best: its whole wave rescans that thread's candidates
-    // (items owner_tid + 256 k) together — a single thread walking its B*V/256 items made every round cost
-    // ~100 dependent LDS round trips at B = 100
-    if (any && wave == (owner_tid >> 6)) {
-      Cand best; best.s = -INFINITY; best.item = 0x7fffffff;
-      for (int item = owner_tid + 256 * lane; item < items; item += 256 * 64) {
-        if ((taken[item >> 6] >> (item & 63)) & 1ull) continue;
-        Cand c; c.s = cand_score(item); c.item = item;
-        if (better(c, best)) best = c;
+    if (owner) {
+      taken[win.item >> 6] |= 1ull << (win.item & 63);  // single writer per round (one winner), fenced by the barriers
+      if (left > 0) {                     // pop the list head
+#pragma unroll
+        for (int i = 0; i < TK - 1; ++i) { ts[i] = ts[i + 1]; ti[i] = ti[i + 1]; }
+        ts[TK - 1] = -INFINITY; ti[TK - 1] = 0x7fffffff;
+        --left;
       }
+      mine.s = ts[0]; mine.item = ti[0];
+      *resc = (left == 0 && more) ? 1 : 0;
+    }
+    __syncthreads();
+    if (any && *resc && wave == (owner_tid >> 6)) {   // list exhausted: the wave rescans that thread's candidates
+      Cand best = scan_items(owner_tid + 256 * lane, 256 * 64);
       best = wave_best(best);
       if (owner) mine = best;
     }
@@ -211,7 +268,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 static size_t select_smem(int B, int V) {
   const size_t words = (size_t)B * V / 64;
   return (2 * (size_t)B + 4) * sizeof(double) + 2 * words * sizeof(unsigned long long) +
-         (3 * (size_t)B + 4) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
+         (3 * (size_t)B + 8) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
 }
 
 hipError_t init_beam_kernel_attributes() {

@@ -137,6 +137,7 @@ struct DecCrossAttnArgs {
   __half* out_h; size_t o_ps;
   const int32_t* last;     // [Q] index of the last attended key + 1 (launch_mask_lengths)
   const int32_t* offs;     // nullable (packed encoder): K/V row (q, j) is row offs[q] + j instead of q*Lq + j
+  int bchunk;              // set by the launcher: beams per block when the beam is split over blockIdx.y (0 = all)
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 

@@ -486,13 +486,17 @@ constexpr int XK_LD = DKV + 4, QS_LD = DKV + 4;
 
 __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = a.H, B = a.B, inner = H * DKV;
+  // Bq = beams of the query, B = the beams this block handles (all of them, or one chunk of a.bchunk when the
+  // per-beam LDS rows of a large beam — topk = 1000 in the reference's retrieval script — would not fit)
+  const int H = a.H, Bq = a.B, inner = H * DKV;
+  const int b_first = a.bchunk ? (int)blockIdx.y * a.bchunk : 0;
+  const int B = a.bchunk ? min(a.bchunk, Bq - b_first) : Bq;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
   const int SLD = a.Lq + 1;
   float* Ks = smem;                        // [Lq][68]
   float* Vs = Ks + (size_t)a.Lq * XK_LD;   // [Lq][64]
   float* Qs = Vs + (size_t)a.Lq * DKV;     // [B][68]
-  float* S = Qs + (size_t)B * QS_LD;       // [B][Lq+1]
+  float* S = Qs + (size_t)(a.bchunk ? a.bchunk : Bq) * QS_LD;       // [B][Lq+1]
   const int tid = threadIdx.x;
   const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
   const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;   // packed or padded encoder rows
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   for (int i = tid; i < B * 16; i += 256) {
     const int b = i >> 4, c = (i & 15) * 4;
     *reinterpret_cast<float4*>(Qs + b * QS_LD + c) =
-        *reinterpret_cast<const float4*>(a.q + (size_t)(qi * B + b) * inner + h * DKV + c);
+        *reinterpret_cast<const float4*>(a.q + (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c);
   }
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
     }
     const float inv = 1.0f / sum;
     o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-    const size_t oidx = (size_t)(qi * B + b) * inner + h * DKV + c;
+    const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c;
     if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, o);
     else *reinterpret_cast<float4*>(a.out + oidx) = o;
   }
@@ -589,11 +593,20 @@ hipError_t init_t5_kernel_attributes() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
+  DecCrossAttnArgs a = a_in;
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
-  const size_t smem = ((size_t)a.Lq * (XK_LD + DKV) + (size_t)a.B * (QS_LD + a.Lq + 1) + 4) * sizeof(float);
+  auto smem_for = [&](int nb) { return ((size_t)a.Lq * (XK_LD + DKV) + (size_t)nb * (QS_LD + a.Lq + 1) + 4) * sizeof(float); };
+  a.bchunk = 0;
+  int chunks = 1;
+  if (smem_for(a.B) > 64 * 1024) {   // large beams: split the query's beams over blockIdx.y (K/V re-staged per chunk)
+    a.bchunk = 64;
+    while (a.bchunk > 1 && smem_for(a.bchunk) > 64 * 1024) a.bchunk >>= 1;
+    chunks = (a.B + a.bchunk - 1) / a.bchunk;
+  }
+  const size_t smem = smem_for(a.bchunk ? a.bchunk : a.B);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H, chunks), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 

@@ -158,3 +158,34 @@ def test_skewed_trie_with_duplicate_smtids(setup):
             assert docs == s2d[key]
             sizes.append(len(docs))
     assert max(sizes) > 1, "the skewed fixture is meant to contain smtids shared by several docs"
+
+
+def test_beam_1000_like_the_reference_retrieval_script(setup):
+    """full_scripts/full_evaluate_t5seq_aq_encoder.sh:199 runs the retrieval with --topk=1000. More beams than trie
+    children at the first levels (so -1e9 candidates are selected and later die out), beam-chunked cross-attention,
+    the global-memory path of the select kernel (B*V logits do not fit LDS)."""
+    from oracle import beam_ref, t5_ref
+    E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
+    L, V, N, B, Q = 3, 256, 6000, 1000, 2
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512)
+    sd = synth.make_state_dict(dims, seed=61)
+    codes = synth.make_codes(N, L, V, seed=61)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=62, max_len=9)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    torch.cuda.synchronize()
+    exp_tok = seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:]
+    exp_sc = sc.numpy().reshape(Q, B)
+    got_tok, got_sc = res.tokens.cpu().numpy(), res.scores.cpu().numpy()
+    np.testing.assert_allclose(got_sc, exp_sc, atol=1e-4, rtol=0)
+    # ranks whose score is separated from both neighbours by more than the fp32 reorder noise must agree exactly
+    for q in range(Q):
+        gap = np.minimum(np.abs(np.diff(exp_sc[q], prepend=np.inf)), np.abs(np.diff(exp_sc[q], append=-np.inf)))
+        clear = gap > 5e-4   # 1000 beams are dense in score: most, not all, ranks are clearly separated
+        assert clear.mean() > 0.5
+        assert np.array_equal(got_tok[q][clear], exp_tok[q][clear])
+    leaf = (res.row_hi > res.row_lo).cpu().numpy()
+    assert leaf.all(), "with 6000 docs every one of the 1000 returned smtids must be a real doc"
