@@ -64,7 +64,9 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
   return c;
 }
 
-// One block (256 threads) per query.
+// One block (256 threads) per query. TK = length of the per-thread candidate lists (8 for the rounds of small
+// beams, 16 for the sorted path of large ones).
+template <int TK>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int B = a.B, V = a.V, t = a.t, Lc = a.Lc;
@@ -96,21 +98,83 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   // ---- phase A: child mask of every beam (64 consecutive tokens of one beam per wave) ----
   const float* lg_q = a.logits + (a.shared0 ? (size_t)q * V : (size_t)r0 * V);   // shared0: one row per query
   int* lb_q = a.lb_scratch + (size_t)r0 * V;
-  for (int item = tid; item < items; item += 256) {
-    const int b = item / V, c = item - b * V;
-    const int lo = blo[b], hi = bhi[b];
-    bool ok = false;
-    int l = lo;
-    if (t < Lc && lo < hi) {
-      l = lower_bound_col(a.codes, Lc, t, lo, hi, c);
-      ok = (l < hi) && ((int)a.codes[(size_t)l * Lc + t] == c);
+  // Wide ranges (the first trie levels): one binary search per (beam, token) over the sorted column, the bitmap
+  // word of 64 tokens comes from a ballot. Narrow ranges (<= NARROW rows — every beam from depth ~3 on, one doc
+  // each): the children are enumerated from the rows themselves, <= NARROW reads per beam instead of V searches
+  // (at B = 1000 the V searches per beam were ~1000 dependent global reads per thread and step).
+  constexpr int NARROW = 32;
+  // step 0: every beam starts at the root range (init_beams_kernel), so only beam 0 is searched and copied below
+  const int search_items = (t == 0) ? V : items;
+  for (int item = tid; item < items; item += 4 * 256) {
+    // four (beam, token) pairs per thread advance their binary searches in lockstep: the four probes of a step
+    // are independent loads (one search at a time was one dependent L2/HBM latency per probe)
+    int lo4[4], hi4[4], end4[4], c4[4];
+    bool act[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = item + u * 256;
+      const bool in = it < items;                      // wave-uniform (V % 64 == 0)
+      const int b = in ? it / V : 0, c = it - b * V;
+      const int lo = blo[b], hi = bhi[b];
+      if (in && a.lds_logits) slog[it] = lg_q[a.shared0 ? c : it];
+      const bool narrow = hi - lo <= NARROW;           // wave-uniform: a wave covers 64 tokens of one beam
+      if (in && narrow && lane == 0) valid[it >> 6] = 0ull;
+      act[u] = in && !narrow && it < search_items;
+      lo4[u] = lo; hi4[u] = (act[u] && t < Lc) ? hi : lo; end4[u] = hi; c4[u] = c;
     }
-    lb_q[item] = l;
-    // the arg-max rounds rescan a thread's candidates after every win: keep the logits in LDS when they fit
-    // (B = 100: 100 dependent L2 reads per rescan made the kernel 7 % of the step)
-    if (a.lds_logits) slog[item] = lg_q[a.shared0 ? c : item];
-    const unsigned long long m = __ballot(ok);
-    if (lane == 0) valid[item >> 6] = m;
+    for (;;) {
+      int v4[4];
+      bool go = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v4[u] = 0;
+        if (lo4[u] < hi4[u]) {
+          go = true;
+          v4[u] = a.codes[(size_t)(int)(((unsigned)lo4[u] + (unsigned)hi4[u]) >> 1) * Lc + t];
+        }
+      }
+      if (!go) break;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (lo4[u] < hi4[u]) {
+          const int mid = (int)(((unsigned)lo4[u] + (unsigned)hi4[u]) >> 1);
+          if (v4[u] < c4[u]) lo4[u] = mid + 1; else hi4[u] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = item + u * 256;
+      if (!act[u]) continue;                           // wave-uniform
+      const int l = lo4[u];
+      const bool ok = t < Lc && l < end4[u] && (int)a.codes[(size_t)l * Lc + t] == c4[u];
+      lb_q[it] = l;
+      const unsigned long long m = __ballot(ok);
+      if (lane == 0) valid[it >> 6] = m;
+    }
+  }
+  if (t == 0 && B > 1) {   // replicate beam 0's row (same root range for every beam)
+    __syncthreads();
+    if (bhi[0] - blo[0] > NARROW) {
+      for (int it = V + tid; it < items; it += 256) {
+        const int c = it % V;
+        lb_q[it] = lb_q[c];
+        if ((it & 63) == 0) valid[it >> 6] = valid[c >> 6];
+      }
+    }
+  }
+  __syncthreads();
+  if (t < Lc) {
+    for (int idx = tid; idx < B * NARROW; idx += 256) {
+      const int b = idx / NARROW, k = idx - b * NARROW;
+      const int lo = blo[b], hi = bhi[b];
+      const int r = lo + k;
+      if (hi - lo > NARROW || r >= hi) continue;
+      const int c = a.codes[(size_t)r * Lc + t];
+      const int item = b * V + c;
+      atomicOr(&valid[item >> 6], 1ull << (item & 63));
+      if (k == 0 || (int)a.codes[(size_t)(r - 1) * Lc + t] != c) lb_q[item] = r;   // first row of this child
+    }
   }
   if (a.log_softmax) {  // fp32 log_softmax over V (generation.py:453-455): (x - max) - log(sum exp(x - max))
     for (int b = wave; b < B; b += 4) {
@@ -164,10 +228,13 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 
   // ---- phase B/C: B rounds of block-wide argmax ----
   // Every thread owns the candidates tid, tid + 256, ... and keeps its TK best in a sorted register list, built in
-  // one pass. A round = block-wide arg-max over the list heads; the winner's thread pops its list. Only a thread
-  // that has won TK times (and owns more candidates) falls back to a rescan of its candidates, done cooperatively
-  // by its wave. With B*V/256 <= TK (B = 10) there is no rescan at all; at B = 1000 a rescan per round cost ~7 us.
-  constexpr int TK = 8;
+  // one pass.
+  //  * B <= 256: B rounds of block-wide arg-max over the list heads; the winner's thread pops its list (a thread
+  //    that has won TK times and owns more candidates has its wave rescan them — never happens for B*V/256 <= TK).
+  //  * B > 256 (a.sort_lds): the 256 lists are written to LDS and sorted with one bitonic network (4096 entries);
+  //    the first B entries are the winners in rank order. This is exact unless some thread owns more than TK of
+  //    the top B (its last list entry is inside the top B and it has more candidates) — then the rounds run
+  //    instead. B = 1000 spent 1000 sequential rounds (2.8 us each) per step before.
   double ts[TK];
   int ti[TK];
 #pragma unroll
@@ -200,7 +267,39 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   int left = own < TK ? own : TK;        // entries of the list not yet consumed
   const bool more = own > TK;            // candidates beyond the list exist
   int* resc = red_i + 4;                 // LDS flag: the winner's wave must rescan for it
-  if (tid == 0) *resc = 0;
+  int* overflow = red_i + 5;             // LDS flag: the sorted union of the lists may miss a top-B candidate
+  if (tid == 0) { *resc = 0; *overflow = 0; }
+  bool need_rounds = true;
+  if (a.sort_lds) {
+    constexpr int NS = 256 * TK;
+    double* cs = reinterpret_cast<double*>(smem_raw + a.sort_off);   // [NS]
+    int* ci = reinterpret_cast<int*>(cs + NS);                       // [NS]
+#pragma unroll
+    for (int i = 0; i < TK; ++i) { cs[tid * TK + i] = ts[i]; ci[tid * TK + i] = ti[i]; }
+    __syncthreads();
+    for (int k = 2; k <= NS; k <<= 1) {
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        for (int p = tid; p < NS / 2; p += 256) {
+          const int lo_i = 2 * p - (p & (jj - 1));        // the pair (lo_i, lo_i + jj)
+          const int hi_i = lo_i + jj;
+          const bool desc = (lo_i & k) == 0;               // best-first in the blocks that end up in front
+          Cand x; x.s = cs[lo_i]; x.item = ci[lo_i];
+          Cand y; y.s = cs[hi_i]; y.item = ci[hi_i];
+          if (better(y, x) == desc) { cs[lo_i] = y.s; ci[lo_i] = y.item; cs[hi_i] = x.s; ci[hi_i] = x.item; }
+        }
+        __syncthreads();
+      }
+    }
+    Cand kth; kth.s = cs[B - 1]; kth.item = ci[B - 1];
+    Cand mylast; mylast.s = ts[TK - 1]; mylast.item = ti[TK - 1];
+    if (more && better(mylast, kth)) *overflow = 1;      // benign race: every writer stores 1
+    __syncthreads();
+    if (*overflow == 0) {
+      for (int j = tid; j < B; j += 256) { wscore[j] = cs[j]; widx[j] = ci[j]; }
+      need_rounds = false;
+    }
+  }
+  if (need_rounds) {   // block-uniform
   Cand mine; mine.s = ts[0]; mine.item = ti[0];
   for (int j = 0; j < B; ++j) {
     const Cand wb = wave_best(mine);
@@ -234,6 +333,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       if (owner) mine = best;
     }
   }
+  }
   __syncthreads();
 
   // ---- phase D: write the next beam state (new slot j <- winner j) ----
@@ -245,7 +345,12 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     int nlo = 0, nhi = 0;
     if (ok) {
       nlo = lb_q[item];
-      nhi = (c + 1 < V) ? lb_q[item + 1] : bhi[b];
+      if (bhi[b] - blo[b] <= 32) {   // narrow range (phase A enumerated it): the child ends where the token changes
+        nhi = nlo + 1;
+        while (nhi < bhi[b] && (int)a.codes[(size_t)nhi * Lc + t] == c) ++nhi;
+      } else {
+        nhi = (c + 1 < V) ? lb_q[item + 1] : bhi[b];
+      }
     }
     const int r = r0 + j;
     a.nxt.score[r] = wscore[j];
@@ -265,6 +370,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
 }
 
+constexpr int SEL_TK_HOST = 16;   // list length of the sorted path
 static size_t select_smem(int B, int V) {
   const size_t words = (size_t)B * V / 64;
   return (2 * (size_t)B + 4) * sizeof(double) + 2 * words * sizeof(unsigned long long) +
@@ -272,7 +378,10 @@ static size_t select_smem(int B, int V) {
 }
 
 hipError_t init_beam_kernel_attributes() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<8>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<SEL_TK_HOST>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -281,10 +390,18 @@ hipError_t launch_select(const SelectArgs& a_in, hipStream_t s) {
   if (a.V % 64 != 0) return hipErrorInvalidValue;
   size_t smem = select_smem(a.B, a.V);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  const size_t with_logits = smem + (size_t)a.B * a.V * sizeof(float);
-  a.lds_logits = with_logits <= 160 * 1024 ? 1 : 0;
-  if (a.lds_logits) smem = with_logits;
-  hipLaunchKernelGGL(select_kernel, dim3(a.Q), dim3(256), smem, s, a);
+  smem = (smem + 15) & ~(size_t)15;
+  const size_t sort_bytes = (size_t)256 * SEL_TK_HOST * (sizeof(double) + sizeof(int));
+  // measured: B = 100 -> rounds 8.8 ms per search vs sort 10.9 ms; B = 1000 -> rounds 87 ms vs sort 62 ms
+  a.sort_lds = (a.B > 256 && a.B <= 256 * SEL_TK_HOST && smem + sort_bytes <= 160 * 1024) ? 1 : 0;
+  a.sort_off = (int)smem;
+  const size_t logits_bytes = (size_t)a.B * a.V * sizeof(float);
+  // the logits strip sits right behind the fixed carve (slog = lsum + B in the kernel); the sort buffer follows it
+  a.lds_logits = (smem + logits_bytes + (a.sort_lds ? sort_bytes : 0) <= 160 * 1024) ? 1 : 0;
+  if (a.lds_logits) { smem = (smem + logits_bytes + 15) & ~(size_t)15; a.sort_off = (int)smem; }
+  if (a.sort_lds) smem += sort_bytes;
+  if (a.sort_lds) hipLaunchKernelGGL(select_kernel<SEL_TK_HOST>, dim3(a.Q), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(select_kernel<8>, dim3(a.Q), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 

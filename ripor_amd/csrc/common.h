@@ -161,6 +161,7 @@ struct SelectArgs {
   int Q, B, V, t;
   int log_softmax;
   int lds_logits;            // set by the launcher: stage the query's B*V logits in LDS
+  int sort_lds, sort_off;    // set by the launcher: B > 256 -> bitonic sort of the candidate lists; byte offset of its LDS buffer
   int shared0;               // step 0 computed once per query: logits is [Q, V], position-0 K/V live in slot 0
   // debug taps for step t (nullable)
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
