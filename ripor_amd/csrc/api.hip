@@ -188,13 +188,14 @@ struct Launcher {
 
 // One linear layer C = act(A @ W^T) (+ residual). A and W are given in both representations; the
 // ctx precision picks the exact fp32 MFMA kernel or the f16x2 split kernel.
-struct LinIn { const float* f; const __half* h; size_t ps; int ld; };       // activation [M, K]
+struct LinIn { const float* f; const __half* h; size_t ps; int ld; float scale = A_PLANE_SCALE; };  // activation [M, K]; scale of its planes
 struct LinW { const float* f; const __half* h; int N, K; };                  // weight [N, K] (+ planes, stride N*K)
 struct LinOut {                                                              // destination
   float* f[3]; int ldo[3]; int split_n;                                      //   fp32 (up to 3 column blocks)
   __half* h; size_t ps; int ldh;                                             //   or f16 planes (next GEMM's input)
   const float* resid; int relu;
   int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
+  float plane_scale;                                                         //   scale of the planes written to h (0 = 1)
 };
 
 LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
@@ -218,7 +219,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
     g.trace = L.c->trace_buf;
     g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
-    g.m_dev = m_dev;
+    g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
   } else {
     GemmArgs g{};
@@ -315,9 +316,9 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
     linear(Ln, {attn, attn_h, ps_i, inner}, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, out_f32(x, dm, dm, x), live, Ta);
     norm(m->enc_ln1[i], h, h_h);
     LinOut o = out_f32(ff, dff, dff, nullptr, 1);
-    if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
+    if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
     linear(Ln, {h, h_h, ps_d, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o, live, Ta);
-    linear(Ln, {ff, ff_h, ps_f, dff}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x), live, Ta);
+    linear(Ln, {ff, ff_h, ps_f, dff, FF_PLANE_SCALE}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x), live, Ta);
   }
   // final norm: fp32 copy always (taps / rpr_encode), planes for the cross-K/V GEMM in split mode
   Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
@@ -392,7 +393,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       return launch_rmsnorm(x, wgt, h2 ? nullptr : h, Rt, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
     });
   };
-  const LinIn in_h{h, h_h, ps_d, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff};
+  const LinIn in_h{h, h_h, ps_d, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
   for (int t = 0; t < L; ++t) {
     BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
     Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
@@ -429,7 +430,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, out_f32(x, dm, dm, x));
       norm(m->dec_ln2[i]);
       LinOut o = out_f32(ff, dff, dff, nullptr, 1);
-      if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; }
+      if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
       linear(Ln, in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o);
       linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, out_f32(x, dm, dm, x));
     }
@@ -444,7 +445,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
         g.A = h_h; g.a_ps = ps_d; g.lda = dm;
         g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
         g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
-        g.M = Rt; g.N = V; g.K = dm;
+        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * A_PLANE_SCALE);
         Ln.run(RPR_K_GEMM, 2.0 * Rt * (double)V * dm, 4.0 * ((double)Rt * dm + (double)V * dm + (double)Rt * V),
                [&] { return launch_gemm_h2(g, s); });
       } else {
@@ -581,7 +582,7 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
       if (err) return;
       void* p = nullptr;
       hipError_t e = hipMalloc(&p, n * 2 * sizeof(__half));
-      if (e == hipSuccess) { m->owned.push_back(p); e = launch_split_planes(wf, (__half*)p, n, n, nullptr); }
+      if (e == hipSuccess) { m->owned.push_back(p); e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE); }
       if (e != hipSuccess) { err = hip_fail(e, "weight split", __FILE__, __LINE__); return; }
       *outp = (__half*)p;
     };
@@ -794,9 +795,9 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
     RPR_HIP(At.alloc((size_t)M * K * 2 * sizeof(__half)));
     RPR_HIP(Wt.alloc((size_t)N * K * 2 * sizeof(__half)));
     RPR_HIP(launch_split_planes(A, At.as<__half>(), (size_t)M * K, (size_t)M * K, s));
-    RPR_HIP(launch_split_planes(W, Wt.as<__half>(), (size_t)N * K, (size_t)N * K, s));
+    RPR_HIP(launch_split_planes(W, Wt.as<__half>(), (size_t)N * K, (size_t)N * K, s, W_PLANE_SCALE));
   }
-  linear(Ln, {A, At.as<__half>(), (size_t)M * K, K}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
+  linear(Ln, {A, At.as<__half>(), (size_t)M * K, K, 1.0f}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
   if (At.p) RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
   if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x 18 slots (gemm_h2_pp_kernel<.., TRACE>)
     const char* we = getenv("RPR_GEMM_TRACE_W");

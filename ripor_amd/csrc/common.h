@@ -66,7 +66,18 @@ struct GemmH2Args {
   unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
   int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
   const int* m_dev;                        // nullable: live row count on the device (see GemmArgs)
+  // Power-of-two scaling of the f16 planes (exact; see W_/A_/FF_PLANE_SCALE below): the accumulators are multiplied
+  // by acc_scale = 1 / (scale of A's planes * scale of W's planes); planes written by the epilogue (out_h) are
+  // scaled by plane_scale. 0 means 1.
+  float acc_scale, plane_scale;
 };
+
+// f16 has 5 exponent bits: a plane element below 2^-14 is subnormal, so the lo plane of x = hi + lo (|lo| ~ 2^-11 |x|)
+// keeps its 11 bits only for |x| >= 0.125 — almost no T5 weight and few activations qualify. Planes therefore hold
+// scaled values (powers of two, exact): weights x 2^8 (22 bits down to |w| ~ 5e-4, range |w| < 255), activations
+// x 2^4 (|x| < 4094), and the FF intermediate relu(h Wi^T), the one tensor known to leave the f16 range on real T5
+// checkpoints, x 2^-4 (|x| < 1.05e6). The GEMM epilogue undoes the product of the two scales.
+constexpr float W_PLANE_SCALE = 256.0f, A_PLANE_SCALE = 16.0f, FF_PLANE_SCALE = 0.0625f;
 
 // offset (in floats) of output element (m, on) in output block oi; on..on+3 stay inside one head
 template <class G>
@@ -78,7 +89,8 @@ __device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, in
   return (size_t)m * ldo + on;
 }
 hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s);
-hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s);
+hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s,
+                               float scale = 1.0f);
 
 // ---- T5 elementwise / attention kernels -----------------------------------------------------------
 // post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5

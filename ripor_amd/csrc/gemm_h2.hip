@@ -1,15 +1,16 @@
 // Split-precision linear layer on the gfx950 matrix cores: C[M,N] = act(A[M,K] @ W[N,K]^T) (+ residual)
 // with fp32-equivalent accuracy from f16 MFMA.
 //
-// Every fp32 operand x is carried as two f16 planes  x = hi + lo,  hi = f16(x), lo = f16(x - hi)
-// (22 significant bits; |x - hi - lo| <= 2^-22 |x|, absolute floor 3e-8 from f16 subnormals), and a
-// product is evaluated as  hi*hi + hi*lo + lo*hi  with three v_mfma_f32_32x32x16_f16 accumulating in
-// fp32 (the dropped lo*lo term is <= 2^-22 |xy|). Measured on the golden models (tools/ +
-// DESIGN.md §5): logits differ from the exact-fp32 path by <= 1.1e-4 (mean 1.8e-5), i.e. ~2.5x the
-// difference between two fp32 summation orders, beam scores by <= 1e-5 — inside the 1e-4 parity bar —
-// while the matrix pipe runs at the f16 rate: 3 MFMAs of 32 cycles instead of 8 fp32 MFMAs of 64
-// cycles per 32x32x16 block = 5.3x the fp32-MFMA roof. The exact fp32 kernel (gemm_f32.hip) stays
-// selectable (RPR_PRECISION=f32) as the numerical reference.
+// Every fp32 operand x is carried as two f16 planes  s*x = hi + lo,  hi = f16(s*x), lo = f16(s*x - hi), with a
+// power-of-two scale s per tensor class (weights 2^8, activations 2^4, FF intermediate 2^-4; common.h) that keeps
+// lo out of the f16 subnormals and the FF intermediate inside the f16 range: 22 significant bits,
+// |s*x - hi - lo| <= 2^-22 |s*x|. A product is evaluated as  hi*hi + hi*lo + lo*hi  with three
+// v_mfma_f32_32x32x16_f16 accumulating in fp32 (the dropped lo*lo term is <= 2^-22 |xy|); the epilogue multiplies
+// the accumulators by 1/(s_A s_W) (exact). Measured on the t5-base golden model (tools/precision_probe.py): logits
+// differ from the exact-fp32 path by <= 7.4e-5 (mean 1.2e-5; two fp32 summation orders differ by <= 4e-5), beam
+// scores by <= 5e-6 — inside the 1e-4 parity bar — while the matrix pipe runs at the f16 rate: 3 MFMAs of 32
+// cycles instead of 8 fp32 MFMAs of 64 cycles per 32x32x16 block = 5.3x the fp32-MFMA roof. The exact fp32 kernel
+// (gemm_f32.hip) stays selectable (RPR_PRECISION=f32) as the numerical reference.
 //
 // Planes are produced where the data is written (RMSNorm, attention and ReLU epilogues emit hi/lo
 // planes; weights are split once at rpr_load_model), so this kernel only moves 16-bit data:
@@ -234,12 +235,12 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (FULL || m < g.M) {
-          float v = acc[i][j][r];
+          float v = acc[i][j][r] * g.acc_scale;
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.resid) v = res[r] + v;
           if (g.out_h) {
             __half hi, lo;
-            split_f16(v, hi, lo);
+            split_f16(v * g.plane_scale, hi, lo);
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
           } else {
@@ -299,12 +300,14 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     for (int k = 0; k < NK; ++k) {
       const int rl = k * RPI + rrow, m = mrow0 + rl;
       float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+      v.x *= g.acc_scale; v.y *= g.acc_scale; v.z *= g.acc_scale; v.w *= g.acc_scale;
       if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
       if (ncol_ok && (FULL || m < g.M)) {
         if (g.out_h) {
           __half h[4], l[4];
-          split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+          const float ps = g.plane_scale;
+          split_f16(v.x * ps, h[0], l[0]); split_f16(v.y * ps, h[1], l[1]); split_f16(v.z * ps, h[2], l[2]); split_f16(v.w * ps, h[3], l[3]);
           *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
           *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
         } else {
@@ -523,7 +526,10 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s) {
+hipError_t launch_gemm_h2(const GemmH2Args& a_in, hipStream_t s) {
+  GemmH2Args a = a_in;
+  if (a.acc_scale == 0.f) a.acc_scale = 1.f;      // zero-initialised args mean "no scaling"
+  if (a.plane_scale == 0.f) a.plane_scale = 1.f;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
@@ -536,20 +542,22 @@ hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s) {
 
 // fp32 [rows, cols] -> two f16 planes [2][rows][cols] (weights at load time, generic activations)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __half* __restrict__ out,
-                                                            size_t n, size_t plane_stride) {
+                                                            size_t n, size_t plane_stride, float scale) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const float4 v = *reinterpret_cast<const float4*>(x + i);
   __half h[4], l[4];
-  split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+  split_f16(v.x * scale, h[0], l[0]); split_f16(v.y * scale, h[1], l[1]);
+  split_f16(v.z * scale, h[2], l[2]); split_f16(v.w * scale, h[3], l[3]);
   *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<uint2*>(h);
   *reinterpret_cast<uint2*>(out + plane_stride + i) = *reinterpret_cast<uint2*>(l);
 }
 
-hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s) {
+hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s, float scale) {
   if (n == 0) return hipSuccess;
   if (n & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n, plane_stride);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n, plane_stride,
+                     scale);
   return hipGetLastError();
 }
 

@@ -15,8 +15,9 @@
 namespace rpr {
 
 __device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t idx, float4 v) {
-  __half h[4], l[4];
-  split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+  __half h[4], l[4];   // activation planes hold x * A_PLANE_SCALE (common.h)
+  split_f16(v.x * A_PLANE_SCALE, h[0], l[0]); split_f16(v.y * A_PLANE_SCALE, h[1], l[1]);
+  split_f16(v.z * A_PLANE_SCALE, h[2], l[2]); split_f16(v.w * A_PLANE_SCALE, h[3], l[3]);
   *reinterpret_cast<uint2*>(out_h + idx) = *reinterpret_cast<uint2*>(h);
   *reinterpret_cast<uint2*>(out_h + o_ps + idx) = *reinterpret_cast<uint2*>(l);
 }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     const size_t oidx = (row0 + i) * inner + h * DKV + lane;
     if (a.out_h) {
       __half hi, lo;
-      split_f16(o, hi, lo);
+      split_f16(o * A_PLANE_SCALE, hi, lo);
       a.out_h[oidx] = hi;
       a.out_h[a.o_ps + oidx] = lo;
     } else {

@@ -189,3 +189,38 @@ def test_beam_1000_like_the_reference_retrieval_script(setup):
         assert np.array_equal(got_tok[q][clear], exp_tok[q][clear])
     leaf = (res.row_hi > res.row_lo).cpu().numpy()
     assert leaf.all(), "with 6000 docs every one of the 1000 returned smtids must be a real doc"
+
+
+def test_ff_intermediate_beyond_f16_range(setup):
+    """Real T5 checkpoints are known to overflow fp16 in the FF intermediate relu(h Wi^T). The split-precision GEMM
+    carries that tensor as f16 planes scaled by 2^-4 (exact), i.e. up to 1.05e6. A model whose pre-FF layer-norm
+    weights are scaled by 256 and wi by 128 (FF activations ~1e5, and a residual stream ~1e4 that the following
+    norms bring back) must still match the fp32 oracle."""
+    from oracle import beam_ref, t5_ref
+    E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
+    L, V, N, B, Q = 4, 256, 800, 4, 3
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512)
+    sd = dict(synth.make_state_dict(dims, seed=71))
+    for k in list(sd):
+        enc_ff_ln = k.startswith("encoder.block.") and k.endswith("layer.1.layer_norm.weight")
+        dec_ff_ln = k.startswith("decoder.block.") and k.endswith("layer.2.layer_norm.weight")
+        if k.endswith("DenseReluDense.wi.weight"):
+            sd[k] = (sd[k] * 128.0).astype(np.float32)
+        elif enc_ff_ln or dec_ff_ln:
+            sd[k] = (sd[k] * 256.0).astype(np.float32)
+    codes = synth.make_codes(N, L, V, seed=71)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=72, max_len=10)
+    ref = t5_ref.T5RefCached(sd, dims)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    seqs, sc = beam_ref.beam_search_ref(ref, pm, ids, mask, B, L, use_kv_cache=True)
+    # the premise of the test: the encoder's FF intermediate really leaves the f16 range
+    h = torch.from_numpy(sd["shared.weight"])[torch.from_numpy(ids[0])]
+    hn = t5_ref.rmsnorm(h, torch.from_numpy(sd["encoder.block.0.layer.1.layer_norm.weight"]), 1e-6)
+    big = float((hn @ torch.from_numpy(sd["encoder.block.0.layer.1.DenseReluDense.wi.weight"]).T).abs().max())
+    assert 65504.0 < big < 5e5, big
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:])
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
