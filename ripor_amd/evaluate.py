@@ -209,6 +209,29 @@ def query_batches(collection: QueryCollection, tokenizer, indices: Sequence[int]
                "id": torch.tensor([int(collection.ids[i]) for i in sel], dtype=torch.long)}
 
 
+def search_batch_size(cfg, batch_size: int, topk: int, max_new_token: int, flag: int = -1, device=None) -> int:
+    """Queries per ``rpr_search`` call for the CLI tasks. The reference scripts pass ``--batch_size=1`` (retrieval,
+    topk 1000) or 4 (rank-data generation, topk 100) because their decoding loop is host-bound; this path is built
+    for many queries in flight and its results do not depend on how queries are batched (tests/test_gpu_fullsize.py),
+    so by default (``--search_batch_size=-1``) the tasks regroup the query stream into the largest batch whose
+    workspace (dominated by the self-attention KV cache, 2*Ndec*L*B*inner*4 bytes per query) fits ~60 % of the free
+    HBM, capped at 2048. ``--search_batch_size=0`` keeps ``--batch_size``; a positive value is used as given."""
+    if flag == 0:
+        return batch_size
+    if flag > 0:
+        return flag
+    nd, inner = cfg.num_decoder_layers, cfg.num_heads * cfg.d_kv
+    per_query = 2 * nd * max_new_token * topk * inner * 4                       # K and V cache
+    per_query += topk * (6 * cfg.d_model + 4 * inner + 3 * cfg.d_ff) * 4          # activations + f16 planes of a step
+    per_query += topk * max(cfg.decoder_vocab_sizes) * 8 + 64 * 1024            # logits, trie bounds, encoder side
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+    except Exception:
+        free = 64 << 30
+    auto = int(0.6 * free // per_query)
+    return max(batch_size, min(2048, max(1, auto)))
+
+
 def ddp_setup():
     """reference evaluate.py:181-182; RCCL is torch's "nccl" backend on ROCm."""
     import torch.distributed as dist
@@ -251,7 +274,10 @@ def t5seq_aq_retrieve_docids(args):
         out_dir = os.path.join(args.out_dir, get_dataset_name(data_dir))
         print("out_dir: ", out_dir)
         os.makedirs(out_dir, exist_ok=True)  # every rank: removes the reference's mkdir race
-        loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), args.batch_size, 256)
+        qbs = search_batch_size(model.config, args.batch_size, args.topk, max_new_token, args.search_batch_size, local_rank)
+        if rank == 0:
+            print(f"queries per search call: {qbs} (--batch_size={args.batch_size})")
+        loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), qbs, 256)
         constrained_decode_doc(model.base_model, loader, processor, table, max_new_token, device=local_rank,
                                out_dir=out_dir, local_rank=local_rank, topk=args.topk,
                                apply_log_softmax_for_scores=args.apply_log_softmax_for_scores)
@@ -303,7 +329,10 @@ def t5seq_aq_get_qid_to_smtid_rankdata(args):
     coll = QueryCollection(args.train_query_dir)
     model.to(local_rank)
     model.base_model.config.decoding = True
-    loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), args.batch_size, 256)
+    qbs = search_batch_size(model.config, args.batch_size, args.topk, args.max_new_token, args.search_batch_size, local_rank)
+    if rank == 0:
+        print(f"queries per search call: {qbs} (--batch_size={args.batch_size})")
+    loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), qbs, 256)
     constrained_decode_smtid(model.base_model, loader, processor, table, args.max_new_token, device=local_rank,
                              out_dir=args.out_dir, local_rank=local_rank, topk=args.topk,
                              apply_log_softmax_for_scores=args.apply_log_softmax_for_scores)
@@ -383,6 +412,8 @@ def get_args(argv=None):
     ap.add_argument("--eval_qrel_path", nargs="+", default=[])
     ap.add_argument("--eval_metric", nargs="+", default=[["mrr_10", "recall"]])
     ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--search_batch_size", type=int, default=-1,
+                    help="queries per search call: -1 = as many as fit the HBM (>= --batch_size), 0 = --batch_size")
     ap.add_argument("--max_new_token_for_docid", type=int, default=32)
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)

@@ -224,3 +224,20 @@ def test_constrained_decode_smtid_and_merge(monkeypatch, tmp_path):
     assert os.listdir(tmp_path) == ["qid_smtid_rankdata.json"]
     c = EV.constrained_decode(None, [batch], FakeProc(), None, L, "cpu", str(tmp_path), 0, topk=B)
     assert c == {5: {"1_2": 2.0}, 6: {"4_4": 0.5, "1_3": 0.25}}
+
+
+def test_search_batch_size_policy(monkeypatch):
+    """CLI tasks regroup the query stream: never below --batch_size, capped at 2048, sized by the KV cache."""
+    import torch
+    from ripor_amd import evaluate as ev
+    from ripor_amd.modeling.t5_generative_retriever import T5forDocIDConfig
+    cfg = T5forDocIDConfig(decoder_vocab_sizes=[256] * 32)           # t5-base dims
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (250 << 30, 288 << 30))
+    assert ev.search_batch_size(cfg, 1, 10, 32, -1) == 2048           # beam 10: capped
+    b100 = ev.search_batch_size(cfg, 4, 100, 32, -1)
+    b1000 = ev.search_batch_size(cfg, 1, 1000, 32, -1)
+    assert 200 <= b100 <= 1024 and 30 <= b1000 <= 80, (b100, b1000)   # 2.36 GB of KV cache per query at beam 1000
+    assert ev.search_batch_size(cfg, 7, 1000, 32, 0) == 7             # 0 = keep --batch_size
+    assert ev.search_batch_size(cfg, 7, 1000, 32, 16) == 16           # explicit
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (1 << 30, 288 << 30))
+    assert ev.search_batch_size(cfg, 5, 1000, 32, -1) == 5            # never below --batch_size
