@@ -224,3 +224,23 @@ def test_ff_intermediate_beyond_f16_range(setup):
     torch.cuda.synchronize()
     assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:])
     np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
+
+
+def test_long_docids_beyond_the_register_attention_path(setup):
+    """L = 40 positions: self-attention depths 33..36 run the largest register instantiation and 37..40 the generic
+    LDS kernel (the reference's docids have 32 or 16 positions; the library accepts up to 64)."""
+    from oracle import beam_ref, t5_ref
+    E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
+    L, V, N, B, Q = 40, 256, 300, 3, 2
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512)
+    sd = synth.make_state_dict(dims, seed=81)
+    codes = synth.make_codes(N, L, V, seed=81)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=82, max_len=9)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:])
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
