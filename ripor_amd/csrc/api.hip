@@ -512,12 +512,13 @@ void rpr_free_ctx(rpr_ctx* c) {
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   Workspace& w = c->ws;
-  DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
+  DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.offs, &w.row_src, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
                    &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
                    &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
                    &w.o_scores, &w.o_lo, &w.o_hi, &w.eh_h, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.h_h, &w.attn_h,
                    &w.ff_h};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  if (c->trace_buf) (void)hipFree(c->trace_buf);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
