@@ -43,8 +43,12 @@ constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 // unpadded (64 B) and the 16-byte segments of a row are XOR-swizzled with (row>>2)&3 on the SOURCE
 // address and again on the fragment read: the 16-lane groups of ds_read_b128 then hit 16 distinct
 // 4-bank slots.
-template <int BM, int BN, int WM, int WN, bool FULL, bool ILV = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
+// STAGES = LDS buffers. 2: one K-tile of prefetch, several blocks per CU hide the rest (large launches).
+// 4: launches with fewer tiles than CUs (small in-flight batches) — one block per CU walks its whole K alone, and
+// with one tile of prefetch every K-tile paid a full L2/HBM latency (~1.2 us x 24 K-tiles per GEMM); three tiles
+// in flight and a counted s_waitcnt make the walk bandwidth-bound instead.
+template <int BM, int BN, int WM, int WN, bool FULL, int STAGES = 2>
+__global__ __launch_bounds__(64 * WM * WN, STAGES > 2 ? 1 : (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
 void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;                    // waves per block
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA 32x32 tiles per wave
@@ -52,7 +56,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   constexpr int NINST = ROWS / 16;               // DMA wave-instructions per K-tile (16 rows each)
   constexpr int PER_WAVE = NINST / NW;
   static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
-  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
+  __shared__ __attribute__((aligned(16))) __half smem[STAGES * ROWS * HBK];
 
   int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -140,77 +144,37 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     }
   };
 
-  // fused form of {stage(next); compute(cur)}: the DMA pieces of the next tile are spread between
-  // the product groups of the current tile's MFMAs, so a wave's DMA issue stalls overlap its own
-  // in-flight MFMAs and the co-resident wave's (both waves of a SIMD run this same stream)
-  auto compute_and_stage = [&](int buf, int nbuf, int k0) {
-    const __half* base = smem + (size_t)buf * ROWS * HBK;
-    constexpr int SLOTS = 3 * (HBK / 16);
-    int piece = 0;
-    auto dma_some = [&](int slot) {
-      // distribute PER_WAVE pieces over SLOTS slots
-      const int upto = (PER_WAVE * (slot + 1) + SLOTS - 1) / SLOTS;
-#pragma unroll
-      for (int j = 0; j < PER_WAVE; ++j) {
-        if (j >= piece && j < upto) {
-          __half* dst = smem + (size_t)nbuf * ROWS * HBK + 16 * (wave + NW * j) * HBK;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-      }
-      piece = upto;
-    };
-#pragma unroll
-    for (int c = 0; c < HBK / 16; ++c) {
-      const int so = ((2 * c + hf) ^ sw) * 8;
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(base + (a_row + i * 32) * HBK + so);
-        al[i] = *reinterpret_cast<const f16x8*>(base + (BM + a_row + i * 32) * HBK + so);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(base + (w_row + j * 32) * HBK + so);
-        bl[j] = *reinterpret_cast<const f16x8*>(base + (BN + w_row + j * 32) * HBK + so);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      dma_some(3 * c + 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      dma_some(3 * c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      dma_some(3 * c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
   const int nkt = g.K / HBK;
-  stage(0, 0);
-  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
-    if (ILV) {
-      compute_and_stage(kt & 1, (kt + 1) & 1, (kt + 1) * HBK);
-    } else {
+  if (STAGES == 2) {
+    stage(0, 0);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
       stage((kt + 1) & 1, (kt + 1) * HBK);
       compute(kt & 1);
+      __syncthreads();
     }
-    __syncthreads();
+    compute((nkt - 1) & 1);
+  } else {
+    constexpr int AHEAD = STAGES - 1;                          // tiles requested before the first compute
+    static_assert(PER_WAVE * (AHEAD - 1) <= 63, "vmcnt is a 6-bit counter");
+    // vmcnt(N) immediate: bits [3:0] = N & 15, [15:14] = N >> 4; expcnt/lgkmcnt fields left at "no wait"
+    constexpr int KEEP = PER_WAVE * (AHEAD - 1);
+    constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | 0x0f70;
+    constexpr int WAIT_NONE = 0x0f70;
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+      if (t < nkt) stage(t, t * HBK);
+    for (int kt = 0; kt < nkt; ++kt) {
+      // this wave's pieces of tile kt have landed once at most the pieces of the AHEAD-1 younger tiles are pending
+      // (fewer tiles are in flight at the tail: wait for everything there)
+      if (kt + AHEAD - 1 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_KEEP); else __builtin_amdgcn_s_waitcnt(WAIT_NONE);
+      __builtin_amdgcn_s_barrier();                            // everyone's pieces landed; compute(kt-1) is over everywhere
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + AHEAD < nkt) stage((kt + AHEAD) % STAGES, (kt + AHEAD) * HBK);   // refills the buffer of tile kt-1
+      compute(kt % STAGES);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  compute((nkt - 1) & 1);
 
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
@@ -500,14 +464,128 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn);
 }
 
-template <int BM, int BN>
+// ---- skinny variant: M <= 400 rows (one to a few dozen queries in flight) ---------------------------------------
+// Such a launch is a weight stream: 2.4 MB of W for 10 live rows. The tile kernels give it N/64..N/32 blocks
+// that each walk all of K through ONE LDS-DMA stream (~25 GB/s per CU): 18-29 us per launch, 2385 launches per
+// search. Here a block is a 32x32 output tile whose four waves split K between them (wave w takes K-tiles
+// w, w+4, ...), each with a private 4-stage LDS ring fed by its own LDS-DMA stream and no block barrier in the
+// loop (a wave only reads what it loaded itself: s_waitcnt vmcnt is the whole synchronisation). The four partial
+// accumulators are added in the fixed order 0..3 through LDS and wave 0 runs the epilogue — deterministic.
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  constexpr int BM = 32, BN = 32, ST = 4, ROWS = 2 * (BM + BN), PIECES = ROWS / 16;   // 8 KB per stage, 8 pieces
+  __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];             // 128 KB
+  const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
+
+  const __half* src[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    const int lrow = 16 * j + (lane >> 2);
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const __half* base;
+    int trow, limit;
+    size_t ld;
+    if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
+    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    if (!FULL && trow >= limit) trow = limit - 1;
+    src[j] = base + (size_t)trow * ld + seg * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)(wsm + (size_t)buf * ROWS * HBK + 16 * j * HBK),
+                                       16, 0, 0);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
+  auto compute = [&](int buf) {
+    const __half* base = wsm + (size_t)buf * ROWS * HBK;
+#pragma unroll
+    for (int c = 0; c < HBK / 16; ++c) {
+      const int so = ((2 * c + hf) ^ sw) * 8;
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(base + frow * HBK + so);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(base + (BM + frow) * HBK + so);
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(base + (2 * BM + frow) * HBK + so);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(base + (2 * BM + BN + frow) * HBK + so);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    }
+  };
+  const int nkt = g.K / HBK;
+  const int mine = wave < nkt ? (nkt - wave + 3) / 4 : 0;         // K-tiles wave, wave + 4, ...
+  constexpr int KEEP = PIECES * (ST - 2);                         // 16 pieces of the two younger tiles may be pending
+  constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | 0x0f70, WAIT_NONE = 0x0f70;
+#pragma unroll
+  for (int t = 0; t < ST - 1; ++t)
+    if (t < mine) stage(t, (wave + 4 * t) * HBK);
+  for (int i = 0; i < mine; ++i) {
+    if (i + ST - 2 < mine) __builtin_amdgcn_s_waitcnt(WAIT_KEEP); else __builtin_amdgcn_s_waitcnt(WAIT_NONE);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + ST - 1 < mine) stage((i + ST - 1) % ST, (wave + 4 * (i + ST - 1)) * HBK);   // buffer of tile i-1: its reads are done
+    compute(i % ST);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // reduce the four waves' partial tiles in fixed order through LDS (the operand rings are idle now)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    acc[r] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+             red[(3 * 16 + r) * 64 + lane];
+  const int n = bn + (lane & 31), rsub = 4 * (lane >> 5);
+  if (!FULL && n >= g.N) return;
+  const int oi = n / g.split_n, on = n - oi * g.split_n;
+  float* outp = g.out[oi];
+  const int ldo = g.ldo[oi];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
+    if (!FULL && m >= g.M) continue;
+    float v = acc[r] * g.acc_scale;
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.resid) v = g.resid[(size_t)m * g.ldr + n] + v;
+    if (g.out_h) {
+      __half hi, lo;
+      split_f16(v * g.plane_scale, hi, lo);
+      g.out_h[(size_t)m * g.ldoh + n] = hi;
+      g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+    } else {
+      outp[out_off(g, oi, m, ldo, on)] = v;
+    }
+  }
+}
+
+template <int BM, int BN, int WM = 2, int WN = 2>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const bool full = (a.M % BM == 0) && (a.N % BN == 0);
+  const dim3 grid(tiles_m * tiles_n), blk(64 * WM * WN);
+  static const int deep_max = [] { const char* e = getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
+  if ((tiles_m * tiles_n <= deep_max || BM < 128) && !a.m_dev) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
+    if (full)
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 4>), grid, blk, 0, s, a, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false, 4>), grid, blk, 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (full)
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true>), grid, blk, 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, 2, 2, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false>), grid, blk, 0, s, a, tiles_m, tiles_n);
   return hipGetLastError();
 }
 
@@ -535,6 +613,16 @@ hipError_t launch_gemm_h2(const GemmH2Args& a_in, hipStream_t s) {
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (force == 256 || (force == 0 && t256 >= 112)) return launch_256(a, s);
+  // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
+  // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
+  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 400; }();   // max rows (measured: 320 rows 53 vs 76 ms per search, 640 rows 86 vs 77)
+  if (force == 0 && !a.m_dev && a.M <= skinny) {
+    const int tiles_m = (a.M + 31) / 32, tiles_n = (a.N + 31) / 32;
+    const bool full = (a.M % 32 == 0) && (a.N % 32 == 0);
+    if (full) hipLaunchKernelGGL((gemm_h2_skinny_kernel<true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_h2_skinny_kernel<false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool narrow = force ? (force == 64) : (t128 < 512);
   return narrow ? launch_cfg<128, 64>(a, s) : launch_cfg<128, 128>(a, s);
