@@ -276,8 +276,27 @@ def main():
             out["kernel_breakdown_ms"]["sum"] = round(tot, 3)
             sa = stats["dec_self_attn"]
             if sa["total_ms"] > 0:
-                out["self_attn_hbm"] = {"achieved_GBs": sa["bytes"] / (sa["total_ms"] * 1e-3) / 1e9,
-                                        "frac_of_8TBs": sa["bytes"] / (sa["total_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)}
+                # second roofline object: the HBM-bound kernel of the step (same accounting as `roofline`:
+                # algorithmic bytes / hipEvent time; traffic from the PMC passes summed over the depth instantiations)
+                ach = sa["bytes"] / (sa["total_ms"] * 1e-3) / 1e9
+                sa_traffic = None
+                try:
+                    pmc = json.load(open(os.path.join(REPO, "profiles", "latest_hbm_pmc.json")))
+                    ks = [k for k in pmc["FETCH_SIZE"] if "dec_self_attn_fast_kernel" in k]
+                    tot_b = sum((2.0 * pmc["FETCH_SIZE"][k]["sum"] + pmc["WRITE_SIZE"][k]["sum"]) * 1024.0 for k in ks)
+                    n = sum(pmc["FETCH_SIZE"][k]["launches"] for k in ks)
+                    sa_traffic = tot_b / n if n else None
+                except Exception:
+                    pass
+                out["roofline_hbm"] = {"kernel": "rpr::dec_self_attn_fast_kernel<2|4|6|8>", "bound": "hbm", "achieved": ach,
+                                       "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": ach / (PEAK_HBM_TBS * 1e3),
+                                       "traffic": sa_traffic,
+                                       "algorithmic_bytes_per_launch": sa["bytes"] / max(1, sa["launches"]),
+                                       "avg_launch_us": sa["total_ms"] * 1e3 / max(1, sa["launches"]),
+                                       "launches_per_step": sa["launches"],
+                                       "note": "K/V rows of every beam's ancestry, read once per step; ~6.3 TB/s is what "
+                                               "streaming reads reach on this part (MI355X_MICROARCH.md)"}
+                out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd, dims, B, L)
