@@ -12,6 +12,8 @@ tot_t = tot_f = 0.0
 for N, K, resid in shapes:
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda") * K ** -0.5
+    if os.environ.get("GEMM_ZERO"):   # data-dependent power: all-zero operands toggle no multiplier bits
+        A.zero_(); W.zero_()
     R = torch.randn(M, N, device="cuda") if resid else None
     for _ in range(3):
         ctx.linear(A, W, R)
