@@ -725,6 +725,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
   RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
   RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
+  RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int e = alloc_workspace(c, m, Q, Lq, B, L);

@@ -377,6 +377,8 @@ static size_t select_smem(int B, int V) {
          (3 * (size_t)B + 8) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
 }
 
+bool select_fits(int B, int V) { return V % 64 == 0 && select_smem(B, V) <= 160 * 1024; }
+
 hipError_t init_beam_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

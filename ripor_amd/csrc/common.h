@@ -179,6 +179,7 @@ struct SelectArgs {
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
+bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
 
 struct FinalizeArgs {
   BeamState st;

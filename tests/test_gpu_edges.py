@@ -103,6 +103,13 @@ def test_argument_errors_cross_the_abi_as_exceptions(setup):
         setup["hip"](big, big, 2, 2)
 
 
+def test_beam_too_large_is_refused_with_a_message(setup):
+    E = setup["E"]
+    ids = np.array([[5, 6, 1]], dtype=np.int64)
+    with pytest.raises(E.RiporHipError, match="too large for the select kernel"):
+        setup["hip"](ids, np.ones_like(ids), 4000, setup["L"])
+
+
 def test_scaleup_output_hidden_and_1024_codebook(setup):
     """config.scaleup_output_hidden (reference t5_generative_retriever.py:427-428) and the 16 x 1024 code
     layout (full_16_1024_scripts): a second model built here, compared with the oracle."""
