@@ -39,12 +39,37 @@ class DocidTable:
         self.docids = list(docids)
 
 
+def rankdata_from_ranges(qids, row_lo, row_hi, scores, perm, docids, max_new_token, apply_log_softmax_for_scores=False,
+                         into: Optional[Dict[int, Dict[str, float]]] = None) -> Dict[int, Dict[str, float]]:
+    """``{qid: {docid: score}}`` from sorted-row ranges (docids of a returned smtid = perm[lo:hi]); scores follow the
+    reference (evaluate.py:118-127: sequences_scores * max_new_token unless log-softmax mode). Inputs are nested
+    lists / arrays ``[Q]``, ``[Q, B]``."""
+    out = {} if into is None else into
+    for qid, los, his, rel_scores in zip(qids, row_lo, row_hi, scores):
+        cur = out[int(qid)] = {}
+        for l, h, rel_score in zip(los, his, rel_scores):
+            if h <= l:
+                print("smtid not in smtid_to_docid")
+                continue
+            for row in perm[l:h]:
+                cur[docids[int(row)]] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+    return out
+
+
 def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_to_docids, max_new_token, device,
-                           out_dir, local_rank, topk=100, apply_log_softmax_for_scores=False, write=True):
+                           out_dir, local_rank, topk=100, apply_log_softmax_for_scores=False, write=True, gather=False):
     """reference evaluate.py:87-132. ``smtid_to_docids``: the reference's dict
-    ``{"c1_.._cL": [docids]}`` or a :class:`DocidTable` (range lookup, no strings)."""
+    ``{"c1_.._cL": [docids]}`` or a :class:`DocidTable` (range lookup, no strings).
+
+    ``gather=True`` (multi-process runs with a DocidTable): instead of one ``run_{rank}.json`` per rank, the ranks'
+    row ranges and scores are exchanged with one RCCL all_gather (ripor_amd/dist_gather.py) and rank 0 writes the
+    merged ``run.json`` itself — the ``..._2`` merge step then finds it complete (:func:`merge_runs`)."""
+    import torch.distributed as dist
+    from .dist_gather import all_gather_results
     qid_to_rankdata: Dict[int, Dict[str, float]] = {}
     use_ranges = isinstance(smtid_to_docids, DocidTable)
+    gather = bool(gather) and use_ranges and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    kept = []   # per batch (qids, row_lo, row_hi, scores) on the device, for the gather
     for batch in dataloader:
         with torch.no_grad():
             inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
@@ -54,20 +79,16 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                 return_dict=True, return_dict_in_generate=True, num_beams=topk, num_return_sequences=topk,
                 apply_log_softmax_for_scores=apply_log_softmax_for_scores)
         batch_qids = batch["id"].cpu().tolist()
+        if gather:
+            kept.append((batch["id"].to(outputs.row_lo.device), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk),
+                         outputs.sequences_scores.view(-1, topk)))
+            continue
         relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
         if use_ranges:
-            lo = outputs.row_lo.view(-1, topk).cpu().tolist()
-            hi = outputs.row_hi.view(-1, topk).cpu().tolist()
             perm = prefix_constrain_processor.trie(device).perm
-            for qid, los, his, rel_scores in zip(batch_qids, lo, hi, relevant_scores):
-                cur = qid_to_rankdata[qid] = {}
-                for l, h, rel_score in zip(los, his, rel_scores):
-                    if h <= l:
-                        print("smtid not in smtid_to_docid")
-                        continue
-                    for row in perm[l:h]:
-                        docid = smtid_to_docids.docids[int(row)]
-                        cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+            rankdata_from_ranges(batch_qids, outputs.row_lo.view(-1, topk).cpu().tolist(),
+                                 outputs.row_hi.view(-1, topk).cpu().tolist(), relevant_scores, perm,
+                                 smtid_to_docids.docids, max_new_token, apply_log_softmax_for_scores, into=qid_to_rankdata)
         else:
             str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
             for qid, ranked_smtids, rel_scores in zip(batch_qids, str_smtids, relevant_scores):
@@ -78,6 +99,19 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                     else:
                         for docid in smtid_to_docids[smtid]:
                             cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+    if gather:
+        qids = torch.cat([k[0] for k in kept]); lo = torch.cat([k[1] for k in kept])
+        hi = torch.cat([k[2] for k in kept]); sc = torch.cat([k[3] for k in kept])
+        qids, _, sc, lo, hi = all_gather_results(qids, lo, sc, lo, hi)       # equal shard sizes (wrap-around padding)
+        if dist.get_rank() == 0:
+            perm = prefix_constrain_processor.trie(device).perm
+            rankdata_from_ranges(qids.cpu().tolist(), lo.cpu().tolist(), hi.cpu().tolist(), sc.cpu().tolist(), perm,
+                                 smtid_to_docids.docids, max_new_token, apply_log_softmax_for_scores, into=qid_to_rankdata)
+            if write:
+                with open(os.path.join(out_dir, "run.json"), "w") as fout:
+                    json.dump(qid_to_rankdata, fout)
+        dist.barrier()
+        return qid_to_rankdata
     if write:
         with open(os.path.join(out_dir, f"run_{local_rank}.json"), "w") as fout:
             json.dump(qid_to_rankdata, fout)
@@ -280,12 +314,20 @@ def t5seq_aq_retrieve_docids(args):
         loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), qbs, 256)
         constrained_decode_doc(model.base_model, loader, processor, table, max_new_token, device=local_rank,
                                out_dir=out_dir, local_rank=local_rank, topk=args.topk,
-                               apply_log_softmax_for_scores=args.apply_log_softmax_for_scores)
+                               apply_log_softmax_for_scores=args.apply_log_softmax_for_scores,
+                               gather=bool(args.gather_results))
 
 
 def merge_runs(out_dir: str, expected_files: Optional[int] = None) -> Dict[str, Dict[str, float]]:
     """reference evaluate.py:496-524: merge ``run_*.json`` into ``run.json`` and delete the parts."""
     run_path = os.path.join(out_dir, "run.json")
+    parts = [p for p in os.listdir(out_dir) if "run" in p and p != "run.json"]
+    if os.path.exists(run_path) and not parts:
+        # written by rank 0 after the RCCL gather (constrained_decode_doc(gather=True)): already complete
+        with open(run_path) as fin:
+            merged = json.load(fin)
+        print("run.json is already merged (gathered over RCCL): {} queries".format(len(merged)))
+        return merged
     if os.path.exists(run_path):
         print("old run.json exisit.")
         os.remove(run_path)
@@ -412,6 +454,8 @@ def get_args(argv=None):
     ap.add_argument("--eval_qrel_path", nargs="+", default=[])
     ap.add_argument("--eval_metric", nargs="+", default=[["mrr_10", "recall"]])
     ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--gather_results", type=int, default=1,
+                    help="multi-process runs: 1 = one RCCL all_gather, rank 0 writes run.json; 0 = run_{rank}.json files")
     ap.add_argument("--search_batch_size", type=int, default=-1,
                     help="queries per search call: -1 = as many as fit the HBM (>= --batch_size), 0 = --batch_size")
     ap.add_argument("--max_new_token_for_docid", type=int, default=32)
