@@ -97,11 +97,19 @@ def cpu_baseline(sd, dims, B, L, n_queries=12, trie_docs=10_000):
     beam_ref.beam_search_ref(model, pm, ids[1:], mask[1:], B, L)
     dt = time.time() - t0
     log(f"[bench] cpu_baseline: {n_queries} queries in {dt:.1f}s on {best_t} threads")
+    # the reference retrieval script runs batch_size=1 (full_evaluate_t5seq_aq_encoder.sh:197): three single-query calls
+    t1 = time.time()
+    for i in range(3):
+        beam_ref.beam_search_ref(model, pm, ids[1 + i:2 + i], mask[1 + i:2 + i], B, L)
+    dt1 = (time.time() - t1) / 3
+    log(f"[bench] cpu_baseline at batch 1: {dt1:.2f}s per query")
     return {"value": n_queries / dt, "unit": "queries/s", "cores": best_t, "kind": "port",
+            "value_batch1": 1.0 / dt1,
             "sample": f"{n_queries} queries in one batch, t5-base dims fp32, beams={B}, len={L}, "
                       f"{trie_docs}-doc dict+CSR trie (the reference's dict structure for 8.8M docs does not fit "
                       f"host RAM), full-prefix decoder recompute like the reference (no KV cache); "
-                      f"{dt:.1f}s wall on {best_t} threads (fastest of 8/16/32/64; host has {host_cores} cores)"}
+                      f"{dt:.1f}s wall on {best_t} threads (fastest of 8/16/32/64; host has {host_cores} cores); "
+                      f"value_batch1 = the same loop at the reference script's batch size 1 ({dt1:.2f}s per query)"}
 
 
 def main():
