@@ -68,7 +68,7 @@ def algorithmic_flops_per_query(dims, B, L, Lq):
             + 4 * Lq * Lq * inner * ne + 4 * inner * nd * B * L * (L + 1) / 2 + 4 * inner * nd * B * L * Lq)
 
 
-def cpu_baseline(sd, dims, B, L, n_queries=12, trie_docs=10_000):
+def cpu_baseline(sd, dims, B, L, n_queries=16, trie_docs=10_000):
     """Reference-faithful CPU loop (oracle 'port') on the host cores; bounded sample.
 
     The GPU box has far more cores than these small fp32 GEMMs can use (torch CPU gets *slower*
@@ -112,6 +112,20 @@ def cpu_baseline(sd, dims, B, L, n_queries=12, trie_docs=10_000):
                       f"value_batch1 = the same loop at the reference script's batch size 1 ({dt1:.2f}s per query)"}
 
 
+def launch_command(gpus, env, argv):
+    """The N>1 contract is one process per GPU under torch.distributed.run. When --gpus N > 1 is given without a
+    launcher (no WORLD_SIZE in the environment), return the command that re-runs this script as N ranks on
+    127.0.0.1 with a free port; None when already launched or N == 1."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,22 +138,44 @@ def main():
     ap.add_argument("--model", default="t5-base", choices=["t5-base", "t5-large"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"],
                     help="GEMM arithmetic: f16x2 = fp32 operands as two f16 planes, 3 f16 MFMAs per product "
                          "(fp32-equivalent to ~2^-22); f32 = exact fp32 MFMA")
     args = ap.parse_args()
 
+    relaunch = launch_command(args.gpus, os.environ, sys.argv)
+    if relaunch is not None:   # `python bench.py --gpus N` without a launcher: become N ranks (one per GPU)
+        log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching as " + " ".join(relaunch))
+        os.execvp(relaunch[0], relaunch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world != args.gpus:     # never print an N=1 number under --gpus 8 (or the other way round)
+        raise SystemExit(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to run a mislabelled job")
     import torch.distributed as dist
+    backend = os.environ.get("RPR_BENCH_BACKEND", "nccl")   # "nccl" = RCCL on ROCm; tests use gloo on CPU for the launcher
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    if os.environ.get("RPR_BENCH_LAUNCH_ONLY"):   # launcher self-test (tests/test_dist_gloo.py): rendezvous, report, exit
+        if world > 1:
+            t = torch.tensor([rank], dtype=torch.int64)
+            lst = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(lst, t)
+            if rank == 0:
+                print(json.dumps({"n_gpus": args.gpus, "rccl_world_size": dist.get_world_size(),
+                                  "ranks_seen": [int(x) for x in lst]}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"n_gpus": 1, "rccl_world_size": 1, "ranks_seen": [0]}), flush=True)
+        return
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -210,6 +246,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Second timed loop, same K steps, with the boundary's PCIe legs inside (SURVEY §8d wording of the metric): ids and
+    # mask start in pinned host memory, results end in pinned host memory. Reported as value_pcie_inclusive; `value`
+    # stays the resident-input rate.
+    host_in = [(b[0].cpu().pin_memory(), b[1].cpu().pin_memory()) for b in batches[W:W + K]]
+    host_out = None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_pcie = time.perf_counter()
+    for i in range(K):
+        ids_d = host_in[i][0].to(dev, non_blocking=True)
+        mask_d = host_in[i][1].to(dev, non_blocking=True)
+        r = E.search(model, trie, ids_d, mask_d, B, L, use_graph=not args.no_graph)
+        if host_out is None:
+            host_out = [torch.empty(x.shape, dtype=x.dtype).pin_memory() for x in (r.tokens, r.scores, r.row_lo, r.row_hi)]
+        for dst, src in zip(host_out, (r.tokens, r.scores, r.row_lo, r.row_hi)):
+            dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_pcie = time.perf_counter() - t_pcie
+    if world > 1:
+        t = torch.tensor([elapsed_pcie], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_pcie = float(t.item())
+    status_flags = ctx.status(clear=True)   # sticky saturation / empty-query word over everything run so far
+
     # sanity on the timed outputs: every returned smtid of the last step is a trie leaf range
     last = results[-1]
     n_leaf = int((last.row_hi > last.row_lo).sum().item())
@@ -231,6 +294,10 @@ def main():
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 via f16x2-split MFMA (fp32 accumulate)", "data": "synthetic",
+            "value_pcie_inclusive": world * Q * K / elapsed_pcie,
+            "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "gather_bytes_per_rank": int(tok.numel() * tok.element_size() + sc.numel() * sc.element_size()) if world > 1 else 0,
+            "saturated": bool(status_flags & 1), "model_f32_only": bool(model.f32_only),
             "config": {"workload": f"{args.model} dims, {trie.N}-doc synthetic 32x256 docid trie, beams={B}, len={L}, "
                                    f"{Q} queries/step/GPU (MSMARCO-dev-shaped, mean {mean_len:.1f} tokens, padded to {lq_used})",
                        "queries_per_step_per_gpu": Q, "beams": B, "len": L, "docs": trie.N, "enc_len_padded": lq_used,
@@ -249,7 +316,8 @@ def main():
             stats = ctx.profile_get()
             ctx.profile_enable(False)
             log("[bench] roofline leg done")
-            g = stats["gemm"]
+            g = stats["gemm"]           # launches of the dominant kernel only (256x256 ping-pong / fp32 MFMA kernel);
+            gs = stats["gemm_small"]    # the few small-tile launches (encoder tail, logits of step 0) are listed apart
             ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
             if args.precision == "f32":
                 kname, peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
@@ -270,6 +338,13 @@ def main():
                         traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
                         traffic_src = ("profiles/latest_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
                                        "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
+                        # the counters come from an earlier profiled run of tools/profile_round.sh: refuse them when that
+                        # run's launch count per step no longer matches this build's (kernels changed since)
+                        n_pmc = pmc["FETCH_SIZE"][key[0]]["launches"]
+                        if n_pmc != g["launches"]:
+                            traffic_src = (f"stale: profiles/latest_hbm_pmc.json has {n_pmc} launches of the kernel per step, "
+                                           f"this build {g['launches']}; re-run tools/profile_round.sh")
+                            traffic = None
                 except Exception:
                     pass
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach,
@@ -278,7 +353,9 @@ def main():
                                "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                                "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
                                "launches_per_step": g["launches"],
-                               "flops_per_launch": g["flops"] / max(1, g["launches"])}
+                               "flops_per_launch": g["flops"] / max(1, g["launches"]),
+                               "other_gemm_launches": {"launches_per_step": gs["launches"], "total_ms": gs["total_ms"],
+                                                       "tflops": gs["flops"] / max(1e-9, gs["total_ms"] * 1e-3) / 1e12}}
             tot = sum(s["total_ms"] for s in stats.values())
             out["kernel_breakdown_ms"] = {k: round(s["total_ms"], 3) for k, s in stats.items()}
             out["kernel_breakdown_ms"]["sum"] = round(tot, 3)
@@ -305,6 +382,18 @@ def main():
                                        "note": "K/V rows of every beam's ancestry, read once per step; ~6.3 TB/s is what "
                                                "streaming reads reach on this part (MI355X_MICROARCH.md)"}
                 out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
+        if world == 1 and args.precision != "f32" and not args.no_exact_fp32:
+            # secondary figure: the same step on the exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), 1 warm-up + 2 timed
+            ctx.set_precision("f32")
+            run_step(W); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2):
+                run_step(W + (i % K))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            ctx.set_precision("f16x2")
+            out["exact_fp32"] = {"value": Q / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": 2,
+                                 "dtype": "f32 (exact fp32 MFMA GEMMs)"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd, dims, B, L)

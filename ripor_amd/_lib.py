@@ -12,8 +12,10 @@ from typing import Optional
 LIB_NAME = "libripor_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_COUNT = range(8)
-KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other"]
+K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_GEMM_SMALL, K_COUNT = range(9)
+KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other", "gemm_small"]
+STATUS_SATURATED, STATUS_EMPTY_QUERY = 1, 2
+ABI_VERSION = 2
 
 PREC_F32, PREC_F16X2 = 0, 1
 FLAG_LOG_SOFTMAX = 1
@@ -47,7 +49,7 @@ class ModelDesc(C.Structure):
 
 class DebugTaps(C.Structure):
     _fields_ = [("encoder_out", C.c_void_p), ("step_logits", C.c_void_p), ("step_scores", C.c_void_p),
-                ("step_tokens", C.c_void_p), ("step_parent", C.c_void_p)]
+                ("step_tokens", C.c_void_p), ("step_parent", C.c_void_p), ("step_valid", C.c_void_p)]
 
 
 class KernelStats(C.Structure):
@@ -79,6 +81,8 @@ SIGNATURES = {
     "rpr_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(DebugTaps), C.c_void_p]),
+    "rpr_get_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "rpr_model_f32_only": (C.c_int, [C.c_void_p]),
     "rpr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rpr_profile_reset": (C.c_int, [C.c_void_p]),
     "rpr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(KernelStats)]),

@@ -67,6 +67,10 @@ struct rpr_model {
   std::vector<__half*> h_dec_qkv, h_dec_o, h_dec_xq, h_dec_xo, h_dec_wi, h_dec_wo;
   __half* h_dec_xkv = nullptr;
   __half* h_out_embeds = nullptr;  // [2][L*V][d]
+  // Fused RMSNorm: the planes of every projection that consumes a normalised input hold W * diag(ln_weight)
+  // (enc_qkv: ln0, enc_wi: ln1, dec_qkv: ln0, dec_xq: ln1, dec_wi: ln2, out_embeds: final ln * scaleup factor);
+  // the fp32 weights of the caller stay untouched and serve the exact-fp32 mode.
+  bool f32_only = false;           // a weight does not fit the f16 planes: every search of this model runs exact fp32
   std::vector<void*> owned;
   int inner() const { return d.num_heads * d.d_kv; }
   ~rpr_model() {   // device memory goes with the object, also on the error paths of rpr_load_model
@@ -109,13 +113,17 @@ struct Workspace {
   DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
   // staged outputs
   DevBuf o_tokens, o_scores, o_lo, o_hi;
-  // f16 hi/lo planes of the GEMM inputs (split-precision mode)
-  DevBuf eh_h, eattn_h, eff_h, enc_out_h, h_h, attn_h, ff_h;
+  // f16 hi/lo planes of the GEMM inputs (split-precision mode): attention outputs, FF intermediates, the final
+  // encoder states, and the UN-normalised residual streams (fused RMSNorm) with their row sums of squares
+  DevBuf eattn_h, eff_h, enc_out_h, attn_h, ff_h, ex_h, x_h, ssq_e, ssq_d;
+  DevBuf tr_x, tr_misc;   // rpr_train_forward scratch (teacher-forced decoder)
 };
 
 struct rpr_ctx {
   int device;
   int precision = RPR_PREC_F16X2;
+  unsigned int* status = nullptr;       // [dev] sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing
+  unsigned int* status_host = nullptr;  // pinned mirror filled by rpr_get_status
   unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
   Workspace ws;
   size_t ws_bytes = 0;
@@ -170,7 +178,7 @@ struct Launcher {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
   }
-  template <class F> void run(int cls, double flops, double bytes, F&& f) {
+  template <class F> void run(int cls, double flops, double bytes, F&& f, const int* cls_after = nullptr) {
     if (err) return;
     hipEvent_t ea = nullptr, eb = nullptr;
     if (c->profiling) {
@@ -181,14 +189,17 @@ struct Launcher {
     if (e != hipSuccess) { err = hip_fail(e, "kernel launch", __FILE__, __LINE__); return; }
     if (c->profiling && ea && eb) {
       (void)hipEventRecord(eb, s);
-      c->recs.push_back({cls, ea, eb, flops, bytes});
+      c->recs.push_back({cls_after ? *cls_after : cls, ea, eb, flops, bytes});
     }
   }
 };
 
 // One linear layer C = act(A @ W^T) (+ residual). A and W are given in both representations; the
 // ctx precision picks the exact fp32 MFMA kernel or the f16x2 split kernel.
-struct LinIn { const float* f; const __half* h; size_t ps; int ld; float scale = A_PLANE_SCALE; };  // activation [M, K]; scale of its planes
+struct LinIn {                                                               // activation [M, K]
+  const float* f; const __half* h; size_t ps; int ld; float scale = A_PLANE_SCALE;   //   fp32 / planes (+ their scale)
+  const unsigned long long* ssq = nullptr; float inv_d_fix = 0.f, eps = 0.f;         //   fused RMSNorm: h = planes of x, W folded
+};
 struct LinW { const float* f; const __half* h; int N, K; };                  // weight [N, K] (+ planes, stride N*K)
 struct LinOut {                                                              // destination
   float* f[3]; int ldo[3]; int split_n;                                      //   fp32 (up to 3 column blocks)
@@ -196,6 +207,7 @@ struct LinOut {                                                              // 
   const float* resid; int relu;
   int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
   float plane_scale;                                                         //   scale of the planes written to h (0 = 1)
+  __half* x_h; size_t x_ps; unsigned long long* ssq_out;                     //   fused RMSNorm producer outputs (with f[0])
 };
 
 LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
@@ -208,7 +220,7 @@ LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu =
 void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, const int* m_dev = nullptr, int m_acc = -1) {
   const double Ma = m_acc >= 0 ? m_acc : M;
   const double fl = 2.0 * Ma * (double)W.N * W.K;
-  const double by = 4.0 * (Ma * W.K + (double)W.N * W.K + Ma * W.N * (O.resid ? 2 : 1));
+  const double by = 4.0 * (Ma * W.K + (double)W.N * W.K + Ma * W.N * (O.resid ? 2 : 1) + (O.x_h ? Ma * W.N : 0.0));
   hipStream_t s = L.s;
   if (L.c->precision == RPR_PREC_F16X2) {
     GemmH2Args g{};
@@ -220,7 +232,10 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.trace = L.c->trace_buf;
     g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
     g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
-    L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); });
+    g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
+    g.x_h = O.x_h; g.x_ps = O.x_ps; g.ldxh = W.N; g.ssq_out = O.ssq_out;
+    g.sat = L.c->status;
+    L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
     GemmArgs g{};
     g.A = A.f; g.lda = A.ld; g.W = W.f; g.ldw = W.K; g.resid = O.resid; g.ldr = O.ldo[0];
@@ -248,7 +263,7 @@ int flush_profile(rpr_ctx* c) {
 int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L) {
   const auto& d = m->d;
   const size_t T = (size_t)Q * Lq, R = (size_t)Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
-  const size_t nd = d.num_decoder_layers, f = sizeof(float);
+  const size_t nd = d.num_decoder_layers, ne = d.num_layers, f = sizeof(float);
   Workspace& w = c->ws;
   int e = 0;
   auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = ensure(c, b, bytes); };
@@ -265,10 +280,32 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   }
   E(w.o_tokens, R * (size_t)L * 4); E(w.o_scores, R * 4); E(w.o_lo, R * 8); E(w.o_hi, R * 8);
   const size_t hb = sizeof(__half) * 2;  // two planes
-  E(w.eh_h, T * dm * hb); E(w.eattn_h, T * inner * hb); E(w.eff_h, T * dff * hb); E(w.enc_out_h, T * dm * hb);
-  E(w.h_h, R * dm * hb); E(w.attn_h, R * inner * hb); E(w.ff_h, R * dff * hb);
+  E(w.eattn_h, T * inner * hb); E(w.eff_h, T * dff * hb); E(w.enc_out_h, T * dm * hb);
+  E(w.attn_h, R * inner * hb); E(w.ff_h, R * dff * hb);
+  E(w.ex_h, T * dm * hb); E(w.x_h, R * dm * hb);
+  E(w.ssq_e, (2 * ne + 1) * T * 8); E(w.ssq_d, (3 * nd + 1) * R * 8);
   return e;
 }
+
+// Fused RMSNorm plumbing of the split-precision mode: the residual stream x is kept as fp32 (master
+// copy, residual adds) plus two f16 planes (operand of the next projection) plus one fixed-point sum of squares per
+// row and norm site; the projection that follows a norm runs on the x planes against W * diag(ln_weight) and scales
+// its output rows by rsqrt(ssq / d + eps). Sites are numbered in program order; every site of a pass has its own
+// ssq slot, zeroed by one memset per pass (site 0 is stored by the embedding kernel, the others are accumulated with
+// integer atomics by the residual GEMMs' epilogues, so the sums do not depend on the order of arrival).
+struct XStream {
+  float* x; __half* x_h; size_t ps; unsigned long long* ssq; size_t rows; int dm; float eps;
+  LinIn in(int site) const {
+    LinIn a{x, x_h, ps, dm, X_PLANE_SCALE};
+    a.ssq = ssq + (size_t)site * rows; a.inv_d_fix = 1.0f / ((float)dm * SSQ_FIX); a.eps = eps;
+    return a;
+  }
+  LinOut out(int site) const {          // x += projection; refresh the planes and the site's row sums
+    LinOut o = out_f32(x, dm, dm, x);
+    o.x_h = x_h; o.x_ps = ps; o.ssq_out = ssq + (size_t)site * rows;
+    return o;
+  }
+};
 
 // Encoder forward into ws.enc_out (reference generation.py:132-137 -> model.encoder(...)).
 // packed = false: rows are [Q, Lq] padded (taps / rpr_encode return that layout).
@@ -284,7 +321,7 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   hipStream_t s = Ln.s;
   float *x = P<float>(w.ex), *h = P<float>(w.eh), *qkv = P<float>(w.eqkv), *attn = P<float>(w.eattn),
         *ff = P<float>(w.eff);
-  __half *h_h = P<__half>(w.eh_h), *attn_h = P<__half>(w.eattn_h), *ff_h = P<__half>(w.eff_h);
+  __half *attn_h = P<__half>(w.eattn_h), *ff_h = P<__half>(w.eff_h);
   const size_t ps_d = (size_t)T * dm, ps_i = (size_t)T * inner, ps_f = (size_t)T * dff;
   const float eps = d.layer_norm_eps;
   const int32_t* offs = packed ? P<int32_t>(w.offs) : nullptr;
@@ -297,33 +334,39 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
       if (hipMemcpyAsync(&n, live, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) Ta = n;
     }
   }
-  auto norm = [&](const float* wgt, float* of, __half* oh) {
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
-      return launch_rmsnorm(x, wgt, h2 ? nullptr : of, T, dm, eps, s, 1.0f, h2 ? oh : nullptr, ps_d, live);
-    });
+  const XStream xs{x, P<__half>(w.ex_h), ps_d, P<unsigned long long>(w.ssq_e), (size_t)T, dm, eps};
+  if (h2 && !Ln.err) {
+    hipError_t e = hipMemsetAsync(w.ssq_e.p, 0, (size_t)(2 * d.num_layers + 1) * T * 8, s);
+    if (e != hipSuccess) { Ln.err = hip_fail(e, "ssq memset", __FILE__, __LINE__); return; }
+  }
+  auto norm = [&](const float* wgt) {   // exact-fp32 mode only: the split mode folds the norms into the projections
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, T, dm, eps, s, 1.0f, nullptr, 0, live); });
   };
   Ln.run(RPR_K_OTHER, 0, 2.0 * Ta * dm * 4, [&] {
     return launch_embed_rows(d.shared, P<int32_t>(w.ids), x, T, dm, d.vocab_size, s,
-                             packed ? P<int32_t>(w.row_src) : nullptr, live);
+                             packed ? P<int32_t>(w.row_src) : nullptr, live,
+                             h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
   });
+  const LinIn in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
   for (int i = 0; i < d.num_layers; ++i) {
-    norm(m->enc_ln0[i], h, h_h);
-    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_qkv[i], m->h_enc_qkv[i], 3 * inner, dm}, T, out_f32(qkv, 3 * inner, 3 * inner), live, Ta);
+    if (!h2) norm(m->enc_ln0[i]);
+    linear(Ln, h2 ? xs.in(2 * i) : LinIn{h, nullptr, 0, dm}, {m->enc_qkv[i], m->h_enc_qkv[i], 3 * inner, dm}, T,
+           out_f32(qkv, 3 * inner, 3 * inner), live, Ta);
     EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets,
-                  h2 ? attn_h : nullptr, ps_i, offs, P<int32_t>(w.last)};
+                  h2 ? attn_h : nullptr, ps_i, offs, P<int32_t>(w.last), c->status, 0};
     Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV * ((double)Ta / T) * ((double)Ta / T), 4.0 * Ta * 4 * inner,
            [&] { return launch_enc_attn(a, s); });
-    linear(Ln, {attn, attn_h, ps_i, inner}, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, out_f32(x, dm, dm, x), live, Ta);
-    norm(m->enc_ln1[i], h, h_h);
+    linear(Ln, in_attn, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, h2 ? xs.out(2 * i + 1) : out_f32(x, dm, dm, x), live, Ta);
+    if (!h2) norm(m->enc_ln1[i]);
     LinOut o = out_f32(ff, dff, dff, nullptr, 1);
     if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
-    linear(Ln, {h, h_h, ps_d, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o, live, Ta);
-    linear(Ln, {ff, ff_h, ps_f, dff, FF_PLANE_SCALE}, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, out_f32(x, dm, dm, x), live, Ta);
+    linear(Ln, h2 ? xs.in(2 * i + 1) : LinIn{h, nullptr, 0, dm}, {m->enc_wi[i], m->h_enc_wi[i], dff, dm}, T, o, live, Ta);
+    linear(Ln, in_ff, {m->enc_wo[i], m->h_enc_wo[i], dm, dff}, T, h2 ? xs.out(2 * i + 2) : out_f32(x, dm, dm, x), live, Ta);
   }
   // final norm: fp32 copy always (taps / rpr_encode), planes for the cross-K/V GEMM in split mode
   Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
     return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, eps, s, 1.0f,
-                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live);
+                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live, c->status);
   });
   c->enc_rows_accounted = Ta;
 }
@@ -346,7 +389,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
   // index of the last attended key + 1 per query: row packing of the encoder and the cross-attention loop bound
-  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s, c->status + 1); });
   static const bool packed_env = [] { const char* e = getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
   const bool packed = packed_env && !taps;   // taps return the padded [Q, Lq, d] encoder output
   enqueue_encoder(Ln, c, m, Q, Lq, packed);
@@ -365,7 +408,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
         *logits = P<float>(w.logits);
-  __half *h_h = P<__half>(w.h_h), *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
+  __half *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
   const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
   const size_t layer_stride = (size_t)L * R * inner;
   // KV cache of one layer: [q][head][position][slot][64] — the rows one (query, head) group of beams can
@@ -388,66 +431,74 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   static const bool step0_env = [] { const char* e = getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
   const bool shared0 = step0_env && !taps && B > 1;
   int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
-  auto norm = [&](const float* wgt, float post = 1.0f) {
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Rt * dm * 4, [&] {
-      return launch_rmsnorm(x, wgt, h2 ? nullptr : h, Rt, dm, eps, s, post, h2 ? h_h : nullptr, ps_d);
-    });
+  const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+  auto norm = [&](const float* wgt, float post_scale = 1.0f) {   // exact-fp32 mode only (see XStream)
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Rt * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, Rt, dm, eps, s, post_scale); });
   };
-  const LinIn in_h{h, h_h, ps_d, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
+  const XStream xs{x, P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
+  const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
   for (int t = 0; t < L; ++t) {
     BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
     Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
+    if (h2 && !Ln.err) {
+      hipError_t e = hipMemsetAsync(w.ssq_d.p, 0, (size_t)(3 * nd + 1) * R * 8, s);
+      if (e != hipSuccess) { Ln.err = hip_fail(e, "ssq memset", __FILE__, __LINE__); return; }
+    }
     Ln.run(RPR_K_OTHER, 0, 2.0 * Rt * dm * 4, [&] {
-      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s);
+      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s,
+                              h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
     });
     for (int i = 0; i < nd; ++i) {
       float* kc = P<float>(w.kcache) + i * layer_stride;
       float* vc = P<float>(w.vcache) + i * layer_stride;
-      norm(m->dec_ln0[i]);
+      if (!h2) norm(m->dec_ln0[i]);
       {  // q -> qb, k/v -> cache row block of position t
         LinOut o{};
         o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
         o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
         o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
-        linear(Ln, in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o);
+        linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o);
       }
       {
         DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
-                          h2 ? attn_h : nullptr, ps_i};
+                          h2 ? attn_h : nullptr, ps_i, c->status};
         Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Rt * H * (double)(t + 1) * DKV,
                4.0 * ((double)Rt * inner * 2 + 2.0 * Rt * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
       }
-      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, out_f32(x, dm, dm, x));
-      norm(m->dec_ln1[i]);
-      linear(Ln, in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, Rt, out_f32(qb, inner, inner));
+      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x));
+      if (!h2) norm(m->dec_ln1[i]);
+      linear(Ln, h2 ? xs.in(3 * i + 1) : in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, Rt, out_f32(qb, inner, inner));
       {
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
         DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
-                           P<int32_t>(w.last), packed ? P<int32_t>(w.offs) : nullptr};
+                           P<int32_t>(w.last), packed ? P<int32_t>(w.offs) : nullptr, 0, c->status};
         Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Rt * H * (double)Lq * DKV,
                4.0 * ((double)Rt * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
       }
-      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, out_f32(x, dm, dm, x));
-      norm(m->dec_ln2[i]);
+      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x));
+      if (!h2) norm(m->dec_ln2[i]);
       LinOut o = out_f32(ff, dff, dff, nullptr, 1);
       if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
-      linear(Ln, in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o);
-      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, out_f32(x, dm, dm, x));
+      linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o);
+      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x));
     }
-    norm(d.dec_final_ln, d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f);
+    if (!h2) norm(d.dec_final_ln, post);
     // logits of position t only (the reference computes every position and keeps [-1])
     float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
     {
       LinW wt{d.out_embeds + (size_t)t * V * dm, nullptr, V, dm};
       if (h2) {
-        // planes of codebook t inside the stacked [2][L*V][d] buffer: plane stride is L*V*d
+        // planes of codebook t (times the final layer-norm weight and the scaleup factor) inside the stacked
+        // [2][L*V][d] buffer: plane stride is L*V*d
+        const LinIn a = xs.in(3 * nd);
         GemmH2Args g{};
-        g.A = h_h; g.a_ps = ps_d; g.lda = dm;
+        g.A = a.h; g.a_ps = a.ps; g.lda = dm;
         g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
         g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
-        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * A_PLANE_SCALE);
+        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
+        g.row_ssq = a.ssq; g.inv_d_fix = a.inv_d_fix; g.eps = a.eps; g.sat = c->status;
         Ln.run(RPR_K_GEMM, 2.0 * Rt * (double)V * dm, 4.0 * ((double)Rt * dm + (double)V * dm + (double)Rt * V),
-               [&] { return launch_gemm_h2(g, s); });
+               [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
       } else {
         linear(Ln, in_h, wt, Rt, out_f32(lg, V, V));
       }
@@ -461,6 +512,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       sa.tap_scores = taps->step_scores ? taps->step_scores + (size_t)t * R : nullptr;
       sa.tap_tokens = taps->step_tokens ? taps->step_tokens + (size_t)t * R : nullptr;
       sa.tap_parent = taps->step_parent ? taps->step_parent + (size_t)t * R : nullptr;
+      sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
     }
     Ln.run(RPR_K_SELECT, 0, (double)R * V * 4 + (double)R * 40, [&] { return launch_select(sa, s); });
   }
@@ -473,7 +525,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
 
 extern "C" {
 
-int rpr_abi_version(void) { return 1; }
+int rpr_abi_version(void) { return 2; }
 const char* rpr_last_error(void) { return g_err.c_str(); }
 
 int rpr_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
@@ -501,7 +553,15 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   }
   std::memset(c->done, 0, sizeof(c->done));
   hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), 64);
+  if (e == hipSuccess) e = hipMemset(c->status, 0, 64);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 64, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (c->status) (void)hipFree(c->status);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    delete c;
+    return hip_fail(e, "ctx setup", __FILE__, __LINE__);
+  }
   *out_ctx = c;
   return RPR_OK;
 }
@@ -515,9 +575,11 @@ void rpr_free_ctx(rpr_ctx* c) {
   DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.offs, &w.row_src, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
                    &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
                    &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
-                   &w.o_scores, &w.o_lo, &w.o_hi, &w.eh_h, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.h_h, &w.attn_h,
-                   &w.ff_h};
+                   &w.o_scores, &w.o_lo, &w.o_hi, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.attn_h,
+                   &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  if (c->status) (void)hipFree(c->status);
+  if (c->status_host) (void)hipHostFree(c->status_host);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -579,27 +641,40 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   {
     const size_t inner = (size_t)m->inner(), dm = d->d_model, dff = d->d_ff;
     int err = 0;
-    auto mk = [&](const float* wf, size_t n, __half** outp) {
+    RPR_HIP(hipMemset(c->status, 0, 4));
+    // ln (nullable): layer-norm weight folded into the columns (length = the projection's input dim, always d_model);
+    // pre = extra scalar on the weights (scaleup_output_hidden on the codebooks)
+    auto mk = [&](const float* wf, size_t n, __half** outp, const float* ln = nullptr, float pre = 1.0f) {
       if (err) return;
       void* p = nullptr;
       hipError_t e = hipMalloc(&p, n * 2 * sizeof(__half));
-      if (e == hipSuccess) { m->owned.push_back(p); e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE); }
+      if (e == hipSuccess) {
+        m->owned.push_back(p);
+        e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE * pre, ln, (int)dm, c->status);
+      }
       if (e != hipSuccess) { err = hip_fail(e, "weight split", __FILE__, __LINE__); return; }
       *outp = (__half*)p;
     };
-    auto mkv = [&](const std::vector<const float*>& src, size_t n, std::vector<__half*>& dst) {
+    auto mkv = [&](const std::vector<const float*>& src, size_t n, std::vector<__half*>& dst,
+                   const std::vector<const float*>* ln = nullptr) {
       dst.assign(src.size(), nullptr);
-      for (size_t i = 0; i < src.size(); ++i) mk(src[i], n, &dst[i]);
+      for (size_t i = 0; i < src.size(); ++i) mk(src[i], n, &dst[i], ln ? (*ln)[i] : nullptr);
     };
-    mkv(m->enc_qkv, 3 * inner * dm, m->h_enc_qkv); mkv(m->enc_o, dm * inner, m->h_enc_o);
-    mkv(m->enc_wi, dff * dm, m->h_enc_wi); mkv(m->enc_wo, dm * dff, m->h_enc_wo);
-    mkv(m->dec_qkv, 3 * inner * dm, m->h_dec_qkv); mkv(m->dec_o, dm * inner, m->h_dec_o);
-    mkv(m->dec_xq, inner * dm, m->h_dec_xq); mkv(m->dec_xo, dm * inner, m->h_dec_xo);
-    mkv(m->dec_wi, dff * dm, m->h_dec_wi); mkv(m->dec_wo, dm * dff, m->h_dec_wo);
+    mkv(m->enc_qkv, 3 * inner * dm, m->h_enc_qkv, &m->enc_ln0); mkv(m->enc_o, dm * inner, m->h_enc_o);
+    mkv(m->enc_wi, dff * dm, m->h_enc_wi, &m->enc_ln1); mkv(m->enc_wo, dm * dff, m->h_enc_wo);
+    mkv(m->dec_qkv, 3 * inner * dm, m->h_dec_qkv, &m->dec_ln0); mkv(m->dec_o, dm * inner, m->h_dec_o);
+    mkv(m->dec_xq, inner * dm, m->h_dec_xq, &m->dec_ln1); mkv(m->dec_xo, dm * inner, m->h_dec_xo);
+    mkv(m->dec_wi, dff * dm, m->h_dec_wi, &m->dec_ln2); mkv(m->dec_wo, dm * dff, m->h_dec_wo);
     mk(d->dec_xkv, (size_t)nd * 2 * inner * dm, &m->h_dec_xkv);
-    mk(d->out_embeds, (size_t)d->L * d->V * dm, &m->h_out_embeds);
+    mk(d->out_embeds, (size_t)d->L * d->V * dm, &m->h_out_embeds, d->dec_final_ln,
+       d->scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f);
     if (!err) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) err = hip_fail(e, "sync", __FILE__, __LINE__); }
     if (err) return err;
+    // a weight (times its folded layer-norm weight, times 2^8) outside the f16 range cannot be carried by the planes:
+    // the model is pinned to the exact-fp32 kernels instead of being clipped silently
+    unsigned int sat = 0;
+    RPR_HIP(hipMemcpy(&sat, c->status, 4, hipMemcpyDeviceToHost));
+    if (sat) { m->f32_only = true; RPR_HIP(hipMemset(c->status, 0, 4)); }
   }
   *out = m.release();
   return RPR_OK;
@@ -735,6 +810,9 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
   RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
 
+  // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
+  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (m->f32_only) c->precision = RPR_PREC_F32;
   const bool eager = (flags & RPR_FLAG_NO_GRAPH) || taps || c->profiling;
   if (eager) {
     Launcher Ln{c, s};
@@ -778,6 +856,8 @@ int rpr_encode(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t
   const size_t T = (size_t)Q * Lq;
   RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
   RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
+  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (m->f32_only) c->precision = RPR_PREC_F32;
   Launcher Ln{c, s};
   enqueue_encoder(Ln, c, m, Q, Lq, false);
   if (Ln.err) return Ln.err;
@@ -796,8 +876,8 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   if (c->precision == RPR_PREC_F16X2) {  // test hook: split the operands on the fly
     RPR_HIP(At.alloc((size_t)M * K * 2 * sizeof(__half)));
     RPR_HIP(Wt.alloc((size_t)N * K * 2 * sizeof(__half)));
-    RPR_HIP(launch_split_planes(A, At.as<__half>(), (size_t)M * K, (size_t)M * K, s));
-    RPR_HIP(launch_split_planes(W, Wt.as<__half>(), (size_t)N * K, (size_t)N * K, s, W_PLANE_SCALE));
+    RPR_HIP(launch_split_planes(A, At.as<__half>(), (size_t)M * K, (size_t)M * K, s, 1.0f, nullptr, 0, c->status));
+    RPR_HIP(launch_split_planes(W, Wt.as<__half>(), (size_t)N * K, (size_t)N * K, s, W_PLANE_SCALE, nullptr, 0, c->status));
   }
   linear(Ln, {A, At.as<__half>(), (size_t)M * K, K, 1.0f}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
   if (At.p) RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
@@ -823,6 +903,19 @@ int rpr_op_rmsnorm(rpr_ctx* c, const float* x, const float* w, float* out, int32
   RPR_HIP(launch_rmsnorm(x, w, out, rows, d, eps, reinterpret_cast<hipStream_t>(stream)));
   return RPR_OK;
 }
+
+int rpr_get_status(rpr_ctx* c, void* stream, uint32_t* out_flags, int clear) {
+  RPR_REQUIRE(c && out_flags, "NULL argument");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RPR_HIP(hipMemcpyAsync(c->status_host, c->status, 8, hipMemcpyDeviceToHost, s));
+  if (clear) RPR_HIP(hipMemsetAsync(c->status, 0, 8, s));
+  RPR_HIP(hipStreamSynchronize(s));
+  *out_flags = (c->status_host[0] ? RPR_STATUS_SATURATED : 0u) | (c->status_host[1] ? RPR_STATUS_EMPTY_QUERY : 0u);
+  return RPR_OK;
+}
+
+int rpr_model_f32_only(const rpr_model* m) { return m ? (m->f32_only ? 1 : 0) : -1; }
 
 int rpr_profile_enable(rpr_ctx* c, int enable) {
   RPR_REQUIRE(c, "NULL ctx");

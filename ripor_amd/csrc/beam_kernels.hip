@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
   }
   __syncthreads();
+  if (a.tap_valid)   // debug tap: the child bitmap the selection below works from (tests/test_gpu_parity.py)
+    for (int w = tid; w < words; w += 256) a.tap_valid[(size_t)q * words + w] = valid[w];
 
   auto raw_logit = [&](int item) -> float {
     if (a.lds_logits) return slog[item];

@@ -31,11 +31,25 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     }                                                                        \
   } while (0)
 
-// x = hi + lo carried as two f16 values (22 significant bits); see gemm_h2.hip
-__device__ __forceinline__ void split_f16(float x, __half& hi, __half& lo) {
-  x = fminf(fmaxf(x, -65504.f), 65504.f);
+// x = hi + lo carried as two f16 values (22 significant bits); see gemm_h2.hip.
+// A value outside the f16 range is clamped AND reported: `sat` (nullable) is the ctx's sticky saturation word
+// (rpr_get_status); the host then repeats the call on the exact fp32 path instead of returning clipped results.
+// NaN/Inf inputs also count (the comparison is written so that NaN fails it).
+__device__ __forceinline__ void split_f16(float x, __half& hi, __half& lo, unsigned int* sat = nullptr) {
+  if (!(fabsf(x) <= 65504.f)) {
+    if (sat) *sat = 1u;              // benign race: every writer stores 1
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+  }
   hi = __float2half_rn(x);
   lo = __float2half_rn(x - __half2float(hi));
+}
+
+// Row sum of squares in fixed point (2^-20 units, int64): partial sums from different blocks are combined with
+// integer atomics, so the total does not depend on the order of arrival (bitwise-reproducible RMSNorm scale).
+constexpr float SSQ_FIX = 1048576.0f;
+__device__ __forceinline__ unsigned long long ssq_to_fix(float ss) { return (unsigned long long)(long long)(ss * SSQ_FIX); }
+__device__ __forceinline__ float ssq_rsqrt(unsigned long long fix, float inv_d_fix, float eps) {
+  return rsqrtf(fmaf((float)(long long)fix, inv_d_fix, eps));   // inv_d_fix = 1 / (d * SSQ_FIX)
 }
 
 // ---- GEMM: C = act(A @ W^T) (+ residual), fp32 MFMA --------------------------------------------
@@ -70,6 +84,14 @@ struct GemmH2Args {
   // by acc_scale = 1 / (scale of A's planes * scale of W's planes); planes written by the epilogue (out_h) are
   // scaled by plane_scale. 0 means 1.
   float acc_scale, plane_scale;
+  // Fused RMSNorm. Consumer side: A holds the planes of the UN-normalised residual stream x and W the
+  // planes of W * diag(ln_weight); row m of the result is multiplied by rsqrt(row_ssq[m] / d + eps) in the epilogue.
+  // Producer side (residual GEMMs): besides the fp32 stream out[0], the epilogue writes the planes of the new x
+  // (x_h, scale X_PLANE_SCALE) and adds its tile's part of every row's sum of squares to ssq_out (fixed point).
+  const unsigned long long* row_ssq; float inv_d_fix, eps;
+  __half* x_h; size_t x_ps; int ldxh; unsigned long long* ssq_out;
+  unsigned int* sat;                       // sticky saturation word of the ctx (split_f16)
+  int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 
 // f16 has 5 exponent bits: a plane element below 2^-14 is subnormal, so the lo plane of x = hi + lo (|lo| ~ 2^-11 |x|)
@@ -78,6 +100,9 @@ struct GemmH2Args {
 // x 2^4 (|x| < 4094), and the FF intermediate relu(h Wi^T), the one tensor known to leave the f16 range on real T5
 // checkpoints, x 2^-4 (|x| < 1.05e6). The GEMM epilogue undoes the product of the two scales.
 constexpr float W_PLANE_SCALE = 256.0f, A_PLANE_SCALE = 16.0f, FF_PLANE_SCALE = 0.0625f;
+// planes of the un-normalised residual stream x (fused RMSNorm): unscaled, |x| < 65504; elements below 0.125 keep an
+// absolute precision of 2^-25 (subnormal lo plane), i.e. 2^-25 relative to a row of O(1) RMS
+constexpr float X_PLANE_SCALE = 1.0f;
 
 // offset (in floats) of output element (m, on) in output block oi; on..on+3 stay inside one head
 template <class G>
@@ -88,9 +113,12 @@ __device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, in
   }
   return (size_t)m * ldo + on;
 }
-hipError_t launch_gemm_h2(const GemmH2Args& a, hipStream_t s);
+hipError_t launch_gemm_h2(GemmH2Args& a, hipStream_t s);
+// colscale (nullable, length cols): element (r, c) is multiplied by colscale[c] before the split (folds a layer-norm
+// weight into the columns of the consuming projection); cols is ignored when colscale is null
 hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s,
-                               float scale = 1.0f);
+                               float scale = 1.0f, const float* colscale = nullptr, int cols = 0,
+                               unsigned int* sat = nullptr);
 
 // ---- T5 elementwise / attention kernels -----------------------------------------------------------
 // post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5
@@ -98,17 +126,21 @@ hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t pla
 // rows_dev (nullable): live row count on the device; rows past it are skipped (packed encoder)
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
                           float post_scale = 1.0f, __half* out_h = nullptr, size_t o_ps = 0,
-                          const int* rows_dev = nullptr);
+                          const int* rows_dev = nullptr, unsigned int* sat = nullptr);
+// Fused-RMSNorm producers: besides the fp32 row, x_h (planes of the row, X_PLANE_SCALE) and ssq (fixed-point sum of
+// squares of the row, stored — one wave owns a whole row) are written when non-null.
+struct XOut { __half* x_h; size_t x_ps; unsigned long long* ssq; unsigned int* sat; };
 hipError_t init_t5_kernel_attributes();
 hipError_t init_beam_kernel_attributes();
 // row_src (nullable): out row p takes ids[row_src[p]] for p < *rows_dev (packed encoder)
 hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
-                             hipStream_t s, const int32_t* row_src = nullptr, const int* rows_dev = nullptr);
+                             hipStream_t s, const int32_t* row_src = nullptr, const int* rows_dev = nullptr,
+                             XOut xo = XOut{});
 // Packed encoder rows: offs[q] = sum of lens[<q] (offs[Q] = live rows), row_src[offs[q] + j] = q * Lq + j
 hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src, int Q, int Lq, hipStream_t s);
 // x[r] = t==0 ? start : in_embeds[t-1][tokens[r][t-1]]
 hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
-                            float* out, int R, int d, int V, int t, hipStream_t s);
+                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo = XOut{});
 
 struct EncAttnArgs {
   const float* qkv;        // [Q*Lq, 3*inner]  (q | k | v)
@@ -120,6 +152,9 @@ struct EncAttnArgs {
   __half* out_h; size_t o_ps;   // when non-null: write f16 planes instead of fp32
   const int32_t* offs;     // nullable (packed encoder): rows of query q are offs[q] .. offs[q] + lens[q] - 1
   const int32_t* lens;     //   instead of q*Lq .. q*Lq + Lq - 1
+  unsigned int* sat;       // sticky saturation word (planes output)
+  int causal;              // teacher-forced decoder self-attention (rpr_train_forward): key j <= query i only,
+                           //   bucket table indexed by i - j (unidirectional)
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
 
@@ -135,6 +170,7 @@ struct DecSelfAttnArgs {
   float* out;              // [R, inner]
   int Q, B, H, t;
   __half* out_h; size_t o_ps;
+  unsigned int* sat;
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 
@@ -150,6 +186,7 @@ struct DecCrossAttnArgs {
   const int32_t* last;     // [Q] index of the last attended key + 1 (launch_mask_lengths)
   const int32_t* offs;     // nullable (packed encoder): K/V row (q, j) is row offs[q] + j instead of q*Lq + j
   int bchunk;              // set by the launcher: beams per block when the beam is split over blockIdx.y (0 = all)
+  unsigned int* sat;
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 
@@ -177,6 +214,7 @@ struct SelectArgs {
   int shared0;               // step 0 computed once per query: logits is [Q, V], position-0 K/V live in slot 0
   // debug taps for step t (nullable)
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
+  unsigned long long* tap_valid;                                   // [Q, B*V/64] phase-A child bitmap (bit = beam*V + token)
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
@@ -194,6 +232,8 @@ hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
 // mask-only kernel for rpr_trie_mask: prefix rows -> child byte mask
 hipError_t launch_prefix_mask(const uint16_t* codes, int Lc, int64_t N, const int32_t* prefix, int R, int T,
                               int V, uint8_t* out_mask, hipStream_t s);
-hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s);
+// status (nullable): the ctx's sticky "empty query" word, set to 1 when a query attends to no token
+hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s,
+                               unsigned int* status = nullptr);
 
 }  // namespace rpr

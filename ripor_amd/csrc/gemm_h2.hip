@@ -177,40 +177,67 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   }
 
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn + wn * (BN / WN) + j * 32 + ncol;
-    if (!FULL && n >= g.N) continue;
-    const int oi = n / g.split_n, on = n - oi * g.split_n;
-    float* outp = g.out[oi];
-    const int ldo = g.ldo[oi];
+  for (int i = 0; i < TM; ++i) {
+    const int mbase = bm + wm * (BM / WM) + i * 32 + rsub;
+    float rs[16], ssr[16];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mbase = bm + wm * (BM / WM) + i * 32 + rsub;
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2);
+      ssr[r] = 0.f;
+      rs[r] = (g.row_ssq && (FULL || m < Mlim)) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = bn + wn * (BN / WN) + j * 32 + ncol;
+      const bool nok = FULL || n < g.N;
+      const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
+      float* outp = g.out[oi];
+      const int ldo = g.ldo[oi];
       float res[16];
       if (g.resid) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
-          res[r] = (FULL || m < g.M) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+          res[r] = (nok && (FULL || m < Mlim)) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
         }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (FULL || m < g.M) {
-          float v = acc[i][j][r] * g.acc_scale;
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.resid) v = res[r] + v;
+        const bool ok = nok && (FULL || m < Mlim);
+        float v = acc[i][j][r] * g.acc_scale;
+        if (g.row_ssq) v *= rs[r];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.resid) v = res[r] + v;
+        if (ok) {
           if (g.out_h) {
             __half hi, lo;
-            split_f16(v * g.plane_scale, hi, lo);
+            split_f16(v * g.plane_scale, hi, lo, g.sat);
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
           } else {
             outp[out_off(g, oi, m, ldo, on)] = v;
           }
+          if (g.x_h) {
+            __half hi, lo;
+            split_f16(v * X_PLANE_SCALE, hi, lo, g.sat);
+            g.x_h[(size_t)m * g.ldxh + n] = hi;
+            g.x_h[g.x_ps + (size_t)m * g.ldxh + n] = lo;
+          }
+          ssr[r] += v * v;
         }
+      }
+    }
+    if (g.ssq_out) {   // this wave's part of every row's sum of squares: 32 lanes share a row
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float ss = ssr[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (ncol == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
       }
     }
   }
@@ -228,6 +255,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   // operand LDS and streams them out as float4 rows: 16 residual loads in flight per lane, 4x fewer
   // store instructions, f16 planes written 8 bytes at a time.
   __syncthreads();                                   // all waves are done reading operand tiles
+  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
@@ -252,11 +280,19 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     const int mrow0 = bm + wm * (BM / WM) + half * 64;
     constexpr int NK = 64 / RPI;
     float4 res[NK];
+    float rsc[NK];
+    if (g.row_ssq) {   // fused RMSNorm: per-row scale of the consumer
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int m = mrow0 + k * RPI + rrow;
+        rsc[k] = (FULL || m < Mlim) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+      }
+    }
     if (g.resid) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int m = mrow0 + k * RPI + rrow;
-        res[k] = (ncol_ok && (FULL || m < g.M)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
+        res[k] = (ncol_ok && (FULL || m < Mlim)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -265,18 +301,34 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       const int rl = k * RPI + rrow, m = mrow0 + rl;
       float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
       v.x *= g.acc_scale; v.y *= g.acc_scale; v.z *= g.acc_scale; v.w *= g.acc_scale;
+      if (g.row_ssq) { v.x *= rsc[k]; v.y *= rsc[k]; v.z *= rsc[k]; v.w *= rsc[k]; }
       if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
-      if (ncol_ok && (FULL || m < g.M)) {
+      const bool ok = ncol_ok && (FULL || m < Mlim);
+      if (ok) {
         if (g.out_h) {
           __half h[4], l[4];
           const float ps = g.plane_scale;
-          split_f16(v.x * ps, h[0], l[0]); split_f16(v.y * ps, h[1], l[1]); split_f16(v.z * ps, h[2], l[2]); split_f16(v.w * ps, h[3], l[3]);
+          split_f16(v.x * ps, h[0], l[0], g.sat); split_f16(v.y * ps, h[1], l[1], g.sat);
+          split_f16(v.z * ps, h[2], l[2], g.sat); split_f16(v.w * ps, h[3], l[3], g.sat);
           *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
           *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
         } else {
           *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
         }
+        if (g.x_h) {   // planes of the new residual stream (next consumer's A operand)
+          __half h[4], l[4];
+          split_f16(v.x * X_PLANE_SCALE, h[0], l[0], g.sat); split_f16(v.y * X_PLANE_SCALE, h[1], l[1], g.sat);
+          split_f16(v.z * X_PLANE_SCALE, h[2], l[2], g.sat); split_f16(v.w * X_PLANE_SCALE, h[3], l[3], g.sat);
+          *reinterpret_cast<uint2*>(g.x_h + (size_t)m * g.ldxh + n0) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(g.x_h + g.x_ps + (size_t)m * g.ldxh + n0) = *reinterpret_cast<uint2*>(l);
+        }
+      }
+      if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
+        float ss = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
       }
     }
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
@@ -547,24 +599,39 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
     acc[r] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
              red[(3 * 16 + r) * 64 + lane];
   const int n = bn + (lane & 31), rsub = 4 * (lane >> 5);
-  if (!FULL && n >= g.N) return;
-  const int oi = n / g.split_n, on = n - oi * g.split_n;
+  const bool nok = FULL || n < g.N;
+  const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
   float* outp = g.out[oi];
   const int ldo = g.ldo[oi];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
-    if (!FULL && m >= g.M) continue;
+    const bool mok = FULL || m < g.M, ok = nok && mok;
     float v = acc[r] * g.acc_scale;
+    if (g.row_ssq && mok) v *= ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
-    if (g.resid) v = g.resid[(size_t)m * g.ldr + n] + v;
-    if (g.out_h) {
-      __half hi, lo;
-      split_f16(v * g.plane_scale, hi, lo);
-      g.out_h[(size_t)m * g.ldoh + n] = hi;
-      g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
-    } else {
-      outp[out_off(g, oi, m, ldo, on)] = v;
+    if (g.resid && ok) v = g.resid[(size_t)m * g.ldr + n] + v;
+    if (ok) {
+      if (g.out_h) {
+        __half hi, lo;
+        split_f16(v * g.plane_scale, hi, lo, g.sat);
+        g.out_h[(size_t)m * g.ldoh + n] = hi;
+        g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+      } else {
+        outp[out_off(g, oi, m, ldo, on)] = v;
+      }
+      if (g.x_h) {
+        __half hi, lo;
+        split_f16(v * X_PLANE_SCALE, hi, lo, g.sat);
+        g.x_h[(size_t)m * g.ldxh + n] = hi;
+        g.x_h[g.x_ps + (size_t)m * g.ldxh + n] = lo;
+      }
+    }
+    if (g.ssq_out) {   // wave-uniform branch: all 64 lanes take part in the shuffles
+      float ss = ok ? v * v : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      if ((lane & 31) == 0 && mok) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
     }
   }
 }
@@ -572,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
 template <int BM, int BN, int WM = 2, int WN = 2>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-  const bool full = (a.M % BM == 0) && (a.N % BN == 0);
+  const bool full = (a.M % BM == 0) && (a.N % BN == 0) && !a.m_dev;
   const dim3 grid(tiles_m * tiles_n), blk(64 * WM * WN);
   static const int deep_max = [] { const char* e = getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
   if ((tiles_m * tiles_n <= deep_max || BM < 128) && !a.m_dev) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
@@ -593,7 +660,7 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0);
+  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
   const dim3 gr(tiles_m * tiles_n), bl(512);
   if (full && a.trace)
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
@@ -604,15 +671,16 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_h2(const GemmH2Args& a_in, hipStream_t s) {
+hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   GemmH2Args a = a_in;
   if (a.acc_scale == 0.f) a.acc_scale = 1.f;      // zero-initialised args mean "no scaling"
   if (a.plane_scale == 0.f) a.plane_scale = 1.f;
+  a_in.kernel_cls = RPR_K_GEMM_SMALL;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (force == 256 || (force == 0 && t256 >= 112)) return launch_256(a, s);
+  if (force == 256 || (force == 0 && t256 >= 112)) { a_in.kernel_cls = RPR_K_GEMM; return launch_256(a, s); }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
   static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 400; }();   // max rows (measured: 320 rows 53 vs 76 ms per search, 640 rows 86 vs 77)
@@ -630,22 +698,29 @@ hipError_t launch_gemm_h2(const GemmH2Args& a_in, hipStream_t s) {
 
 // fp32 [rows, cols] -> two f16 planes [2][rows][cols] (weights at load time, generic activations)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __half* __restrict__ out,
-                                                            size_t n, size_t plane_stride, float scale) {
+                                                            size_t n, size_t plane_stride, float scale,
+                                                            const float* __restrict__ colscale, int cols,
+                                                            unsigned int* sat) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
-  const float4 v = *reinterpret_cast<const float4*>(x + i);
+  float4 v = *reinterpret_cast<const float4*>(x + i);
+  if (colscale) {   // cols % 4 == 0: the four elements stay inside one row
+    const float4 c = *reinterpret_cast<const float4*>(colscale + (i % (size_t)cols));
+    v.x *= c.x; v.y *= c.y; v.z *= c.z; v.w *= c.w;
+  }
   __half h[4], l[4];
-  split_f16(v.x * scale, h[0], l[0]); split_f16(v.y * scale, h[1], l[1]);
-  split_f16(v.z * scale, h[2], l[2]); split_f16(v.w * scale, h[3], l[3]);
+  split_f16(v.x * scale, h[0], l[0], sat); split_f16(v.y * scale, h[1], l[1], sat);
+  split_f16(v.z * scale, h[2], l[2], sat); split_f16(v.w * scale, h[3], l[3], sat);
   *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<uint2*>(h);
   *reinterpret_cast<uint2*>(out + plane_stride + i) = *reinterpret_cast<uint2*>(l);
 }
 
-hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s, float scale) {
+hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s, float scale,
+                               const float* colscale, int cols, unsigned int* sat) {
   if (n == 0) return hipSuccess;
-  if (n & 3) return hipErrorInvalidValue;
+  if ((n & 3) || (colscale && (cols <= 0 || (cols & 3)))) return hipErrorInvalidValue;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n, plane_stride,
-                     scale);
+                     scale, colscale, cols, sat);
   return hipGetLastError();
 }
 

@@ -14,10 +14,11 @@
 
 namespace rpr {
 
-__device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t idx, float4 v) {
+__device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t idx, float4 v, unsigned int* sat,
+                                              float scale = A_PLANE_SCALE) {
   __half h[4], l[4];   // activation planes hold x * A_PLANE_SCALE (common.h)
-  split_f16(v.x * A_PLANE_SCALE, h[0], l[0]); split_f16(v.y * A_PLANE_SCALE, h[1], l[1]);
-  split_f16(v.z * A_PLANE_SCALE, h[2], l[2]); split_f16(v.w * A_PLANE_SCALE, h[3], l[3]);
+  split_f16(v.x * scale, h[0], l[0], sat); split_f16(v.y * scale, h[1], l[1], sat);
+  split_f16(v.z * scale, h[2], l[2], sat); split_f16(v.w * scale, h[3], l[3], sat);
   *reinterpret_cast<uint2*>(out_h + idx) = *reinterpret_cast<uint2*>(h);
   *reinterpret_cast<uint2*>(out_h + o_ps + idx) = *reinterpret_cast<uint2*>(l);
 }
@@ -43,7 +44,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ out, int rows, int d, float eps,
                                                        float post_scale, __half* __restrict__ out_h, size_t o_ps,
-                                                       const int* __restrict__ rows_dev) {
+                                                       const int* __restrict__ rows_dev, unsigned int* sat) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows || (rows_dev && row >= *rows_dev)) return;
   const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
@@ -62,37 +63,53 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     float4 o = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
     if (post_scale != 1.0f) { o.x *= post_scale; o.y *= post_scale; o.z *= post_scale; o.w *= post_scale; }
     if (out) orow[i] = o;
-    if (out_h) store_planes4(out_h, o_ps, (size_t)row * d + 4 * (size_t)i, o);
+    if (out_h) store_planes4(out_h, o_ps, (size_t)row * d + 4 * (size_t)i, o, sat);
   }
 }
 
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale, __half* out_h, size_t o_ps, const int* rows_dev) {
+                          float post_scale, __half* out_h, size_t o_ps, const int* rows_dev, unsigned int* sat) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale, out_h, o_ps,
-                     rows_dev);
+                     rows_dev, sat);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ embeddings
+// One wave copies an embedding row into the residual stream; with the fused RMSNorm (XOut) it also emits the row's
+// f16 planes and its fixed-point sum of squares (the wave owns the whole row: plain store, no atomic).
+__device__ __forceinline__ void copy_row_x(const float4* __restrict__ src, float* __restrict__ out, int row, int d,
+                                           int lane, const XOut& xo) {
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
+  float ss = 0.f;
+  for (int i = lane; i < (d >> 2); i += 64) {
+    const float4 v = src[i];
+    dst[i] = v;
+    if (xo.x_h) store_planes4(xo.x_h, xo.x_ps, (size_t)row * d + 4 * (size_t)i, v, xo.sat, X_PLANE_SCALE);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (xo.ssq) {
+    ss = wave_sum(ss);
+    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss);
+  }
+}
+
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                                           float* __restrict__ out, int rows, int d, int vocab,
                                                           const int32_t* __restrict__ row_src,
-                                                          const int* __restrict__ rows_dev) {
+                                                          const int* __restrict__ rows_dev, XOut xo) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows || (rows_dev && row >= *rows_dev)) return;
   int id = ids[row_src ? row_src[row] : row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * d);
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
-  for (int i = lane; i < (d >> 2); i += 64) dst[i] = src[i];
+  copy_row_x(reinterpret_cast<const float4*>(table + (size_t)id * d), out, row, d, lane, xo);
 }
 
 hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out, int rows, int d, int vocab,
-                             hipStream_t s, const int32_t* row_src, const int* rows_dev) {
+                             hipStream_t s, const int32_t* row_src, const int* rows_dev, XOut xo) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(embed_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, out, rows, d, vocab, row_src,
-                     rows_dev);
+                     rows_dev, xo);
   return hipGetLastError();
 }
 
@@ -141,7 +158,7 @@ hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src
 // position 0 is the constant start_token_embed, position t>=1 is list_decoder_embeds[t-1][token_t].
 __global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict__ start, const float* __restrict__ in_embeds,
                                                          const uint16_t* __restrict__ tokens, int tok_ld,
-                                                         float* __restrict__ out, int R, int d, int V, int t) {
+                                                         float* __restrict__ out, int R, int d, int V, int t, XOut xo) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const float* src = start;
@@ -149,15 +166,13 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict_
     const int tok = tokens[(size_t)row * tok_ld + (t - 1)];
     src = in_embeds + ((size_t)(t - 1) * V + tok) * d;
   }
-  const float4* s4 = reinterpret_cast<const float4*>(src);
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
-  for (int i = lane; i < (d >> 2); i += 64) dst[i] = s4[i];
+  copy_row_x(reinterpret_cast<const float4*>(src), out, row, d, lane, xo);
 }
 
 hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
-                            float* out, int R, int d, int V, int t, hipStream_t s) {
+                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo) {
   hipLaunchKernelGGL(dec_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, s, start, in_embeds, tokens, tok_ld, out,
-                     R, d, V, t);
+                     R, d, V, t, xo);
   return hipGetLastError();
 }
 
@@ -209,7 +224,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
         acc = fmaf(qd, kr[d], acc);
       }
       float s = -INFINITY;
-      if (j < nrow && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
+      if (a.causal) { if (j <= i) s = acc + Bs[a.bucket[i - j]]; }   // teacher-forced decoder: rel = j - i <= 0, table[n = i - j]
+      else if (j < nrow && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
       sc[c] = s;
       mx = fmaxf(mx, s);
     }
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     const size_t oidx = (row0 + i) * inner + h * DKV + lane;
     if (a.out_h) {
       __half hi, lo;
-      split_f16(o * A_PLANE_SCALE, hi, lo);
+      split_f16(o * A_PLANE_SCALE, hi, lo, a.sat);
       a.out_h[oidx] = hi;
       a.out_h[a.o_ps + oidx] = lo;
     } else {
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
                                                         float* __restrict__ out, int Q, int B, int H, int t, int Lq,
                                                         int xld, __half* __restrict__ out_h, size_t o_ps,
                                                         size_t q_stride, size_t h_stride, size_t pos_stride,
-                                                        size_t slot_stride) {
+                                                        size_t slot_stride, unsigned int* sat) {
   __shared__ float Ss[4][MAX_LQ];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   }
   if (g == 0) {
     const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
-    if (out_h) store_planes4(out_h, o_ps, oidx, acc);
+    if (out_h) store_planes4(out_h, o_ps, oidx, acc, sat);
     else *reinterpret_cast<float4*>(out + oidx) = acc;
   }
 }
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   }
   if (g == 0) {
     const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
-    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, acc);
+    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, acc, a.sat);
     else *reinterpret_cast<float4*>(a.out + oidx) = acc;
   }
 }
@@ -475,7 +491,7 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
                      a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps,
-                     a.q_stride, a.h_stride, a.pos_stride, a.slot_stride);
+                     a.q_stride, a.h_stride, a.pos_stride, a.slot_stride, a.sat);
   return hipGetLastError();
 }
 
@@ -506,7 +522,18 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   // keys at and beyond the last attended position are padding: every loop runs over that prefix only
   // (queries are padded to the batch maximum, typically 2-3x their own length); a.last[q] is computed
   // once per search. All global loads of the block are issued back to back before the first wait.
-  const int Lq = max(1, a.last[qi]);
+  const int Lq = a.last[qi];
+  if (Lq == 0) {   // query without a single attended token (reported through the ctx status word by mask_lengths_kernel):
+                   // its packed encoder has no rows — write zeros instead of reading a neighbour's K/V
+    for (int item = tid; item < B * 16; item += 256) {
+      const int b = item >> 4, c = (item & 15) * 4;
+      const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, z, a.sat);
+      else *reinterpret_cast<float4*>(a.out + oidx) = z;
+    }
+    return;
+  }
   constexpr int PF = 2;  // float4 K and V items per thread held in registers (covers Lq <= 32 rows)
   float4 pk[PF], pv[PF];
 #pragma unroll
@@ -581,7 +608,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
     const float inv = 1.0f / sum;
     o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
     const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c;
-    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, o);
+    if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, o, a.sat);
     else *reinterpret_cast<float4*>(a.out + oidx) = o;
   }
 }
@@ -611,16 +638,18 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   return hipGetLastError();
 }
 
-__global__ void mask_lengths_kernel(const int32_t* __restrict__ mask, int32_t* __restrict__ lens, int Q, int Lq) {
+__global__ void mask_lengths_kernel(const int32_t* __restrict__ mask, int32_t* __restrict__ lens, int Q, int Lq,
+                                    unsigned int* status) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
   int n = 0;  // index of the last attended key + 1 (the mask need not be a prefix)
   for (int j = 0; j < Lq; ++j) if (mask[(size_t)q * Lq + j] != 0) n = j + 1;
   lens[q] = n;
+  if (n == 0 && status) *status = 1u;   // benign race: every writer stores 1
 }
 
-hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s) {
-  hipLaunchKernelGGL(mask_lengths_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, mask, lens, Q, Lq);
+hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s, unsigned int* status) {
+  hipLaunchKernelGGL(mask_lengths_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, mask, lens, Q, Lq, status);
   return hipGetLastError();
 }
 

@@ -14,15 +14,15 @@ import torch
 import torch.distributed as dist
 
 
-def all_gather_results(qids: torch.Tensor, tokens: torch.Tensor, scores: torch.Tensor,
-                       row_lo: torch.Tensor, row_hi: torch.Tensor) -> Tuple[torch.Tensor, ...]:
-    """Each input is this rank's shard with identical leading size on every rank.
-    Returns the concatenation over ranks (rank-major) of every tensor."""
+def all_gather_results(*tensors: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+    """Each input is this rank's shard (e.g. qids, tokens, scores, row_lo, row_hi — callers pass only what
+    they consume) with identical leading size on every rank. Returns the concatenation over ranks
+    (rank-major) of every tensor, in the order given."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return qids, tokens, scores, row_lo, row_hi
+        return tuple(tensors)
     world = dist.get_world_size()
     outs = []
-    for t in (qids, tokens, scores, row_lo, row_hi):
+    for t in tensors:
         t = t.contiguous()
         buf = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(buf, t)  # concatenated along dim 0, rank-major

@@ -58,6 +58,14 @@ class Context:
     def workspace_bytes(self) -> int:
         return int(self.lib.rpr_workspace_bytes(self.handle))
 
+    def status(self, clear: bool = True) -> int:
+        """Synchronises the current stream and returns the sticky status flags of the work enqueued so far
+        (``_lib.STATUS_SATURATED``: an activation left the f16 plane range in f16x2 mode and was clamped — the results
+        since the last clear must be recomputed in 'f32' precision; ``_lib.STATUS_EMPTY_QUERY``)."""
+        out = C.c_uint32(0)
+        check(self.lib.rpr_get_status(self.handle, _stream_ptr(self.device), C.byref(out), 1 if clear else 0), "rpr_get_status")
+        return int(out.value)
+
     # -- profiling (bench.py roofline leg) --
     def profile_enable(self, on: bool):
         check(self.lib.rpr_profile_enable(self.handle, 1 if on else 0), "rpr_profile_enable")
@@ -211,6 +219,8 @@ class DeviceModel:
         check(ctx.lib.rpr_load_model(ctx.handle, C.byref(d), C.byref(h)), "rpr_load_model")
         self.handle = h
         self.L, self.V, self.d_model = L, V, cfg.d_model
+        # a weight outside the range of the f16 planes pins the model to the exact-fp32 kernels (rpr_load_model)
+        self.f32_only = bool(ctx.lib.rpr_model_f32_only(h))
 
     def __del__(self):
         try:
@@ -315,9 +325,12 @@ def search(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attent
             step_logits=torch.empty((L, Q * B, model.V), dtype=torch.float32, device=dev),
             step_scores=torch.empty((L, Q, B), dtype=torch.float64, device=dev),
             step_tokens=torch.empty((L, Q, B), dtype=torch.int32, device=dev),
-            step_parent=torch.empty((L, Q, B), dtype=torch.int32, device=dev))
+            step_parent=torch.empty((L, Q, B), dtype=torch.int32, device=dev),
+            # bit (beam*V + token) of word [t, q, (beam*V + token) // 64]: token is a trie child of the beam (uint64 bits)
+            step_valid=torch.zeros((L, Q, B * model.V // 64), dtype=torch.int64, device=dev))
         tap_struct = _lib.DebugTaps(*[tap_out[k].data_ptr() for k in
-                                      ("encoder_out", "step_logits", "step_scores", "step_tokens", "step_parent")])
+                                      ("encoder_out", "step_logits", "step_scores", "step_tokens", "step_parent",
+                                       "step_valid")])
     check(ctx.lib.rpr_search(ctx.handle, model.handle, trie.handle, ids.data_ptr(), mask.data_ptr(), Q, Lq, B, L, flags,
                              tokens.data_ptr(), scores.data_ptr(), lo.data_ptr(), hi.data_ptr(),
                              C.byref(tap_struct) if tap_struct is not None else None, _stream_ptr(dev)), "rpr_search")

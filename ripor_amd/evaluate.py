@@ -100,10 +100,19 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                         for docid in smtid_to_docids[smtid]:
                             cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
     if gather:
-        qids = torch.cat([k[0] for k in kept]); lo = torch.cat([k[1] for k in kept])
-        hi = torch.cat([k[2] for k in kept]); sc = torch.cat([k[3] for k in kept])
-        qids, _, sc, lo, hi = all_gather_results(qids, lo, sc, lo, hi)       # equal shard sizes (wrap-around padding)
+        gdev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if kept:
+            qids = torch.cat([k[0] for k in kept]); lo = torch.cat([k[1] for k in kept])
+            hi = torch.cat([k[2] for k in kept]); sc = torch.cat([k[3] for k in kept])
+        else:   # a rank whose shard is empty (fewer queries than ranks cannot happen with wrap-around padding,
+                # but an empty collection can): zero-size tensors keep the collective well-formed
+            qids = torch.zeros((0,), dtype=torch.long, device=gdev); lo = torch.zeros((0, topk), dtype=torch.long, device=gdev)
+            hi = torch.zeros((0, topk), dtype=torch.long, device=gdev); sc = torch.zeros((0, topk), dtype=torch.float32, device=gdev)
+        qids, sc, lo, hi = all_gather_results(qids, sc, lo, hi)       # equal shard sizes (wrap-around padding)
         if dist.get_rank() == 0:
+            # leftovers of an earlier per-rank run would make merge_runs prefer them over the gathered file
+            for stale in [p for p in os.listdir(out_dir) if p.startswith("run_") and p.endswith(".json")]:
+                os.remove(os.path.join(out_dir, stale))
             perm = prefix_constrain_processor.trie(device).perm
             rankdata_from_ranges(qids.cpu().tolist(), lo.cpu().tolist(), hi.cpu().tolist(), sc.cpu().tolist(), perm,
                                  smtid_to_docids.docids, max_new_token, apply_log_softmax_for_scores, into=qid_to_rankdata)
@@ -426,6 +435,8 @@ def evaluate(args):
     eval_metric = args.eval_metric
     if isinstance(eval_metric, (list, tuple)) and len(eval_metric) == 1 and isinstance(eval_metric[0], str):
         eval_metric = json.loads(eval_metric[0])
+    if len(eval_metric) < len(eval_qrel_path):   # zip() would silently drop the qrels without a metric list
+        raise ValueError(f"--eval_metric has {len(eval_metric)} entries for {len(eval_qrel_path)} --eval_qrel_path files")
     res_all: Dict[str, dict] = {}
     for qrel_file_path, metrics in zip(eval_qrel_path, eval_metric):
         if qrel_file_path is None:
@@ -452,7 +463,10 @@ def get_args(argv=None):
     ap.add_argument("--docid_to_smtid_path", default=None)
     ap.add_argument("--q_collection_paths", nargs="+", default=[])
     ap.add_argument("--eval_qrel_path", nargs="+", default=[])
-    ap.add_argument("--eval_metric", nargs="+", default=[["mrr_10", "recall"]])
+    # reference arguments.py:170-175: one metric list per entry of the stock --eval_qrel_path (MSMARCO dev,
+    # TREC-DL 2019 graded / binary, TREC-DL 2020 graded / binary)
+    ap.add_argument("--eval_metric", nargs="+", default=[["mrr_10", "recall"], ["ndcg_cut"], ["mrr_10", "recall"],
+                                                          ["ndcg_cut"], ["mrr_10", "recall"]])
     ap.add_argument("--batch_size", type=int, default=64)
     ap.add_argument("--gather_results", type=int, default=1,
                     help="multi-process runs: 1 = one RCCL all_gather, rank 0 writes run.json; 0 = run_{rank}.json files")

@@ -156,8 +156,27 @@ def generate_for_constrained_prefix_beam_search(
 
     em = model.engine_model()
     trie = valid_smtids.trie(model.device)
+    ctx = em.ctx
+    ctx.status(clear=True)
     res = E.search(em, trie, input_ids, attention_mask, num_beams, L,
                    apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
+    # Saturation guard (the reference call is synchronous too: it syncs >= 2*B*Q times per step). The split-precision
+    # GEMMs carry activations in f16 planes; a value outside their range is clamped and flagged on the device, and the
+    # call is then repeated on the exact-fp32 MFMA path instead of returning rankings computed from clipped tensors.
+    st = ctx.status(clear=True)
+    if st & E._lib.STATUS_EMPTY_QUERY:
+        raise ValueError("a query has an all-zero attention_mask (no token to attend to)")
+    if (st & E._lib.STATUS_SATURATED) and ctx.get_precision() != "f32":
+        import warnings
+        warnings.warn("activation outside the f16 plane range of the split-precision GEMMs: repeating this batch with "
+                      "exact fp32 MFMA (RPR_PRECISION=f32 avoids the retry)")
+        ctx.set_precision("f32")
+        try:
+            res = E.search(em, trie, input_ids, attention_mask, num_beams, L,
+                           apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
+            ctx.status(clear=True)
+        finally:
+            ctx.set_precision("f16x2")
     Q, B, K = input_ids.shape[0], num_beams, num_return_sequences
     tok = res.tokens[:, :K, :].to(torch.long)
     seqs = torch.cat([torch.zeros((Q, K, 1), dtype=torch.long, device=tok.device), tok], dim=2).reshape(Q * K, L + 1)

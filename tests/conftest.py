@@ -17,7 +17,12 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """Search fixtures (g*). The training-step fixtures (f4_*) are listed by train_golden_names()."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("g"))
+
+
+def train_golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("f4_"))
 
 
 class Golden:
@@ -58,27 +63,78 @@ class Golden:
     def sequences_scores(self):
         return self.z["sequences_scores"]
 
-    def step_margins(self):
-        """Per query: the smallest gap between consecutive candidates among the sorted top-(B+1)
-        cumulative scores over all steps, recomputed from the reference's per-step processed scores.
-        A tiny margin means fp32 summation-order noise may legitimately reorder/replace beams."""
-        if "step_scores" not in self.z.files:
-            return None
-        ss = self.z["step_scores"]  # [L, Q*B, V] float64 = logits + (1-mask)*(-1e9)
-        Q, B, V = self.Q, self.B, self.V
-        beam = np.zeros((Q, B), dtype=np.float64)
-        beam[:, 1:] = np.float32(-1e9)
-        margins = np.full(Q, np.inf)
-        for t in range(ss.shape[0]):
-            cand = (ss[t].reshape(Q, B, V) + beam[:, :, None]).reshape(Q, B * V)
-            order = np.argsort(-cand, axis=1, kind="stable")[:, : B + 1]
-            top = np.take_along_axis(cand, order, axis=1)
-            gaps = top[:, :-1] - top[:, 1:]
-            live = top[:, :-1] > -1e8  # gaps among dead (-1e9) candidates are irrelevant
-            gaps = np.where(live, gaps, np.inf)
-            margins = np.minimum(margins, gaps.min(axis=1))
-            beam = top[:, :B]
-        return margins
+
+SCORE_TOL = 1e-4          # north_star: beam scores within 1e-4
+ORDER_TOL = 2 * SCORE_TOL  # two final scores closer than this may legitimately come out in either order
+PRUNE_TOL = 1e-3          # cumulative float64 scores at the pruning boundary (rank B-1 vs rank B of a step)
+
+
+def prune_margins(g):
+    """Per query: (smallest gap over the steps between the last kept candidate (rank B-1) and the first dropped
+    one (rank B) of the reference's sorted candidates, number of steps whose gap is below PRUNE_TOL). Only these
+    gaps decide WHICH sequences survive; gaps between kept candidates only permute slots. Dead candidates
+    (-1e9 mask / initial beam scores) are not competitors."""
+    ts = g.z["top_scores"]                      # [L, Q, min(B+1, B*V)] float64, sorted desc
+    B = g.B
+    if ts.shape[2] <= B:
+        return np.full(g.Q, np.inf), np.zeros(g.Q, dtype=int)
+    gap = ts[:, :, B - 1] - ts[:, :, B]
+    gap = np.where(ts[:, :, B] > -1e8, gap, np.inf)
+    return gap.min(axis=0), (gap < PRUNE_TOL).sum(axis=0)
+
+
+def compare_ranked(g, tokens, scores, label=""):
+    """Parity of one search result ([Q,B,L] tokens, [Q,B] float32 scores) with the reference's golden output.
+
+    For every query:
+      * the SET of returned smtid sequences must equal the reference's, unless the reference itself dropped a
+        candidate by less than PRUNE_TOL at some step (then at most that many sequences may differ);
+      * every sequence present in both carries the reference's score within SCORE_TOL;
+      * at every rank whose reference score is more than ORDER_TOL away from both neighbours the token sequence
+        must be identical (ranks inside a near-tie may swap).
+    Returns a dict of counts; raises AssertionError with the offending query/rank. A fixture whose queries are ALL
+    boundary-excused fails: such a fixture pins nothing."""
+    Q, B, L = g.Q, g.B, g.L
+    exp_tok = g.sequences.reshape(Q, B, L + 1)
+    assert (exp_tok[:, :, 0] == 0).all()
+    exp_tok = exp_tok[:, :, 1:]
+    exp_sc = g.sequences_scores.reshape(Q, B).astype(np.float64)
+    margins, near = prune_margins(g)
+    stats = dict(queries=Q, boundary_excused=0, ranks_checked=0, ranks_in_near_tie=0, sequences_missing=0,
+                 max_score_err=0.0)
+    for q in range(Q):
+        ref = {tuple(int(x) for x in exp_tok[q, r]): r for r in range(B)}
+        got = {tuple(int(x) for x in tokens[q, r]): r for r in range(B)}
+        assert len(got) == B or len(ref) < B, f"{g.name}{label} query {q}: duplicate sequences among the beams"
+        missing = [s for s in ref if s not in got]
+        allowed = int(near[q])
+        if allowed:
+            stats["boundary_excused"] += 1
+        assert len(missing) <= allowed, (
+            f"{g.name}{label} query {q}: {len(missing)} reference sequences missing from the result, "
+            f"{allowed} allowed (pruning margin {margins[q]:.3g})")
+        stats["sequences_missing"] += len(missing)
+        for s, r in ref.items():
+            if s in got:
+                err = abs(float(scores[q, got[s]]) - exp_sc[q, r])
+                stats["max_score_err"] = max(stats["max_score_err"], err)
+                assert err <= SCORE_TOL, f"{g.name}{label} query {q} ref rank {r}: score differs by {err:.3g}"
+        if missing:
+            continue   # ranks are shifted by the replaced sequences; the set/score checks above still held
+        for r in range(B):
+            up = exp_sc[q, r - 1] - exp_sc[q, r] if r > 0 else np.inf
+            dn = exp_sc[q, r] - exp_sc[q, r + 1] if r + 1 < B else np.inf
+            if min(up, dn) > ORDER_TOL:
+                stats["ranks_checked"] += 1
+                assert (tokens[q, r] == exp_tok[q, r]).all(), (
+                    f"{g.name}{label} query {q} rank {r}: tokens differ although the reference score is "
+                    f"{min(up, dn):.3g} away from its neighbours")
+            else:
+                stats["ranks_in_near_tie"] += 1
+    assert stats["boundary_excused"] < Q or Q == 0, (
+        f"{g.name}{label}: every query sits on a pruning near-tie; the fixture pins nothing — regenerate it")
+    print(f"[parity] {g.name}{label}: {stats}")
+    return stats
 
 
 @pytest.fixture(scope="session")

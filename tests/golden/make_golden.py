@@ -339,6 +339,26 @@ def run_reference(gen, utils, shim, model, processor, input_ids, attention_mask,
     return enc.numpy(), out.sequences.numpy(), out.sequences_scores.numpy(), strs, step_scores
 
 
+def replay_top(step_scores, Q, B, V):
+    """Per step and query: the reference's sorted top-(B+1) cumulative candidates (float64 score, flat index
+    beam*V + token), recomputed from its per-step processed scores exactly as generation.py:457-492 combines
+    them (processed + beam_scores, beam_scores init [0, -1e9, ...] float32, :418-420). Rank B (0-based) is the
+    first candidate that did NOT become a beam: tests use the gap between ranks B-1 and B as the pruning margin."""
+    L = step_scores.shape[0]
+    K = min(B + 1, B * V)
+    beam = np.zeros((Q, B), dtype=np.float64)
+    beam[:, 1:] = np.float32(-1e9)
+    ts = np.zeros((L, Q, K), dtype=np.float64)
+    ti = np.zeros((L, Q, K), dtype=np.int32)
+    for t in range(L):
+        cand = (step_scores[t].reshape(Q, B, V) + beam[:, :, None]).reshape(Q, B * V)
+        order = np.argsort(-cand, axis=1, kind="stable")[:, :K]
+        ts[t] = np.take_along_axis(cand, order, axis=1)
+        ti[t] = order
+        beam = ts[t][:, :B]
+    return ts, ti
+
+
 def reference_trie(gen, codes):
     """Build the reference's own structures from the synthetic code matrix, with the reference's
     dict-building loop restated (evaluate.py:410-424 cannot be imported: top-level `import faiss`)."""
@@ -364,9 +384,23 @@ CASES = {
     "g1_mini_b4_l8_shared": dict(kind="mini", N=500, Q=4, B=4, L=8, V=256, seed=106, shared=True),
     "g2_base_b10_l32": dict(kind="base", N=1000, Q=4, B=10, L=32, V=256, seed=201),
     # t5-large decoder shape (24 layers, 16 heads, d=1024 are forced by the reference ctor), B=100 top-k stress
-    "g3_large_b100_l16": dict(kind="large", N=3000, Q=2, B=100, L=16, V=256, seed=301),
-    # BASELINE config 4 exactly: t5-large decoder, beam 100, len 32 (one query keeps the fixture small)
-    "g3_large_b100_l32": dict(kind="large", N=3000, Q=1, B=100, L=32, V=256, seed=302),
+    "g3_large_b100_l16": dict(kind="large", N=3000, Q=4, B=100, L=16, V=256, seed=301),
+    # BASELINE config 4 exactly: t5-large decoder, beam 100, len 32; four queries so that the per-rank parity
+    # test (tests/test_gpu_parity.py) keeps its force even if one query sits on a pruning near-tie
+    "g3_large_b100_l32": dict(kind="large", N=3000, Q=4, B=100, L=32, V=256, seed=302),
+    # BASELINE config 1 at its stated shape: t5-base dims, 1k-doc trie, beam 1 (greedy), 64 queries. HF 4.17's
+    # BeamSearchScorer refuses num_beams <= 1, so the restated scorer is allowed a single beam
+    # here; everything else (model forward, processor, beam loop) is the imported reference.
+    "g4_base_b1_l32_q64": dict(kind="base", N=1000, Q=64, B=1, L=32, V=256, seed=401, single_beam=True),
+}
+
+# SURVEY §8 row f4 (BASELINE config 5): T5SeqAQEncoderForLngKnpMarginMSE.forward on a seeded batch
+# (reference modeling/t5_generative_retriever.py:902-966). smtid length 8 / 16 / 32 -> 2 / 3 / 4 losses.
+TRAIN_CASES = {
+    "f4_mini_bz6_l32": dict(kind="mini", bz=6, L=32, V=256, seed=501),
+    "f4_mini_bz4_l16": dict(kind="mini", bz=4, L=16, V=256, seed=502),
+    "f4_mini_bz4_l8": dict(kind="mini", bz=4, L=8, V=256, seed=503),
+    "f4_base_bz4_l32": dict(kind="base", bz=4, L=32, V=256, seed=504),
 }
 
 
@@ -389,8 +423,12 @@ def make_case(name, spec, gen, mod, utils, shim):
     d2s, lst = reference_trie(gen, codes)
     processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
     ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=20)
+    global ALLOW_SINGLE_BEAM
+    ALLOW_SINGLE_BEAM = bool(spec.get("single_beam", False))
     enc, seqs, scores, strs, step_scores = run_reference(
         gen, utils, shim, model, processor, ids, mask, B, L, spec.get("log_softmax", False))
+    ALLOW_SINGLE_BEAM = False
+    top_scores, top_idx = replay_top(step_scores, Q, B, V)
     # processor-only vectors (G4): valid and invalid prefixes at a few depths
     pm = {}
     for T in sorted({1, 2, min(3, L), L}):
@@ -411,9 +449,10 @@ def make_case(name, spec, gen, mod, utils, shim):
         input_ids=ids, attention_mask=mask, codes=codes,
         encoder_out=enc.astype(np.float32), sequences=seqs.astype(np.int64),
         sequences_scores=scores.astype(np.float32), smtid_strings=np.array(strs),
+        top_scores=top_scores, top_idx=top_idx,
         **pm,
     )
-    if step_scores.size <= 4_000_000:
+    if step_scores.size <= 500_000:   # larger cases keep the compact per-step top-(B+1) record only
         out["step_scores"] = step_scores
     else:
         out["step_scores_first"] = step_scores[:2]
@@ -423,6 +462,64 @@ def make_case(name, spec, gen, mod, utils, shim):
     print(f"[golden] {name}: {time.time() - t0:.1f}s -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+TEACHER_KEYS = {8: ["", "smtid_4_"], 16: ["", "smtid_4_", "smtid_8_"], 32: ["", "smtid_4_", "smtid_8_", "smtid_16_"]}
+
+
+def train_batch(name, dims, bz, L, V, seed):
+    """Seeded batch in the layout LngKnpMarginMSEforT5SeqAQCollator emits (reference dataset/data_collator.py:11-88;
+    dataset/dataset.py:488-500: doc encoding = smtid[1:], decoder_input_ids = smtid[:-1] with smtid[0] = -1; the
+    positive and the negative example of a row carry the same query text)."""
+    ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=seed, max_len=20)
+    codes = synth.make_codes(2 * bz, L, V, seed=seed).astype(np.int64)
+    pos, neg = codes[:bz], codes[bz:]
+    neg[:, :2] = pos[:, :2]          # hard negatives share a prefix with the positive, like beam-search rank data
+    teacher = {}
+    for k in TEACHER_KEYS[L]:
+        for side in ("pos", "neg"):
+            teacher[f"{k}teacher_{side}_scores"] = synth.uniform_f32(f"train/{name}/{k}{side}", (bz,), 30.0, seed)
+    return ids, mask, pos, neg, teacher
+
+
+@torch.no_grad()
+def make_train_case(name, spec, gen, mod, utils, shim):
+    kind, bz, L, V, seed = spec["kind"], spec["bz"], spec["L"], spec["V"], spec["seed"]
+    dims = synth.mini_dims(L=L, V=V) if kind == "mini" else synth.t5_base_dims(L=L, V=V, vocab_size=2048)
+    t0 = time.time()
+    sd = synth.make_state_dict(dims, seed=seed)
+    base = build_reference_model(mod, dims, sd)
+    base.config.decoding = False      # T5SeqAQEncoder.__init__ (t5_generative_retriever.py:774): no logits in training
+    Cls = mod.T5SeqAQEncoderForLngKnpMarginMSE
+    m = Cls.__new__(Cls)              # the ctor only loads a checkpoint dir; the forward below is the reference's own
+    torch.nn.Module.__init__(m)
+    m.base_model, m.config, m.loss_fn = base, base.config, torch.nn.MSELoss()
+    m.eval()
+    ids, mask, pos, neg, teacher = train_batch(name, dims, bz, L, V, seed)
+    start = np.full((bz, 1), -1, dtype=np.int64)
+
+    def tq(codes):
+        return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask),
+                "decoder_input_ids": torch.from_numpy(np.concatenate([start, codes[:, :-1]], axis=1))}
+
+    inputs = {"pos_tokenized_query": tq(pos), "neg_tokenized_query": tq(neg),
+              "pos_doc_encoding": torch.from_numpy(pos), "neg_doc_encoding": torch.from_numpy(neg)}
+    inputs.update({k: torch.from_numpy(v) for k, v in teacher.items()})
+    losses = m(**inputs)
+    # per-position student scores from the reference's own hidden states and codebooks (diagnostic granularity)
+    ph = base(**tq(pos)).decoder_last_hidden_state
+    nh = base(**tq(neg)).decoder_last_hidden_state
+    pos_pp = (ph * m.decode(torch.from_numpy(pos))).sum(-1).numpy()
+    neg_pp = (nh * m.decode(torch.from_numpy(neg))).sum(-1).numpy()
+    out = dict(spec=json.dumps(dict(spec, name=name, dims=dims.__dict__)), input_ids=ids, attention_mask=mask,
+               pos_doc_encoding=pos, neg_doc_encoding=neg, pos_position_scores=pos_pp.astype(np.float32),
+               neg_position_scores=neg_pp.astype(np.float32),
+               loss_names=np.array(sorted(losses.keys())),
+               losses=np.array([float(losses[k]) for k in sorted(losses.keys())], dtype=np.float64))
+    out.update(teacher)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: {time.time() - t0:.1f}s losses {dict((k, float(v)) for k, v in losses.items())} -> {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -430,9 +527,13 @@ def main():
     torch.manual_seed(0)
     gen, mod, utils, shim = load_reference()
     for name, spec in CASES.items():
-        if args.only and args.only != name:
+        if args.only and args.only not in (name, "search"):
             continue
         make_case(name, spec, gen, mod, utils, shim)
+    for name, spec in TRAIN_CASES.items():
+        if args.only and args.only not in (name, "train"):
+            continue
+        make_train_case(name, spec, gen, mod, utils, shim)
 
 
 if __name__ == "__main__":

@@ -27,13 +27,13 @@ def test_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ripor_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.rpr_abi_version() == 1
+    assert lib.rpr_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_layout_matches_header():
     from ripor_amd import _lib
     assert C.sizeof(_lib.KernelStats) == 32
-    assert C.sizeof(_lib.DebugTaps) == 5 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.DebugTaps) == 6 * C.sizeof(C.c_void_p)
     # 12 int32 + float (52 bytes, padded to 56) + 9 + 15 pointers
     assert C.sizeof(_lib.ModelDesc) == 56 + 24 * 8
 

@@ -137,3 +137,39 @@ def test_cli_gathered_run_json_equals_single_process(tmp_path):
     ev.constrained_decode_doc(None, batches, _FakeProcessor(64), table, 4, "cpu", str(single_dir), 0, topk=B)
     single = ev.merge_runs(str(single_dir))
     assert json.loads(json.dumps(merged)) == json.loads(json.dumps(single)) and len(single) == N_QUERIES
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus N` must become N ranks ----------------------------------------
+def test_bench_gpus_flag_launches_n_ranks():
+    """The driver may call `python bench.py --gpus 8` without torchrun: the script then re-executes itself under
+    torch.distributed.run. RPR_BENCH_LAUNCH_ONLY stops after the rendezvous (no GPU here), gloo stands in for RCCL."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RPR_BENCH_LAUNCH_ONLY="1", RPR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["ranks_seen"] == [0, 1]
+    # a launcher that provides a different world size than --gpus is refused instead of mislabelled
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode != 0 and "refusing" in (r2.stderr + r2.stdout)
+
+
+def test_bench_launch_command():
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_command(1, {}, ["bench.py"]) is None
+    assert bench.launch_command(8, {"WORLD_SIZE": "8"}, ["bench.py", "--gpus", "8"]) is None
+    cmd = bench.launch_command(8, {}, ["bench.py", "--gpus", "8", "--steps", "3"])
+    assert "--nproc-per-node=8" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"]

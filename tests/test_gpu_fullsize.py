@@ -1,4 +1,5 @@
-"""-m gpu: the BASELINE-size configuration (t5-base dims, 8 841 823-doc trie, beam 10, len 32) checked
+"""-m gpu: the BASELINE-size configurations — config 2 (t5-base dims, 8 841 823-doc trie, beam 10, len 32) and
+config 4 (t5-large dims: d = 1024, d_ff = 4096, 24 + 24 layers, 16 heads; beam 100, len 32) — checked
 through size-independent properties — the oracle cannot run at this size:
   * every returned smtid is a leaf of the trie: its sorted-row range is non-empty and the code rows
     under it equal the returned tokens (mask/trie walk/beam expand are consistent over 32 levels);
@@ -15,26 +16,57 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-N_DOCS, L, V, B = 8_841_823, 32, 256, 10
+N_DOCS, L, V = 8_841_823, 32, 256
 
 
 @pytest.fixture(scope="module")
-def world():
+def big_trie():
     from ripor_amd import engine as E
     from ripor_amd.utils import synth
     ctx = E.Context.get(0)
-    dims = synth.t5_base_dims(L=L, V=V)
-    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
     codes = synth.make_codes_fast(N_DOCS, L, V)
-    trie = E.DeviceTrie.from_codes(ctx, codes, V)
-    ids, mask = synth.make_queries(48, vocab_size=dims.vocab_size, seed=11)
-    yield E, ctx, model, trie, codes, torch.from_numpy(ids), torch.from_numpy(mask)
+    return E.DeviceTrie.from_codes(ctx, codes, V), codes
+
+
+@pytest.fixture(scope="module", params=["t5-base", "t5-large"])
+def world(request, big_trie):
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    ctx = E.Context.get(0)
+    trie, codes = big_trie
+    if request.param == "t5-base":
+        dims, B, nq = synth.t5_base_dims(L=L, V=V), 10, 48
+    else:
+        dims, B, nq = synth.t5_large_dims(L=L, V=V), 100, 6
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+    ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=11)
+    yield E, ctx, model, trie, codes, torch.from_numpy(ids), torch.from_numpy(mask), B
     ctx.set_precision("f16x2")
+    del model
+    torch.cuda.empty_cache()
+
+
+def _same_ranked(tok_a, sc_a, tok_b, sc_b, what):
+    """Two runs of the same query through different tile kernels (a lone query takes the skinny GEMM, a batch the
+    256x256 one: different fp32 summation orders): same set of sequences, scores within 1e-4, identical tokens at
+    every rank whose score is more than 2e-4 away from its neighbours."""
+    B = tok_a.shape[0]
+    a = {tuple(x): r for r, x in enumerate(tok_a.tolist())}
+    b = {tuple(x): r for r, x in enumerate(tok_b.tolist())}
+    assert a.keys() == b.keys(), f"{what}: different sets of smtids"
+    for k, r in b.items():
+        assert abs(float(sc_a[a[k]]) - float(sc_b[r])) <= 1e-4, what
+    for r in range(B):
+        up = sc_b[r - 1] - sc_b[r] if r else np.inf
+        dn = sc_b[r] - sc_b[r + 1] if r + 1 < B else np.inf
+        if min(up, dn) > 2e-4:
+            assert (tok_a[r] == tok_b[r]).all(), f"{what}: rank {r} differs"
 
 
 def test_fullsize_properties(world):
-    E, ctx, model, trie, codes, ids, mask = world
+    E, ctx, model, trie, codes, ids, mask, B = world
     ctx.set_precision("f16x2")
+    ctx.status(clear=True)
     res = E.search(model, trie, ids, mask, B, L)
     torch.cuda.synchronize()
     tok = res.tokens.cpu().numpy()
@@ -48,20 +80,20 @@ def test_fullsize_properties(world):
             rows = trie.perm[lo[q, b]:hi[q, b]]
             assert (codes[rows] == tok[q, b][None, :]).all()
         assert len({tuple(t) for t in tok[q]}) == B, "duplicate smtid among the beams of a query"
+    assert ctx.status() == 0, "saturation flag raised at BASELINE size"
     # determinism of the cached graph
     res2 = E.search(model, trie, ids, mask, B, L)
     assert torch.equal(res.tokens, res2.tokens) and torch.equal(res.scores, res2.scores)
     # batch invariance (alone, padded to its own length bucket or to the batch's: same answer)
-    for q in (0, 7, 31):
+    for q in (0, 7, 31)[: 3 if ids.shape[0] > 31 else 1]:
         n = int(mask[q].sum())
         for width in (n, ids.shape[1]):
             r1 = E.search(model, trie, ids[q:q + 1, :width], mask[q:q + 1, :width], B, L)
-            assert np.array_equal(r1.tokens.cpu().numpy()[0], tok[q]), f"query {q} differs when searched alone"
-            np.testing.assert_allclose(r1.scores.cpu().numpy()[0], sc[q], atol=1e-4, rtol=0)
+            _same_ranked(r1.tokens.cpu().numpy()[0], r1.scores.cpu().numpy()[0], tok[q], sc[q], f"query {q} searched alone")
 
 
 def test_split_precision_agrees_with_exact_fp32(world):
-    E, ctx, model, trie, codes, ids, mask = world
+    E, ctx, model, trie, codes, ids, mask, B = world
     ctx.set_precision("f32")
     ref = E.search(model, trie, ids, mask, B, L, taps=True)
     torch.cuda.synchronize()
@@ -71,12 +103,26 @@ def test_split_precision_agrees_with_exact_fp32(world):
     rt, rs = ref.tokens.cpu().numpy(), ref.scores.cpu().numpy()
     tt, ts = res.tokens.cpu().numpy(), res.scores.cpu().numpy()
     step_scores = ref.taps["step_scores"].cpu().numpy()  # [L, Q, B] float64, sorted desc per step
-    excused = 0
+    diverged = 0
     for q in range(rt.shape[0]):
-        if np.array_equal(rt[q], tt[q]):
-            np.testing.assert_allclose(ts[q], rs[q], atol=1e-4, rtol=0)
-        else:
+        # same scheme as the golden comparison: set of sequences, per-sequence scores, exact tokens at every rank whose
+        # fp32-run score is more than 2e-4 from its neighbours. A query may only lose sequences if the fp32 run's own
+        # kept candidates came within 1e-3 of each other at some step (the (B+1)-th candidate is not tapped, so the
+        # smallest gap among the kept B stands in for the pruning margin — conservative for B = 10, where from depth 3
+        # on every beam has a single child and nothing is pruned).
+        ref_set = {tuple(x): r for r, x in enumerate(rt[q].tolist())}
+        got_set = {tuple(x): r for r, x in enumerate(tt[q].tolist())}
+        missing = [k for k in ref_set if k not in got_set]
+        if missing:
             gaps = -np.diff(step_scores[:, q, :], axis=1)
-            assert gaps.min() < 1e-3, f"query {q}: smtids differ although the fp32 run has no near-tie"
-            excused += 1
-    assert excused <= rt.shape[0] // 8, excused
+            assert gaps.min() < 1e-3, f"query {q}: smtid sets differ although the fp32 run has no near-tie"
+            diverged += 1
+            continue
+        for k, r in ref_set.items():
+            assert abs(float(ts[q, got_set[k]]) - float(rs[q, r])) <= 1e-4
+        for r in range(B):
+            up = rs[q, r - 1] - rs[q, r] if r else np.inf
+            dn = rs[q, r] - rs[q, r + 1] if r + 1 < B else np.inf
+            if min(up, dn) > 2e-4:
+                assert (tt[q, r] == rt[q, r]).all(), f"query {q} rank {r}"
+    assert diverged <= rt.shape[0] // 8, diverged

@@ -2,20 +2,21 @@
 against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): ranked smtid sequences bit-exact, beam scores within 1e-4.
-fp32 summation order differs between any two implementations, so an integer mismatch is accepted
-only for a query whose reference margin (gap between neighbouring candidates inside the top-(B+1)
-at some step) is below MARGIN_TOL, i.e. where the reference itself is one rounding away from a
-different answer; such queries are counted and must stay rare.
+fp32 summation order differs between any two implementations, so what "bit-exact" can mean is fixed by the
+reference's own numbers (tests/conftest.py::compare_ranked): the SET of returned sequences must be the reference's
+unless the reference itself dropped a candidate by < 1e-3 at some step (no committed fixture does: every pruning
+margin is > 2e-3, tests/test_oracle_golden.py::test_fixture_margins_are_comfortable); every sequence's score must
+match within 1e-4; the tokens at a rank must be identical whenever the reference's score at that rank is more than
+2e-4 away from both neighbours. The counts of checked / near-tie ranks are printed per fixture.
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names
+from conftest import ORDER_TOL, compare_ranked, golden_names
 
 SCORE_TOL = 1e-4     # north_star: beam scores within 1e-4
 LOGIT_TOL = 2e-3     # fp32 logits O(10..100) through 12-24 layers; reference-vs-KV-cached differs by ~3e-5
-MARGIN_TOL = 1e-3
 
 pytestmark = pytest.mark.gpu
 
@@ -42,42 +43,145 @@ def _run(E, g, model, trie, **kw):
     return res
 
 
-def _compare_to_golden(g, tokens, scores):
-    Q, B, L = g.Q, g.B, g.L
-    exp_tok = g.sequences.reshape(Q, B, L + 1)
-    assert (exp_tok[:, :, 0] == 0).all()
-    exp_tok = exp_tok[:, :, 1:]
-    exp_sc = g.sequences_scores.reshape(Q, B)
-    margins = g.step_margins()
-    excused = 0
-    for q in range(Q):
-        same = (tokens[q] == exp_tok[q]).all()
-        if same:
-            np.testing.assert_allclose(scores[q], exp_sc[q], atol=SCORE_TOL, rtol=0,
-                                       err_msg=f"{g.name} query {q}: beam scores differ")
-        else:
-            assert margins is not None and margins[q] < MARGIN_TOL, (
-                f"{g.name} query {q}: smtid sequences differ from the reference although its margin "
-                f"is {None if margins is None else margins[q]}")
-            excused += 1
-    return excused
-
-
 @pytest.mark.parametrize("name", golden_names())
 def test_search_matches_reference_golden(engine, golden_cache, name):
+    """Includes BASELINE config 4 (g3_large_b100_l32: t5-large decoder dims, beam 100, len 32, four queries) and
+    config 1 (g4_base_b1_l32_q64: t5-base dims, 1k-doc trie, beam 1, 64 queries)."""
     g = golden_cache(name)
     ctx, model, trie = _build(engine, g)
+    ctx.status(clear=True)
     res = _run(engine, g, model, trie)
+    assert ctx.status() == 0, "saturation / empty-query flag raised on a golden fixture"
     tokens = res.tokens.cpu().numpy()
     scores = res.scores.cpu().numpy()
-    excused = _compare_to_golden(g, tokens, scores)
-    assert excused <= max(1, g.Q // 4), f"{excused} of {g.Q} queries needed the near-tie excuse"
+    stats = compare_ranked(g, tokens, scores)
+    assert stats["boundary_excused"] == 0 and stats["sequences_missing"] == 0
+    assert stats["ranks_checked"] >= 0.9 * g.Q * g.B or "tiny_trie" in name, stats
     # eager (no graph) launches give the same bits as the graph replay
     res2 = _run(engine, g, model, trie, use_graph=False)
     assert torch.equal(res.tokens, res2.tokens) and torch.equal(res.scores, res2.scores)
     # second replay of the cached graph is deterministic
     res3 = _run(engine, g, model, trie)
     assert torch.equal(res.tokens, res3.tokens) and torch.equal(res.scores, res3.scores)
+    # exact-fp32 GEMM mode: same bar
+    ctx.set_precision("f32")
+    try:
+        res4 = _run(engine, g, model, trie)
+        compare_ranked(g, res4.tokens.cpu().numpy(), res4.scores.cpu().numpy(), label=" (exact fp32)")
+    finally:
+        ctx.set_precision("f16x2")
+
+
+def _unpack_valid(words, B, V):
+    """[Q, B*V/64] int64 (uint64 bit patterns) -> bool [Q, B, V]."""
+    w = words.astype(np.uint64)
+    bits = ((w[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)).astype(bool)
+    return bits.reshape(w.shape[0], B, V)
+
+
+def _check_select_taps(g, res, pm, label=""):
+    """The selection kernel against the reference's per-step record and the reference processor's masks:
+      * phase A (trie child mask): the bitmap select_kernel worked from at step t must equal the processor's mask of
+        the beams' own prefixes (reconstructed from the tapped tokens/parents — independent of the oracle's path);
+      * phases B-D (float64 combine, top-B, beam expand): wherever the reference's sorted top-(B+1) of a step has no
+        gap below ORDER_TOL, the (parent, token) of every new slot must equal the reference's candidate of that rank
+        and the cumulative float64 score must match to 1e-3 (fp32 logits summed over <= L steps)."""
+    Q, B, L, V = g.Q, g.B, g.L, g.V
+    tok = res.taps["step_tokens"].cpu().numpy()      # [L, Q, B]
+    par = res.taps["step_parent"].cpu().numpy()
+    ssc = res.taps["step_scores"].cpu().numpy()
+    val = res.taps["step_valid"].cpu().numpy()       # [L, Q, B*V/64]
+    ts, ti = g.z["top_scores"], g.z["top_idx"]
+    prefixes = np.zeros((Q, B, 1), dtype=np.int64)   # column 0 = start id
+    strict_steps = 0
+    follow = np.ones(Q, dtype=bool)                  # slot order still equals the reference's
+    for t in range(L):
+        # ---- phase A
+        got = _unpack_valid(val[t], B, V)
+        exp = pm(prefixes.reshape(Q * B, t + 1)).reshape(Q, B, V) > 0
+        if t == 0:   # beams 1..B-1 start dead (-1e9) on the same root prefix: the mask is the root's for all
+            assert (exp == exp[:, :1]).all()
+        assert (got == exp).all(), f"{g.name}{label} step {t}: select_kernel child bitmap differs from the processor mask"
+        # ---- phases B-D
+        K = ts.shape[2]
+        for q in range(Q):
+            if not follow[q]:
+                continue
+            live = ts[t, q] > -1e8
+            gaps = ts[t, q, :-1] - ts[t, q, 1:]
+            gaps = np.where(live[:-1] & live[1:], gaps, np.inf)
+            nb = min(B, K)
+            if gaps[:nb].min() > ORDER_TOL and live[:nb].all():
+                rb, rt = ti[t, q, :nb] // V, ti[t, q, :nb] % V
+                assert (par[t, q, :nb] == rb).all() and (tok[t, q, :nb] == rt).all(), (
+                    f"{g.name}{label} step {t} query {q}: selected (parent, token) differ from the reference")
+                np.testing.assert_allclose(ssc[t, q, :nb], ts[t, q, :nb], atol=1e-3, rtol=0)
+                strict_steps += 1
+            else:
+                follow[q] = False   # a near-tie (or dead candidates, whose order is a tie rule) may permute slots
+        prefixes = np.concatenate([np.take_along_axis(prefixes, par[t][:, :, None].astype(np.int64), axis=1),
+                                   tok[t][:, :, None].astype(np.int64)], axis=2)
+    print(f"[select] {g.name}{label}: {strict_steps} of {L * Q} (step, query) selections checked slot by slot")
+    return strict_steps
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith("g4_")])
+def test_select_kernel_mask_and_choices_match_reference(engine, golden_cache, name):
+    from oracle import beam_ref
+    g = golden_cache(name)
+    ctx, model, trie = _build(engine, g)
+    res = _run(engine, g, model, trie, taps=True)
+    d2s = {str(i): [-1] + [int(x) for x in row] for i, row in enumerate(g.codes)}
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), g.V)
+    strict = _check_select_taps(g, res, pm)
+    assert strict >= (g.L * g.Q) // 2 or "tiny_trie" in name or g.B >= 100, (strict, g.L * g.Q)
+
+
+def test_select_mask_at_the_narrow_wide_crossover(engine):
+    """select_kernel enumerates the children of ranges of <= 32 rows and binary-searches wider ones; V = 1024 takes
+    the 16-word bitmaps. A constructed trie puts beams on ranges of exactly 1, 31, 32, 33 and 34 rows at the same
+    step; bitmaps vs the oracle processor, results vs the oracle search."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd.utils import synth
+    E = engine
+    L, V, B = 4, 1024, 6
+    sizes = {3: 32, 500: 33, 1000: 31, 7: 34, 900: 1, 64: 40}      # first token -> docs below it
+    rows = []
+    for first, n in sizes.items():
+        sub = synth.randint(f"cross/{first}", (n, L - 1), 0, V, seed=5)
+        sub[:, 0] = (np.arange(n) * 29 + first) % V                  # distinct second tokens: every child is one doc
+        for r in sub:
+            rows.append([first] + [int(x) for x in r])
+    codes = np.asarray(rows, dtype=np.uint16)
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    sd = synth.make_state_dict(dims, seed=9)
+    ids, mask = synth.make_queries(5, vocab_size=dims.vocab_size, seed=9, max_len=14)
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L, taps=True)
+    torch.cuda.synchronize()
+    d2s = {str(i): [-1] + [int(x) for x in row] for i, row in enumerate(codes)}
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), V)
+    tok = res.taps["step_tokens"].cpu().numpy(); par = res.taps["step_parent"].cpu().numpy()
+    val = res.taps["step_valid"].cpu().numpy()
+    Q = ids.shape[0]
+    prefixes = np.zeros((Q, B, 1), dtype=np.int64)
+    range_sizes = set()
+    for t in range(L):
+        got = _unpack_valid(val[t], B, V)
+        exp = pm(prefixes.reshape(Q * B, t + 1)).reshape(Q, B, V) > 0
+        assert (got == exp).all(), f"step {t}"
+        prefixes = np.concatenate([np.take_along_axis(prefixes, par[t][:, :, None].astype(np.int64), axis=1),
+                                   tok[t][:, :, None].astype(np.int64)], axis=2)
+        if t == 0:
+            range_sizes = {sizes[int(x)] for x in tok[0].reshape(-1)}
+    assert range_sizes == set(sizes.values()), "every constructed range size must be on a beam at step 1"
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
+    assert (res.tokens.cpu().numpy() == seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:]).all()
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=SCORE_TOL, rtol=0)
+    lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
+    assert (hi - lo == 1).all()
 
 
 @pytest.mark.parametrize("name", ["g1_mini_b4_l8", "g1_mini_b10_l8_tiny_trie", "g1_mini_b2_l4_v1024"])
@@ -111,6 +215,8 @@ def test_encoder_and_step_logits_match_oracle(engine, golden_cache, name):
 
 
 def test_trie_mask_matches_reference_processor(engine, golden_cache):
+    """rpr_trie_mask (the stand-alone processor entry, prefix_mask_kernel). The mask the search itself uses is
+    checked by test_select_kernel_mask_and_choices_match_reference above."""
     for name in golden_names():
         g = golden_cache(name)
         ctx = engine.Context.get(0)
@@ -130,7 +236,11 @@ def test_linear_kernel_against_torch_fp32(engine):
     torch.manual_seed(0)
     for (M, N, K, relu, resid) in [(1, 256, 768, False, False), (80, 2304, 768, False, False),
                                     (130, 768, 3072, False, True), (257, 3072, 768, True, False),
-                                    (640, 256, 768, False, False), (33, 96, 64, True, True)]:
+                                    (640, 256, 768, False, False), (33, 96, 64, True, True),
+                                    # t5-large shapes (d = 1024, d_ff = 4096): 128-row, skinny and 256x256 kernels
+                                    (300, 1024, 1024, False, True), (1000, 4096, 1024, True, False),
+                                    (640, 1024, 4096, False, True), (12800, 3072, 1024, False, False),
+                                    (12800, 1024, 4096, False, True), (12800, 4096, 1024, True, False)]:
         A = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda") * K ** -0.5
         R = torch.randn(M, N, device="cuda") if resid else None
@@ -155,7 +265,8 @@ def test_rmsnorm_kernel_against_torch_fp32(engine):
         torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(20480, 768, 768), (5120, 2304, 768), (640, 768, 3072), (10, 768, 768), (2050, 832, 768)])
+@pytest.mark.parametrize("M,N,K", [(20480, 768, 768), (5120, 2304, 768), (640, 768, 3072), (10, 768, 768), (2050, 832, 768),
+                                   (12800, 1024, 4096), (12800, 4096, 1024)])
 def test_gemm_kernels_are_repeatable_bitwise(engine, M, N, K):
     """Race screen of the three split-precision GEMM kernels (ping-pong 256x256, LDS-DMA 128-row with deep prefetch,
     skinny): LDS-DMA ordering bugs show up as rare timing-dependent wrong tiles, so the same launch is repeated and

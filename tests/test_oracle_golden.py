@@ -6,10 +6,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names
+from conftest import compare_ranked, golden_names, prune_margins
 from oracle import beam_ref, t5_ref
 from ripor_amd.utils import synth
 
+# The full-prefix oracle (the reference's cost profile: every step recomputes the whole decoder prefix) runs on the
+# mini and t5-base fixtures; the t5-large B=100 and the 64-query config-1 fixtures take minutes that way and are
+# covered by the KV-cached oracle (same arithmetic, different summation order) through the ranked comparison.
+FULL = [n for n in golden_names() if n.startswith(("g1_", "g2_"))]
 FAST = [n for n in golden_names() if not n.startswith("g2_")]
 
 
@@ -18,7 +22,7 @@ def _mask_fn(g):
     return beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), g.V)
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", FULL)
 def test_oracle_reproduces_reference(golden_cache, name):
     g = golden_cache(name)
     torch.set_num_threads(8)
@@ -46,15 +50,12 @@ def test_kv_cached_oracle_equals_full_prefix(golden_cache, name):
     torch.set_num_threads(8)
     seqs, scores = beam_ref.beam_search_ref(t5_ref.T5RefCached(g.state_dict, g.dims), _mask_fn(g), g.input_ids,
                                             g.attention_mask, g.B, g.L, g.log_softmax, use_kv_cache=True)
-    margins = g.step_margins()
-    exp = g.sequences.reshape(g.Q, g.B, g.L + 1)
     got = seqs.numpy().reshape(g.Q, g.B, g.L + 1)
-    for q in range(g.Q):
-        if (got[q] == exp[q]).all():
-            np.testing.assert_allclose(scores.numpy().reshape(g.Q, g.B)[q], g.sequences_scores.reshape(g.Q, g.B)[q],
-                                       atol=1e-4, rtol=0)
-        else:
-            assert margins is not None and margins[q] < 1e-3, (name, q, margins)
+    assert (got[:, :, 0] == 0).all()
+    # the ranked comparison the GPU parity tests use (tests/conftest.py): set of sequences, per-sequence scores,
+    # exact tokens at every rank outside a score near-tie
+    stats = compare_ranked(g, got[:, :, 1:], scores.numpy().reshape(g.Q, g.B), label=" (KV-cached oracle)")
+    assert stats["boundary_excused"] == 0 and stats["sequences_missing"] == 0
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -88,11 +89,16 @@ def test_relative_position_buckets_known_answers():
 
 
 def test_fixture_margins_are_comfortable(golden_cache):
-    """The bit-exact GPU claims rest on margins >> fp32 noise for (almost) every golden query."""
-    tight = total = 0
+    """The bit-exact GPU claims rest on pruning margins >> fp32 noise: no query of any fixture may sit closer than
+    PRUNE_TOL to a pruning decision (the checker would excuse it), and every fixture must check most of its ranks."""
+    total = 0
     for name in golden_names():
-        m = golden_cache(name).step_margins()
-        if m is not None:
-            tight += int((m < 1e-3).sum())
-            total += len(m)
-    assert total >= 20 and tight <= total // 5, (tight, total)
+        g = golden_cache(name)
+        m, near = prune_margins(g)
+        assert (near == 0).all(), (name, m)
+        total += len(m)
+        sc = g.sequences_scores.reshape(g.Q, g.B).astype(np.float64)
+        if g.B > 1:
+            ties = int(((-np.diff(sc, axis=1)) < 2e-4).sum())
+            assert ties <= max(3, g.Q * g.B // 20) or "tiny_trie" in name, (name, ties)
+    assert total >= 90
