@@ -190,6 +190,27 @@ int rpr_search(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, const int32_t* in
                int32_t* out_tokens, float* out_scores, int64_t* out_row_lo, int64_t* out_row_hi,
                const rpr_debug_taps* taps, void* stream);
 
+/* ---- forward of the prefix-oriented ranking fine-tune step (BASELINE config 5) ----------
+ * Replaces the forward of T5SeqAQEncoderForLngKnpMarginMSE (modeling/t5_generative_retriever.py:902-966; also
+ * T5SeqAQEncoderForMarginMSE :847-882 with n_prefix = 1 and T5SeqAQEncoder.rerank_forward :788-792 with n_prefix = 0):
+ * teacher-forced decoder passes of base_model over the smtids of n_docs documents per query
+ * (decoder_input_ids = [-1, c_1 .. c_{L-1}], dataset/dataset.py:497-500), decode() of the doc encodings through the
+ * OUTPUT codebooks (:812-826), per-position scores <decoder_last_hidden_state[i], E_out[i][c_i]>, and the MSE losses
+ * between the student margins over the first prefix_lens[p] positions and the teacher margins.
+ *   input_ids, attention_mask: [dev] int32 [bz, Lq]      (the query; the positive and the negative pass share it)
+ *   doc_codes:   [dev] int32 [bz, n_docs, L]   doc_codes[b][0] = positive, [b][1] = negative smtid (codes in [0, V))
+ *   teacher_pos, teacher_neg: [dev] float [n_prefix, bz]  teacher scores per prefix length (row p belongs to
+ *                prefix_lens[p]; the reference's order is rank (= L), rank_4, rank_8, rank_16)
+ *   prefix_lens: [dev] int32 [n_prefix]
+ *   out_losses:  [dev] float [n_prefix]        mean_b (student_margin - teacher_margin)^2   (torch.nn.MSELoss)
+ *   out_position_scores: [dev] float [bz, n_docs, L], nullable
+ * Forward only in this version (no gradients): the backward pass, the optimizer and the RCCL gradient all-reduce of
+ * config 5 are not built yet. Eager launches on `stream`; asynchronous. */
+int rpr_lngknp_forward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask,
+                       int32_t bz, int32_t Lq, const int32_t* doc_codes, int32_t n_docs, int32_t L,
+                       const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens, int32_t n_prefix,
+                       float* out_losses, float* out_position_scores, void* stream);
+
 /* ---- sticky status of a ctx ------------------------------------------------------------------------
  * RPR_STATUS_SATURATED: in RPR_PREC_F16X2 mode an activation left the range of the f16 planes (|x| > 65504 after
  *   the plane scale: 4094 for normalised activations and attention outputs, 65504 for the residual stream, 1.05e6

@@ -81,6 +81,9 @@ SIGNATURES = {
     "rpr_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(DebugTaps), C.c_void_p]),
+    "rpr_lngknp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "rpr_get_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "rpr_model_f32_only": (C.c_int, [C.c_void_p]),
     "rpr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -207,8 +207,8 @@ struct LinOut {                                                              // 
   const float* resid; int relu;
   int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
   float plane_scale;                                                         //   scale of the planes written to h (0 = 1)
-  __half* x_h; size_t x_ps; unsigned long long* ssq_out;                     //   fused RMSNorm producer outputs (with f[0])
-};
+  const __half* resid_h; unsigned long long* ssq_out;                        //   fused RMSNorm producer: residual read from the
+};                                                                           //   planes h (in place), row sums accumulated
 
 LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
   LinOut o{};
@@ -220,7 +220,7 @@ LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu =
 void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, const int* m_dev = nullptr, int m_acc = -1) {
   const double Ma = m_acc >= 0 ? m_acc : M;
   const double fl = 2.0 * Ma * (double)W.N * W.K;
-  const double by = 4.0 * (Ma * W.K + (double)W.N * W.K + Ma * W.N * (O.resid ? 2 : 1) + (O.x_h ? Ma * W.N : 0.0));
+  const double by = 4.0 * (Ma * W.K + (double)W.N * W.K + Ma * W.N * ((O.resid || O.resid_h) ? 2 : 1));
   hipStream_t s = L.s;
   if (L.c->precision == RPR_PREC_F16X2) {
     GemmH2Args g{};
@@ -233,7 +233,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
     g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
     g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
-    g.x_h = O.x_h; g.x_ps = O.x_ps; g.ldxh = W.N; g.ssq_out = O.ssq_out;
+    g.resid_h = O.resid_h; g.r_ps = O.ps; g.ldrh = O.ldh; g.ssq_out = O.ssq_out;
     g.sat = L.c->status;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
@@ -287,22 +287,24 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   return e;
 }
 
-// Fused RMSNorm plumbing of the split-precision mode: the residual stream x is kept as fp32 (master
-// copy, residual adds) plus two f16 planes (operand of the next projection) plus one fixed-point sum of squares per
-// row and norm site; the projection that follows a norm runs on the x planes against W * diag(ln_weight) and scales
-// its output rows by rsqrt(ssq / d + eps). Sites are numbered in program order; every site of a pass has its own
-// ssq slot, zeroed by one memset per pass (site 0 is stored by the embedding kernel, the others are accumulated with
-// integer atomics by the residual GEMMs' epilogues, so the sums do not depend on the order of arrival).
+// Fused RMSNorm plumbing of the split-precision mode: the residual stream x lives in two f16 planes
+// (hi + lo = 22 bits; operand of the next projection AND residual of the next producer) plus one fixed-point sum of
+// squares per row and norm site; the projection that follows a norm runs on the x planes against W * diag(ln_weight)
+// and scales its output rows by rsqrt(ssq / d + eps). Sites are numbered in program order; every site of a pass has
+// its own ssq slot, zeroed by one small kernel per pass (site 0 is stored by the embedding kernel, the others are
+// accumulated with integer atomics by the residual GEMMs' epilogues, so the sums do not depend on the order of
+// arrival). The exact-fp32 mode keeps the fp32 stream and the separate RMSNorm kernel.
 struct XStream {
-  float* x; __half* x_h; size_t ps; unsigned long long* ssq; size_t rows; int dm; float eps;
+  __half* x_h; size_t ps; unsigned long long* ssq; size_t rows; int dm; float eps;
   LinIn in(int site) const {
-    LinIn a{x, x_h, ps, dm, X_PLANE_SCALE};
+    LinIn a{nullptr, x_h, ps, dm, X_PLANE_SCALE};
     a.ssq = ssq + (size_t)site * rows; a.inv_d_fix = 1.0f / ((float)dm * SSQ_FIX); a.eps = eps;
     return a;
   }
-  LinOut out(int site) const {          // x += projection; refresh the planes and the site's row sums
-    LinOut o = out_f32(x, dm, dm, x);
-    o.x_h = x_h; o.x_ps = ps; o.ssq_out = ssq + (size_t)site * rows;
+  LinOut out(int site) const {          // x += projection (in place in the planes); the site's row sums
+    LinOut o{};
+    o.split_n = dm; o.h = x_h; o.ps = ps; o.ldh = dm; o.plane_scale = X_PLANE_SCALE;
+    o.resid_h = x_h; o.ssq_out = ssq + (size_t)site * rows;
     return o;
   }
 };
@@ -334,11 +336,8 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
       if (hipMemcpyAsync(&n, live, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) Ta = n;
     }
   }
-  const XStream xs{x, P<__half>(w.ex_h), ps_d, P<unsigned long long>(w.ssq_e), (size_t)T, dm, eps};
-  if (h2 && !Ln.err) {
-    hipError_t e = hipMemsetAsync(w.ssq_e.p, 0, (size_t)(2 * d.num_layers + 1) * T * 8, s);
-    if (e != hipSuccess) { Ln.err = hip_fail(e, "ssq memset", __FILE__, __LINE__); return; }
-  }
+  const XStream xs{P<__half>(w.ex_h), ps_d, P<unsigned long long>(w.ssq_e), (size_t)T, dm, eps};
+  if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_e), (size_t)(2 * d.num_layers + 1) * T, s); });
   auto norm = [&](const float* wgt) {   // exact-fp32 mode only: the split mode folds the norms into the projections
     Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, T, dm, eps, s, 1.0f, nullptr, 0, live); });
   };
@@ -366,7 +365,7 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   // final norm: fp32 copy always (taps / rpr_encode), planes for the cross-K/V GEMM in split mode
   Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ta * dm * 4, [&] {
     return launch_rmsnorm(x, d.enc_final_ln, P<float>(w.enc_out), T, dm, eps, s, 1.0f,
-                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live, c->status);
+                          h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live, c->status, h2 ? xs.x_h : nullptr, ps_d);
   });
   c->enc_rows_accounted = Ta;
 }
@@ -435,15 +434,12 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   auto norm = [&](const float* wgt, float post_scale = 1.0f) {   // exact-fp32 mode only (see XStream)
     Ln.run(RPR_K_RMSNORM, 0, 2.0 * Rt * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, Rt, dm, eps, s, post_scale); });
   };
-  const XStream xs{x, P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
+  const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
   const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
   for (int t = 0; t < L; ++t) {
     BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
     Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
-    if (h2 && !Ln.err) {
-      hipError_t e = hipMemsetAsync(w.ssq_d.p, 0, (size_t)(3 * nd + 1) * R * 8, s);
-      if (e != hipSuccess) { Ln.err = hip_fail(e, "ssq memset", __FILE__, __LINE__); return; }
-    }
+    if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_d), (size_t)(3 * nd + 1) * R, s); });
     Ln.run(RPR_K_OTHER, 0, 2.0 * Rt * dm * 4, [&] {
       return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s,
                               h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
@@ -519,6 +515,84 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   FinalizeArgs fa{beam_state(w, L & 1, L), Q, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
                   P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_finalize(fa, s); });
+}
+
+// Teacher-forced forward of the prefix-oriented ranking fine-tune step: reference
+// T5SeqAQEncoderForLngKnpMarginMSE.forward (modeling/t5_generative_retriever.py:902-966). The encoder runs once per
+// query (the positive and the negative example of a row carry the same query text, dataset/dataset.py:502-503: the
+// reference encodes it twice); the decoder runs over all L positions of the n_docs smtids of every query at once:
+// rows (q, doc, position) = bz * n_docs * L, causal block self-attention per (sequence, head), cross-attention with
+// the n_docs * L rows of a query sharing its encoder K/V. Output: the gold-code score of every position.
+void enqueue_train_forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int bz, int Lq, int ndoc, int L,
+                           const int32_t* codes /*[bz, ndoc, L]*/, float* pos_scores /*[bz, ndoc, L]*/) {
+  const auto& d = m->d;
+  Workspace& w = c->ws;
+  const int T = bz * Lq, S = bz * ndoc, R = S * L, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
+  const int nd = d.num_decoder_layers, V = d.V;
+  const bool h2 = c->precision == RPR_PREC_F16X2;
+  const float eps = d.layer_norm_eps;
+  hipStream_t s = Ln.s;
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), bz, Lq, s, c->status + 1); });
+  enqueue_encoder(Ln, c, m, bz, Lq, true);
+  const int xld = nd * 2 * inner;
+  linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
+         out_f32(P<float>(w.xkv), xld, xld), P<int>(w.offs) + bz, c->enc_rows_accounted);
+
+  float *x = P<float>(w.x), *h = P<float>(w.h), *qkv = P<float>(w.tr_x), *qb = P<float>(w.q), *attn = P<float>(w.attn),
+        *ff = P<float>(w.ff);
+  __half *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
+  const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
+  const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+  auto norm = [&](const float* wgt) {   // exact-fp32 mode only (see XStream)
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * R * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, R, dm, eps, s); });
+  };
+  const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
+  const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
+  if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_d), (size_t)(3 * nd + 1) * R, s); });
+  Ln.run(RPR_K_OTHER, 0, 2.0 * R * dm * 4, [&] {
+    return launch_train_dec_embed(d.start_embed, d.in_embeds, codes, x, S, L, dm, V, s,
+                                  h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
+  });
+  for (int i = 0; i < nd; ++i) {
+    if (!h2) norm(m->dec_ln0[i]);
+    linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, out_f32(qkv, 3 * inner, 3 * inner));
+    {  // causal self-attention of every sequence over its own L positions (decoder relative-position table)
+      EncAttnArgs a{qkv, nullptr, d.dec_rel_bias, m->dec_bucket, attn, S, L, H, d.rel_buckets,
+                    h2 ? attn_h : nullptr, ps_i, nullptr, nullptr, c->status, 1};
+      Ln.run(RPR_K_ENC_ATTN, 2.0 * S * H * (double)L * L * DKV, 4.0 * R * 4 * inner, [&] { return launch_enc_attn(a, s); });
+    }
+    linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, R, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x));
+    if (!h2) norm(m->dec_ln1[i]);
+    linear(Ln, h2 ? xs.in(3 * i + 1) : in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, R, out_f32(qb, inner, inner));
+    {
+      const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+      DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, bz, ndoc * L, H, Lq, h2 ? attn_h : nullptr, ps_i,
+                         P<int32_t>(w.last), P<int32_t>(w.offs), 0, c->status};
+      Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * R * H * (double)Lq * DKV, 4.0 * ((double)R * inner * 2 + 2.0 * bz * (double)Lq * inner),
+             [&] { return launch_dec_cross_attn(a, s); });
+    }
+    linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x));
+    if (!h2) norm(m->dec_ln2[i]);
+    LinOut o = out_f32(ff, dff, dff, nullptr, 1);
+    if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
+    linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, R, o);
+    linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, R, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x));
+  }
+  // decoder_last_hidden_state (final RMSNorm, scaleup factor) dotted with the gold codes' OUTPUT codebook rows
+  Ln.run(RPR_K_OTHER, 2.0 * R * dm, 4.0 * 2 * R * dm, [&] {
+    return launch_gold_scores(x, d.dec_final_ln, d.out_embeds, codes, pos_scores, S, L, dm, V, eps, post, s,
+                              h2 ? xs.x_h : nullptr, ps_d);
+  });
+}
+
+int alloc_train_workspace(rpr_ctx* c, const rpr_model* m, int bz, int Lq, int ndoc, int L) {
+  // the search workspace for bz queries with ndoc * L "beams" of one position covers every shared buffer
+  int e = alloc_workspace(c, m, bz, Lq, ndoc * L, 1);
+  if (e) return e;
+  const size_t R = (size_t)bz * ndoc * L;
+  e = ensure(c, c->ws.tr_x, R * 3 * m->inner() * sizeof(float));
+  if (e) return e;
+  return ensure(c, c->ws.tr_misc, R * sizeof(float) + R * sizeof(int32_t) + 4096);
 }
 
 }  // namespace
@@ -841,6 +915,41 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_HIP(hipMemcpyAsync(out_scores, w.o_scores.p, R * 4, hipMemcpyDeviceToDevice, s));
   if (out_row_lo) RPR_HIP(hipMemcpyAsync(out_row_lo, w.o_lo.p, R * 8, hipMemcpyDeviceToDevice, s));
   if (out_row_hi) RPR_HIP(hipMemcpyAsync(out_row_hi, w.o_hi.p, R * 8, hipMemcpyDeviceToDevice, s));
+  return RPR_OK;
+}
+
+int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,
+                       int32_t Lq, const int32_t* doc_codes, int32_t n_docs, int32_t L, const float* teacher_pos,
+                       const float* teacher_neg, const int32_t* prefix_lens, int32_t n_prefix, float* out_losses,
+                       float* out_position_scores, void* stream) {
+  RPR_REQUIRE(c && m && input_ids && attention_mask && doc_codes, "NULL argument");
+  RPR_REQUIRE(m->ctx == c, "model belongs to another ctx");
+  RPR_REQUIRE(bz >= 1 && Lq >= 1 && Lq <= MAX_LQ, "bz or Lq out of range");
+  RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= MAX_LQ, "smtid length exceeds the model's decoder length");
+  RPR_REQUIRE(n_docs >= 1 && (int64_t)bz * n_docs * L < ((int64_t)1 << 24), "n_docs out of range");
+  RPR_REQUIRE(n_prefix >= 0 && n_prefix <= 8, "n_prefix out of range (0..8)");
+  RPR_REQUIRE(n_prefix == 0 || (n_docs == 2 && teacher_pos && teacher_neg && prefix_lens && out_losses),
+              "the margin losses need n_docs == 2 (positive, negative), teacher scores, prefix lengths and out_losses");
+  RPR_REQUIRE(out_losses || out_position_scores, "nothing to return");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int e = alloc_train_workspace(c, m, bz, Lq, n_docs, L);
+  if (e) return e;
+  Workspace& w = c->ws;
+  const size_t T = (size_t)bz * Lq, R = (size_t)bz * n_docs * L;
+  RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
+  RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
+  float* scores = P<float>(w.tr_misc);
+  int32_t* codes = reinterpret_cast<int32_t*>(scores + R);
+  RPR_HIP(hipMemcpyAsync(codes, doc_codes, R * 4, hipMemcpyDeviceToDevice, s));
+  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (m->f32_only) c->precision = RPR_PREC_F32;
+  Launcher Ln{c, s};
+  enqueue_train_forward(Ln, c, m, bz, Lq, n_docs, L, codes, scores);
+  if (Ln.err) return Ln.err;
+  if (n_prefix > 0)
+    RPR_HIP(launch_margin_mse(scores, teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, out_losses, nullptr, s));
+  if (out_position_scores) RPR_HIP(hipMemcpyAsync(out_position_scores, scores, R * 4, hipMemcpyDeviceToDevice, s));
   return RPR_OK;
 }
 

@@ -84,12 +84,14 @@ struct GemmH2Args {
   // by acc_scale = 1 / (scale of A's planes * scale of W's planes); planes written by the epilogue (out_h) are
   // scaled by plane_scale. 0 means 1.
   float acc_scale, plane_scale;
-  // Fused RMSNorm. Consumer side: A holds the planes of the UN-normalised residual stream x and W the
-  // planes of W * diag(ln_weight); row m of the result is multiplied by rsqrt(row_ssq[m] / d + eps) in the epilogue.
-  // Producer side (residual GEMMs): besides the fp32 stream out[0], the epilogue writes the planes of the new x
-  // (x_h, scale X_PLANE_SCALE) and adds its tile's part of every row's sum of squares to ssq_out (fixed point).
+  // Fused RMSNorm. In split-precision mode the residual stream x lives in f16 planes only (hi + lo =
+  // 22 bits, X_PLANE_SCALE) plus one fixed-point sum of squares per row and norm site.
+  // Consumer side: A = the planes of the UN-normalised x, W = the planes of W * diag(ln_weight); row m of the result
+  // is multiplied by rsqrt(row_ssq[m] / d + eps) in the epilogue.
+  // Producer side (residual GEMMs): the residual is read from planes (resid_h, in place with out_h), the sum is
+  // written back as planes (out_h) and the tile's part of every row's sum of squares is added to ssq_out.
   const unsigned long long* row_ssq; float inv_d_fix, eps;
-  __half* x_h; size_t x_ps; int ldxh; unsigned long long* ssq_out;
+  const __half* resid_h; size_t r_ps; int ldrh; unsigned long long* ssq_out;
   unsigned int* sat;                       // sticky saturation word of the ctx (split_f16)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
@@ -124,12 +126,17 @@ hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t pla
 // post_scale: config.scaleup_output_hidden multiplies the final decoder norm by d_model**-0.5
 // out (fp32) and/or out_h (two f16 planes, stride o_ps) are written; either may be null
 // rows_dev (nullable): live row count on the device; rows past it are skipped (packed encoder)
+// x_h (nullable): read the row from the residual-stream planes (stride x_ps) instead of x
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
                           float post_scale = 1.0f, __half* out_h = nullptr, size_t o_ps = 0,
-                          const int* rows_dev = nullptr, unsigned int* sat = nullptr);
-// Fused-RMSNorm producers: besides the fp32 row, x_h (planes of the row, X_PLANE_SCALE) and ssq (fixed-point sum of
-// squares of the row, stored — one wave owns a whole row) are written when non-null.
+                          const int* rows_dev = nullptr, unsigned int* sat = nullptr, const __half* x_h = nullptr,
+                          size_t x_ps = 0);
+// Fused-RMSNorm producers (embedding kernels): when x_h is non-null the row goes to the f16 planes of the residual
+// stream (X_PLANE_SCALE) instead of the fp32 buffer, and ssq receives the fixed-point sum of squares of the row as the
+// planes hold it (stored — one wave owns a whole row).
 struct XOut { __half* x_h; size_t x_ps; unsigned long long* ssq; unsigned int* sat; };
+// a residual-stream element back from its planes (exact: hi and lo do not overlap)
+__device__ __forceinline__ float x_from_planes(__half hi, __half lo) { return (__half2float(hi) + __half2float(lo)) * (1.0f / X_PLANE_SCALE); }
 hipError_t init_t5_kernel_attributes();
 hipError_t init_beam_kernel_attributes();
 // row_src (nullable): out row p takes ids[row_src[p]] for p < *rows_dev (packed encoder)
@@ -232,8 +239,18 @@ hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
 // mask-only kernel for rpr_trie_mask: prefix rows -> child byte mask
 hipError_t launch_prefix_mask(const uint16_t* codes, int Lc, int64_t N, const int32_t* prefix, int R, int T,
                               int V, uint8_t* out_mask, hipStream_t s);
+hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s);
 // status (nullable): the ctx's sticky "empty query" word, set to 1 when a query attends to no token
 hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s,
                                unsigned int* status = nullptr);
+
+// ---- teacher-forced forward of the ranking fine-tune step (train_kernels.hip) -------------------
+hipError_t launch_train_dec_embed(const float* start, const float* in_embeds, const int32_t* codes, float* out, int S,
+                                  int L, int d, int V, hipStream_t s, XOut xo = XOut{});
+hipError_t launch_gold_scores(const float* x, const float* ln, const float* out_embeds, const int32_t* codes, float* scores,
+                              int S, int L, int d, int V, float eps, float post, hipStream_t s,
+                              const __half* x_h = nullptr, size_t x_ps = 0);
+hipError_t launch_margin_mse(const float* scores, const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens,
+                             int n_prefix, int bz, int L, float* losses, float* margins, hipStream_t s);
 
 }  // namespace rpr

@@ -196,11 +196,14 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
       float* outp = g.out[oi];
       const int ldo = g.ldo[oi];
       float res[16];
-      if (g.resid) {
+      if (g.resid || g.resid_h) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
-          res[r] = (nok && (FULL || m < Mlim)) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+          res[r] = 0.f;
+          if (nok && (FULL || m < Mlim))
+            res[r] = g.resid_h ? x_from_planes(g.resid_h[(size_t)m * g.ldrh + n], g.resid_h[g.r_ps + (size_t)m * g.ldrh + n])
+                               : g.resid[(size_t)m * g.ldr + n];
         }
       }
 #pragma unroll
@@ -210,21 +213,16 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
         float v = acc[i][j][r] * g.acc_scale;
         if (g.row_ssq) v *= rs[r];
         if (g.relu) v = fmaxf(v, 0.f);
-        if (g.resid) v = res[r] + v;
+        if (g.resid || g.resid_h) v = res[r] + v;
         if (ok) {
           if (g.out_h) {
             __half hi, lo;
             split_f16(v * g.plane_scale, hi, lo, g.sat);
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+            v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;   // the value the planes carry (row sums below)
           } else {
             outp[out_off(g, oi, m, ldo, on)] = v;
-          }
-          if (g.x_h) {
-            __half hi, lo;
-            split_f16(v * X_PLANE_SCALE, hi, lo, g.sat);
-            g.x_h[(size_t)m * g.ldxh + n] = hi;
-            g.x_h[g.x_ps + (size_t)m * g.ldxh + n] = lo;
           }
           ssr[r] += v * v;
         }
@@ -252,20 +250,14 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
   // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
   // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
-  // operand LDS and streams them out as float4 rows: 16 residual loads in flight per lane, 4x fewer
-  // store instructions, f16 planes written 8 bytes at a time.
+  // operand LDS and streams them out row-wise with 16-byte accesses. The epilogue is bound by the NUMBER of
+  // store instructions, not by their bytes (measured: adding two 8-byte plane stores per float4 tripled it), so
+  // the f16-plane outputs give a lane 8 consecutive columns = one 16-byte store per plane.
   __syncthreads();                                   // all waves are done reading operand tiles
   const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-  constexpr int LPR = SW / 4, RPI = 64 / LPR;          // lanes per staged row, rows per read instruction
-  const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
-  const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
-  const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
-  const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
-  float* outp = g.out[oi];
-  const int ldo = g.ldo[oi];
 #pragma unroll
   for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
@@ -278,57 +270,90 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int mrow0 = bm + wm * (BM / WM) + half * 64;
-    constexpr int NK = 64 / RPI;
-    float4 res[NK];
-    float rsc[NK];
-    if (g.row_ssq) {   // fused RMSNorm: per-row scale of the consumer
+    if (g.out_h) {
+      // ---- f16-plane output (FF intermediate, residual stream): 8 columns per lane, 8 rows per pass
+      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = 64 / RPI;
+      const int rrow = lane / LPR, rc8 = (lane % LPR) * 8;
+      const int n0 = bn + wn * (BN / WN) + rc8;
+      const bool ncol_ok = FULL || (n0 < g.N);          // N % 32 == 0
+      uint4 rh[NK], rl_[NK];
+      float rsc[NK];
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int m = mrow0 + k * RPI + rrow;
-        rsc[k] = (FULL || m < Mlim) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+        const bool ok = ncol_ok && (FULL || m < Mlim);
+        rsc[k] = (g.row_ssq && (FULL || m < Mlim)) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+        if (g.resid_h) {
+          rh[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
+          rl_[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + g.r_ps + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
+        }
       }
-    }
-    if (g.resid) {
+      const float ps = g.plane_scale, ips = 1.0f / g.plane_scale;
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
-        const int m = mrow0 + k * RPI + rrow;
-        res[k] = (ncol_ok && (FULL || m < Mlim)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+        const int rl = k * RPI + rrow, m = mrow0 + rl;
+        const bool ok = ncol_ok && (FULL || m < Mlim);
+        float v[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
+        __half h[8], l[8];
+        float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int rl = k * RPI + rrow, m = mrow0 + rl;
-      float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-      v.x *= g.acc_scale; v.y *= g.acc_scale; v.z *= g.acc_scale; v.w *= g.acc_scale;
-      if (g.row_ssq) { v.x *= rsc[k]; v.y *= rsc[k]; v.z *= rsc[k]; v.w *= rsc[k]; }
-      if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
-      const bool ok = ncol_ok && (FULL || m < Mlim);
-      if (ok) {
-        if (g.out_h) {
-          __half h[4], l[4];
-          const float ps = g.plane_scale;
-          split_f16(v.x * ps, h[0], l[0], g.sat); split_f16(v.y * ps, h[1], l[1], g.sat);
-          split_f16(v.z * ps, h[2], l[2], g.sat); split_f16(v.w * ps, h[3], l[3], g.sat);
-          *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(h);
-          *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint2*>(l);
-        } else {
-          *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * g.acc_scale;
+          if (g.row_ssq) x *= rsc[k];
+          if (g.relu) x = fmaxf(x, 0.f);
+          if (g.resid_h) x += x_from_planes(reinterpret_cast<const __half*>(&rh[k])[e], reinterpret_cast<const __half*>(&rl_[k])[e]);
+          split_f16(x * ps, h[e], l[e], ok ? g.sat : nullptr);
+          const float xr = (__half2float(h[e]) + __half2float(l[e])) * ips;   // what the planes carry
+          ss += xr * xr;
         }
-        if (g.x_h) {   // planes of the new residual stream (next consumer's A operand)
-          __half h[4], l[4];
-          split_f16(v.x * X_PLANE_SCALE, h[0], l[0], g.sat); split_f16(v.y * X_PLANE_SCALE, h[1], l[1], g.sat);
-          split_f16(v.z * X_PLANE_SCALE, h[2], l[2], g.sat); split_f16(v.w * X_PLANE_SCALE, h[3], l[3], g.sat);
-          *reinterpret_cast<uint2*>(g.x_h + (size_t)m * g.ldxh + n0) = *reinterpret_cast<uint2*>(h);
-          *reinterpret_cast<uint2*>(g.x_h + g.x_ps + (size_t)m * g.ldxh + n0) = *reinterpret_cast<uint2*>(l);
+        if (ok) {
+          *reinterpret_cast<uint4*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(h);
+          *reinterpret_cast<uint4*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(l);
+        }
+        if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
+          if (!ok) ss = 0.f;
+#pragma unroll
+          for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+          if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
         }
       }
-      if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
-        float ss = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+    } else {
+      // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes)
+      constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = 64 / RPI;   // lanes per staged row, rows per read instruction
+      const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
+      const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
+      const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
+      const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
+      float* outp = g.out[oi];
+      const int ldo = g.ldo[oi];
+      float4 res[NK];
+      float rsc[NK];
+      if (g.row_ssq) {   // fused RMSNorm: per-row scale of the consumer
 #pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+        for (int k = 0; k < NK; ++k) {
+          const int m = mrow0 + k * RPI + rrow;
+          rsc[k] = (FULL || m < Mlim) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+        }
+      }
+      if (g.resid) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int m = mrow0 + k * RPI + rrow;
+          res[k] = (ncol_ok && (FULL || m < Mlim)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int rl = k * RPI + rrow, m = mrow0 + rl;
+        float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+        v.x *= g.acc_scale; v.y *= g.acc_scale; v.z *= g.acc_scale; v.w *= g.acc_scale;
+        if (g.row_ssq) { v.x *= rsc[k]; v.y *= rsc[k]; v.z *= rsc[k]; v.w *= rsc[k]; }
+        if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
+        if (ncol_ok && (FULL || m < Mlim)) *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
@@ -611,20 +636,16 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
     if (g.row_ssq && mok) v *= ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.resid && ok) v = g.resid[(size_t)m * g.ldr + n] + v;
+    if (g.resid_h && ok) v = x_from_planes(g.resid_h[(size_t)m * g.ldrh + n], g.resid_h[g.r_ps + (size_t)m * g.ldrh + n]) + v;
     if (ok) {
       if (g.out_h) {
         __half hi, lo;
         split_f16(v * g.plane_scale, hi, lo, g.sat);
         g.out_h[(size_t)m * g.ldoh + n] = hi;
         g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+        v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;
       } else {
         outp[out_off(g, oi, m, ldo, on)] = v;
-      }
-      if (g.x_h) {
-        __half hi, lo;
-        split_f16(v * X_PLANE_SCALE, hi, lo, g.sat);
-        g.x_h[(size_t)m * g.ldxh + n] = hi;
-        g.x_h[g.x_ps + (size_t)m * g.ldxh + n] = lo;
       }
     }
     if (g.ssq_out) {   // wave-uniform branch: all 64 lanes take part in the shuffles

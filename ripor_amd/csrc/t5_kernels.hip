@@ -44,22 +44,30 @@ __device__ __forceinline__ float group16_sum(float v) {
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ out, int rows, int d, float eps,
                                                        float post_scale, __half* __restrict__ out_h, size_t o_ps,
-                                                       const int* __restrict__ rows_dev, unsigned int* sat) {
+                                                       const int* __restrict__ rows_dev, unsigned int* sat,
+                                                       const __half* __restrict__ x_h, size_t x_ps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows || (rows_dev && row >= *rows_dev)) return;
-  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);   // only dereferenced when x_h == nullptr
   const float4* wr = reinterpret_cast<const float4*>(w);
   float4* orow = reinterpret_cast<float4*>(out + (size_t)row * d);  // only dereferenced when out != nullptr
   const int n4 = d >> 2;
+  auto load4 = [&](int i) -> float4 {
+    if (!x_h) return xr[i];
+    const size_t idx = (size_t)row * d + 4 * (size_t)i;      // residual stream kept in f16 planes (split-precision mode)
+    const uint2 hh = *reinterpret_cast<const uint2*>(x_h + idx), ll = *reinterpret_cast<const uint2*>(x_h + x_ps + idx);
+    const __half* h = reinterpret_cast<const __half*>(&hh); const __half* l = reinterpret_cast<const __half*>(&ll);
+    return make_float4(x_from_planes(h[0], l[0]), x_from_planes(h[1], l[1]), x_from_planes(h[2], l[2]), x_from_planes(h[3], l[3]));
+  };
   float ss = 0.f;
   for (int i = lane; i < n4; i += 64) {
-    const float4 v = xr[i];
+    const float4 v = load4(i);
     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)d + eps);
   for (int i = lane; i < n4; i += 64) {
-    const float4 v = xr[i], g = wr[i];
+    const float4 v = load4(i), g = wr[i];
     float4 o = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
     if (post_scale != 1.0f) { o.x *= post_scale; o.y *= post_scale; o.z *= post_scale; o.w *= post_scale; }
     if (out) orow[i] = o;
@@ -68,10 +76,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 }
 
 hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, int d, float eps, hipStream_t s,
-                          float post_scale, __half* out_h, size_t o_ps, const int* rows_dev, unsigned int* sat) {
+                          float post_scale, __half* out_h, size_t o_ps, const int* rows_dev, unsigned int* sat,
+                          const __half* x_h, size_t x_ps) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, out, rows, d, eps, post_scale, out_h, o_ps,
-                     rows_dev, sat);
+                     rows_dev, sat, x_h, x_ps);
   return hipGetLastError();
 }
 
@@ -80,12 +89,21 @@ hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, 
 // f16 planes and its fixed-point sum of squares (the wave owns the whole row: plain store, no atomic).
 __device__ __forceinline__ void copy_row_x(const float4* __restrict__ src, float* __restrict__ out, int row, int d,
                                            int lane, const XOut& xo) {
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);   // only written when x_h == nullptr (fp32 mode)
   float ss = 0.f;
   for (int i = lane; i < (d >> 2); i += 64) {
-    const float4 v = src[i];
-    dst[i] = v;
-    if (xo.x_h) store_planes4(xo.x_h, xo.x_ps, (size_t)row * d + 4 * (size_t)i, v, xo.sat, X_PLANE_SCALE);
+    float4 v = src[i];
+    if (xo.x_h) {
+      const size_t idx = (size_t)row * d + 4 * (size_t)i;
+      __half h[4], l[4];
+      split_f16(v.x * X_PLANE_SCALE, h[0], l[0], xo.sat); split_f16(v.y * X_PLANE_SCALE, h[1], l[1], xo.sat);
+      split_f16(v.z * X_PLANE_SCALE, h[2], l[2], xo.sat); split_f16(v.w * X_PLANE_SCALE, h[3], l[3], xo.sat);
+      *reinterpret_cast<uint2*>(xo.x_h + idx) = *reinterpret_cast<uint2*>(h);
+      *reinterpret_cast<uint2*>(xo.x_h + xo.x_ps + idx) = *reinterpret_cast<uint2*>(l);
+      v = make_float4(x_from_planes(h[0], l[0]), x_from_planes(h[1], l[1]), x_from_planes(h[2], l[2]), x_from_planes(h[3], l[3]));
+    } else {
+      dst[i] = v;
+    }
     ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   if (xo.ssq) {
@@ -635,6 +653,20 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   const size_t smem = smem_for(a.bchunk ? a.bchunk : a.B);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H, chunks), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// zeroes the per-site row sums of a pass (a kernel node rather than a memset node: memset nodes captured into the
+// search graph did not re-execute reliably on replay with ROCm 7.2)
+__global__ __launch_bounds__(256) void zero_u64_kernel(unsigned long long* __restrict__ p, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i + 1 < n) *reinterpret_cast<ulonglong2*>(p + i) = make_ulonglong2(0ull, 0ull);
+  else if (i < n) p[i] = 0ull;
+}
+
+hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, s, p, n);
   return hipGetLastError();
 }
 

@@ -336,3 +336,39 @@ def search(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attent
                              C.byref(tap_struct) if tap_struct is not None else None, _stream_ptr(dev)), "rpr_search")
     # ids/mask must stay alive until the async D2D staging copies have been enqueued (they have).
     return SearchResult(tokens, scores, lo, hi, tap_out)
+
+
+def lngknp_forward(model: DeviceModel, input_ids: torch.Tensor, attention_mask: torch.Tensor, doc_codes: torch.Tensor,
+                   teacher_pos: Optional[torch.Tensor] = None, teacher_neg: Optional[torch.Tensor] = None,
+                   prefix_lens: Optional[Sequence[int]] = None):
+    """Forward of the prefix-oriented ranking fine-tune step (``rpr_lngknp_forward``; reference
+    T5SeqAQEncoderForLngKnpMarginMSE.forward, modeling/t5_generative_retriever.py:902-966).
+
+    doc_codes ``[bz, n_docs, L]`` (positive first); teacher_pos / teacher_neg ``[n_prefix, bz]`` aligned with
+    ``prefix_lens``. Returns ``(losses float32 [n_prefix] or None, position_scores float32 [bz, n_docs, L])``,
+    device tensors, asynchronous on the current stream."""
+    ctx = model.ctx
+    dev = ctx.device
+    ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
+    mask = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+    codes = doc_codes.to(device=dev, dtype=torch.int32).contiguous()
+    bz, Lq = ids.shape
+    _, n_docs, L = codes.shape
+    if Lq % 8 and Lq < 256:   # same bucketing as search(): masked padding columns, identical results
+        pad = min(256, (Lq + 7) // 8 * 8) - Lq
+        ids = torch.nn.functional.pad(ids, (0, pad)); mask = torch.nn.functional.pad(mask, (0, pad)); Lq += pad
+    pos_scores = torch.empty((bz, n_docs, L), dtype=torch.float32, device=dev)
+    n_prefix = 0 if prefix_lens is None else len(prefix_lens)
+    losses = tp = tn = pl = None
+    if n_prefix:
+        tp = teacher_pos.to(device=dev, dtype=torch.float32).contiguous()
+        tn = teacher_neg.to(device=dev, dtype=torch.float32).contiguous()
+        assert tuple(tp.shape) == (n_prefix, bz) and tuple(tn.shape) == (n_prefix, bz)
+        pl = torch.tensor(list(prefix_lens), dtype=torch.int32, device=dev)
+        losses = torch.empty((n_prefix,), dtype=torch.float32, device=dev)
+    check(ctx.lib.rpr_lngknp_forward(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq, codes.data_ptr(),
+                                     n_docs, L, tp.data_ptr() if n_prefix else None, tn.data_ptr() if n_prefix else None,
+                                     pl.data_ptr() if n_prefix else None, n_prefix,
+                                     losses.data_ptr() if n_prefix else None, pos_scores.data_ptr(), _stream_ptr(dev)),
+          "rpr_lngknp_forward")
+    return losses, pos_scores

@@ -237,3 +237,38 @@ class T5SeqAQEncoder:
 
     def save_pretrained(self, save_dir):
         self.base_model.save_pretrained(save_dir)
+
+
+class T5SeqAQEncoderForLngKnpMarginMSE(T5SeqAQEncoder):
+    """reference :902-966 — forward of the prefix-oriented ranking fine-tune step, same
+    ``forward(**inputs)`` dict interface and return keys (``rank``, ``rank_4``, ``rank_8``, ``rank_16``). The whole
+    pass runs in ``rpr_lngknp_forward`` (teacher-forced decoder over all positions of the positive and the negative
+    smtid at once, one encoder pass per query). Forward only: no autograd graph is attached to the returned losses."""
+
+    _PREFIXES = {8: [(8, ""), (4, "smtid_4_")], 16: [(16, ""), (4, "smtid_4_"), (8, "smtid_8_")],
+                 32: [(32, ""), (4, "smtid_4_"), (8, "smtid_8_"), (16, "smtid_16_")]}
+
+    def forward(self, **inputs):
+        from .. import engine as E
+        pos_q, neg_q = inputs["pos_tokenized_query"], inputs["neg_tokenized_query"]
+        pos_codes, neg_codes = inputs["pos_doc_encoding"], inputs["neg_doc_encoding"]
+        L = pos_codes.size(1)
+        if L not in self._PREFIXES:
+            raise ValueError("not valid length: {}".format(L))
+        if not (torch.equal(pos_q["input_ids"], neg_q["input_ids"])):
+            # dataset.py:502-503 builds both from the same query text; two different texts would need two encoder passes
+            raise ValueError("pos_tokenized_query and neg_tokenized_query must carry the same query tokens")
+        for side, q, codes in (("pos", pos_q, pos_codes), ("neg", neg_q, neg_codes)):
+            di = q["decoder_input_ids"]
+            if not torch.equal(di[:, 1:].to(codes.device), codes[:, :-1]):
+                raise ValueError(f"{side}: decoder_input_ids must be the doc encoding shifted right (dataset.py:497-500)")
+        names = ["rank" if k == L else f"rank_{k}" for k, _ in self._PREFIXES[L]]
+        tp = torch.stack([inputs[p + "teacher_pos_scores"] for _, p in self._PREFIXES[L]]).float()
+        tn = torch.stack([inputs[p + "teacher_neg_scores"] for _, p in self._PREFIXES[L]]).float()
+        codes = torch.stack([pos_codes, neg_codes], dim=1)
+        losses, self.last_position_scores = E.lngknp_forward(
+            self.base_model.engine_model(), pos_q["input_ids"], pos_q["attention_mask"], codes, tp, tn,
+            [k for k, _ in self._PREFIXES[L]])
+        return {n: losses[i] for i, n in enumerate(names)}
+
+    __call__ = forward

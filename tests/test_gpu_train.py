@@ -1,0 +1,105 @@
+"""-m gpu: forward of the prefix-oriented ranking fine-tune step (BASELINE config 5) through
+rpr_lngknp_forward against the fixtures produced by the imported reference class
+T5SeqAQEncoderForLngKnpMarginMSE.forward (tests/golden/make_golden.py::make_train_case).
+
+Bars: every loss within 1e-4 relative of the reference's float32 loss (losses are O(1e3): the student margins are
+sums of 2 x L fp32 scores of O(10) and enter squared); every per-position score <h_i, E_out[i][c_i]> within 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, train_golden_names
+
+pytestmark = pytest.mark.gpu
+
+REL_LOSS_TOL = 1e-4
+POS_SCORE_TOL = 1e-3
+
+
+class TrainGolden:
+    def __init__(self, name):
+        from ripor_amd.utils import synth
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.spec = json.loads(str(self.z["spec"]))
+        self.dims = synth.ModelDims(**self.spec["dims"])
+        self.bz, self.L, self.V, self.seed = self.spec["bz"], self.spec["L"], self.spec["V"], self.spec["seed"]
+        self.state_dict = synth.make_state_dict(self.dims, seed=self.seed)
+        self.losses = dict(zip([str(x) for x in self.z["loss_names"]], self.z["losses"].tolist()))
+
+
+def _inputs(g):
+    t = torch.from_numpy
+    start = np.full((g.bz, 1), -1, dtype=np.int64)
+
+    def tq(codes):
+        return {"input_ids": t(g.z["input_ids"]), "attention_mask": t(g.z["attention_mask"]),
+                "decoder_input_ids": t(np.concatenate([start, codes[:, :-1]], axis=1))}
+
+    pos, neg = g.z["pos_doc_encoding"], g.z["neg_doc_encoding"]
+    inputs = {"pos_tokenized_query": tq(pos), "neg_tokenized_query": tq(neg), "pos_doc_encoding": t(pos),
+              "neg_doc_encoding": t(neg)}
+    for k in g.z.files:
+        if k.endswith("_scores") and "teacher" in k:
+            inputs[k] = t(g.z[k])
+    return inputs
+
+
+@pytest.mark.parametrize("name", train_golden_names())
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_lngknp_forward_matches_reference_losses(name, precision):
+    from ripor_amd import engine as E
+    from ripor_amd.modeling.t5_generative_retriever import (T5forDocIDConfig, T5ForDocIDGeneration,
+                                                            T5SeqAQEncoderForLngKnpMarginMSE)
+    g = TrainGolden(name)
+    ctx = E.Context.get(0)
+    ctx.set_precision(precision)
+    try:
+        m = T5SeqAQEncoderForLngKnpMarginMSE.__new__(T5SeqAQEncoderForLngKnpMarginMSE)
+        m.config = T5forDocIDConfig.from_dims(g.dims)
+        m.base_model = T5ForDocIDGeneration(m.config, g.state_dict).to(0)
+        m.model_args = None
+        ctx.status(clear=True)
+        out = m(**_inputs(g))
+        torch.cuda.synchronize()
+        assert ctx.status() == 0
+        assert set(out) == set(g.losses)
+        ps = m.last_position_scores.cpu().numpy()
+        np.testing.assert_allclose(ps[:, 0], g.z["pos_position_scores"], atol=POS_SCORE_TOL, rtol=0)
+        np.testing.assert_allclose(ps[:, 1], g.z["neg_position_scores"], atol=POS_SCORE_TOL, rtol=0)
+        for k, v in g.losses.items():
+            got = float(out[k])
+            assert out[k].dtype == torch.float32
+            assert abs(got - v) <= REL_LOSS_TOL * max(1.0, abs(v)), (name, precision, k, got, v)
+        print(f"[train] {name} {precision}: max position-score err "
+              f"{max(np.abs(ps[:, 0] - g.z['pos_position_scores']).max(), np.abs(ps[:, 1] - g.z['neg_position_scores']).max()):.2e}; "
+              f"losses {[(k, float(out[k]), g.losses[k]) for k in sorted(g.losses)]}")
+        # repeat: deterministic
+        out2 = m(**_inputs(g))
+        assert all(torch.equal(out[k], out2[k]) for k in out)
+    finally:
+        ctx.set_precision("f16x2")
+
+
+def test_lngknp_forward_rejects_inconsistent_batches():
+    from ripor_amd.modeling.t5_generative_retriever import (T5forDocIDConfig, T5ForDocIDGeneration,
+                                                            T5SeqAQEncoderForLngKnpMarginMSE)
+    g = TrainGolden("f4_mini_bz4_l8")
+    m = T5SeqAQEncoderForLngKnpMarginMSE.__new__(T5SeqAQEncoderForLngKnpMarginMSE)
+    m.config = T5forDocIDConfig.from_dims(g.dims)
+    m.base_model = T5ForDocIDGeneration(m.config, g.state_dict).to(0)
+    inputs = _inputs(g)
+    bad = dict(inputs)
+    bad["pos_doc_encoding"] = inputs["pos_doc_encoding"][:, :6]
+    bad["neg_doc_encoding"] = inputs["neg_doc_encoding"][:, :6]
+    with pytest.raises(ValueError, match="not valid length"):
+        m(**bad)
+    bad = dict(inputs)
+    bad["pos_tokenized_query"] = dict(inputs["pos_tokenized_query"])
+    bad["pos_tokenized_query"]["decoder_input_ids"] = inputs["pos_tokenized_query"]["decoder_input_ids"].clone()
+    bad["pos_tokenized_query"]["decoder_input_ids"][0, 2] += 1
+    with pytest.raises(ValueError, match="shifted right"):
+        m(**bad)

@@ -102,3 +102,39 @@ def test_fixture_margins_are_comfortable(golden_cache):
             ties = int(((-np.diff(sc, axis=1)) < 2e-4).sum())
             assert ties <= max(3, g.Q * g.B // 20) or "tiny_trie" in name, (name, ties)
     assert total >= 90
+
+
+# ---- forward of the prefix-oriented ranking fine-tune step ---------------------------------------
+class TrainGolden:
+    def __init__(self, name):
+        import json
+        import os
+        from conftest import GOLDEN_DIR
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.spec = json.loads(str(self.z["spec"]))
+        self.dims = synth.ModelDims(**self.spec["dims"])
+        self.bz, self.L, self.V, self.seed = self.spec["bz"], self.spec["L"], self.spec["V"], self.spec["seed"]
+        self.teacher = {k: self.z[k] for k in self.z.files if k.endswith("_scores") and "teacher" in k}
+        self.losses = dict(zip([str(x) for x in self.z["loss_names"]], self.z["losses"].tolist()))
+
+    @property
+    def state_dict(self):
+        return synth.make_state_dict(self.dims, seed=self.seed)
+
+
+def test_train_forward_oracle_reproduces_reference_losses():
+    from conftest import train_golden_names
+    from oracle import train_ref
+    names = train_golden_names()
+    assert len(names) >= 3
+    for name in names:
+        g = TrainGolden(name)
+        torch.set_num_threads(8)
+        out = train_ref.lng_knp_margin_mse(t5_ref.T5Ref(g.state_dict, g.dims), g.z["input_ids"], g.z["attention_mask"],
+                                           g.z["pos_doc_encoding"], g.z["neg_doc_encoding"], g.teacher)
+        assert set(g.losses) == set(train_ref.LOSS_NAMES[g.L])
+        np.testing.assert_allclose(out["pos_position_scores"].numpy(), g.z["pos_position_scores"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(out["neg_position_scores"].numpy(), g.z["neg_position_scores"], atol=2e-5, rtol=1e-5)
+        for k, v in g.losses.items():
+            assert abs(float(out[k]) - v) <= 1e-5 * max(1.0, abs(v)), (name, k, float(out[k]), v)
