@@ -151,9 +151,27 @@ void rpr_free_trie(rpr_trie* trie);
 int64_t rpr_trie_num_rows(const rpr_trie* trie);
 /* [host] perm[N]: perm[sorted_row] = original row index (docid index). Valid until rpr_free_trie. */
 const int64_t* rpr_trie_perm(const rpr_trie* trie);
-/* Binary trie cache replacing list_smtid_to_nextids.pkl (evaluate.py:404-408,428-432). */
+/* Binary trie cache replacing list_smtid_to_nextids.pkl (evaluate.py:404-408,428-432): sorted code matrix,
+ * permutation and (optionally) the docid strings, so that a run needs neither the JSON parse nor the sort.
+ * rpr_trie_build_file is HOST ONLY (no ctx, no GPU): the replacement of
+ * `python -m t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids` (aq_preprocess/build_list_smtid_to_nextids.py:13-41).
+ *   keys: [host] docid strings in row order joined by '\n' (key_bytes = 0: none); src_size / src_mtime_ns: identity of
+ *   the docid_to_smtid.json the codes came from (0 = unknown), returned by rpr_trie_file_info so callers can detect a
+ *   stale cache. rpr_trie_load validates everything it reads (sizes vs file length, codes < V, sorted rows, perm). */
 int rpr_trie_save(const rpr_trie* trie, const char* path);
+int rpr_trie_build_file(const uint16_t* codes, int64_t N, int32_t L, int32_t V, const char* keys, int64_t key_bytes,
+                        int64_t src_size, int64_t src_mtime_ns, const char* path);
+int rpr_trie_file_info(const char* path, int64_t* N, int32_t* L, int32_t* V, int64_t* key_bytes, int64_t* src_size,
+                       int64_t* src_mtime_ns);
 int rpr_trie_load(rpr_ctx* ctx, const char* path, rpr_trie** out_trie);
+/* HOST ONLY: the full validation rpr_trie_load performs, without a device (0 = the file is well-formed). */
+int rpr_trie_file_validate(const char* path);
+/* Dimensions of a trie object (the FILE's L and V after rpr_trie_load); key_bytes = size of its docid blob. */
+int rpr_trie_dims(const rpr_trie* trie, int64_t* N, int32_t* L, int32_t* V, int64_t* key_bytes);
+/* [host] out: key_bytes chars, the docid strings in original row order joined by '\n'. */
+int rpr_trie_keys(const rpr_trie* trie, char* out);
+/* A cache is built without knowing the model: widen V to the model's decoder vocab size (must exceed every code). */
+int rpr_trie_set_vocab(rpr_trie* trie, int32_t V);
 /* Host-side child mask of arbitrary prefixes — the processor's __call__ (generation.py:666-677)
  * without a model, for callers that use the processor object on its own. prefix: [host] [R, T] with
  * column 0 ignored (start id); out_mask: [host] [R, V] bytes 0/1. Runs a stand-alone device kernel

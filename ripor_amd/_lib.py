@@ -73,6 +73,15 @@ SIGNATURES = {
     "rpr_trie_perm": (C.POINTER(C.c_int64), [C.c_void_p]),
     "rpr_trie_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rpr_trie_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rpr_trie_build_file": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, C.c_int64,
+                                      C.c_int64, C.c_char_p]),
+    "rpr_trie_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rpr_trie_file_validate": (C.c_int, [C.c_char_p]),
+    "rpr_trie_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int64)]),
+    "rpr_trie_keys": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpr_trie_set_vocab": (C.c_int, [C.c_void_p, C.c_int32]),
     "rpr_d2s_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rpr_d2s_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "rpr_d2s_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -87,6 +87,7 @@ struct rpr_trie {
   uint16_t* codes = nullptr;  // [dev] sorted [N, L]
   std::vector<int64_t> perm;
   std::vector<uint16_t> host_sorted;
+  std::string keys;           // docid strings in original row order, '\n'-joined (only when loaded from a file that has them)
   ~rpr_trie() { if (codes) (void)hipFree(codes); }
 };
 
@@ -801,24 +802,108 @@ const int64_t* rpr_trie_perm(const rpr_trie* t) { return t ? t->perm.data() : nu
 
 int rpr_trie_save(const rpr_trie* t, const char* path) {
   RPR_REQUIRE(t && path, "NULL argument");
-  if (save_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V) != 0) {
+  if (save_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V, t->keys, 0, 0) != 0) {
     set_error(std::string("cannot write trie file ") + path);
     return RPR_ERR_INVALID;
   }
   return RPR_OK;
 }
 
+int rpr_trie_build_file(const uint16_t* codes, int64_t N, int32_t L, int32_t V, const char* keys, int64_t key_bytes,
+                        int64_t src_size, int64_t src_mtime_ns, const char* path) {
+  RPR_REQUIRE(codes && path, "NULL argument");
+  RPR_REQUIRE(N > 0 && N < ((int64_t)1 << 31) - 1, "N out of range");
+  RPR_REQUIRE(L >= 1 && L <= 4096 && V >= 1 && V <= 65536, "L or V out of range");
+  RPR_REQUIRE(key_bytes >= 0 && (key_bytes == 0 || keys), "keys missing");
+  for (int64_t i = 0; i < N * L; ++i) RPR_REQUIRE(codes[i] < V, "code >= V");
+  try {
+    std::vector<uint16_t> sorted;
+    std::vector<int64_t> perm;
+    sort_codes(codes, N, L, sorted, perm);
+    const std::string k = key_bytes ? std::string(keys, (size_t)key_bytes) : std::string();
+    if (save_trie_file(path, sorted, perm, N, L, V, k, src_size, src_mtime_ns) != 0) {
+      set_error(std::string("cannot write trie file ") + path);
+      return RPR_ERR_INVALID;
+    }
+  } catch (const std::exception& ex) {
+    set_error(std::string("rpr_trie_build_file: ") + ex.what());
+    return RPR_ERR_OOM;
+  }
+  return RPR_OK;
+}
+
+int rpr_trie_file_info(const char* path, int64_t* N, int32_t* L, int32_t* V, int64_t* key_bytes, int64_t* src_size,
+                       int64_t* src_mtime_ns) {
+  RPR_REQUIRE(path, "NULL argument");
+  int64_t h[6];
+  if (trie_file_info(path, h) != 0) { set_error(std::string("not a readable RPRTRIE2 file: ") + path); return RPR_ERR_INVALID; }
+  if (N) *N = h[0];
+  if (L) *L = (int32_t)h[1];
+  if (V) *V = (int32_t)h[2];
+  if (key_bytes) *key_bytes = h[3];
+  if (src_size) *src_size = h[4];
+  if (src_mtime_ns) *src_mtime_ns = h[5];
+  return RPR_OK;
+}
+
+int rpr_trie_file_validate(const char* path) {
+  RPR_REQUIRE(path, "NULL argument");
+  try {
+    std::vector<uint16_t> sorted; std::vector<int64_t> perm; std::string keys, err;
+    int64_t N; int L, V;
+    if (load_trie_file(path, sorted, perm, N, L, V, keys, err) != 0) {
+      set_error(std::string("invalid trie file ") + path + ": " + err);
+      return RPR_ERR_INVALID;
+    }
+  } catch (const std::exception& ex) {
+    set_error(std::string("rpr_trie_file_validate: ") + ex.what());
+    return RPR_ERR_OOM;
+  }
+  return RPR_OK;
+}
+
 int rpr_trie_load(rpr_ctx* c, const char* path, rpr_trie** out) {
   RPR_REQUIRE(c && path && out, "NULL argument");
-  auto t = std::make_unique<rpr_trie>();
-  t->ctx = c;
-  if (load_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V) != 0) {
-    set_error(std::string("cannot read trie file ") + path);
-    return RPR_ERR_INVALID;
+  try {
+    auto t = std::make_unique<rpr_trie>();
+    t->ctx = c;
+    std::string err;
+    if (load_trie_file(path, t->host_sorted, t->perm, t->N, t->L, t->V, t->keys, err) != 0) {
+      set_error(std::string("cannot load trie file ") + path + ": " + err);
+      return RPR_ERR_INVALID;
+    }
+    int e = upload_trie(c, t);
+    if (e) return e;
+    *out = t.release();
+  } catch (const std::exception& ex) {   // nothing may cross the C ABI
+    set_error(std::string("rpr_trie_load: ") + ex.what());
+    return RPR_ERR_OOM;
   }
-  int e = upload_trie(c, t);
-  if (e) return e;
-  *out = t.release();
+  return RPR_OK;
+}
+
+int rpr_trie_dims(const rpr_trie* t, int64_t* N, int32_t* L, int32_t* V, int64_t* key_bytes) {
+  RPR_REQUIRE(t, "NULL trie");
+  if (N) *N = t->N;
+  if (L) *L = t->L;
+  if (V) *V = t->V;
+  if (key_bytes) *key_bytes = (int64_t)t->keys.size();
+  return RPR_OK;
+}
+
+int rpr_trie_keys(const rpr_trie* t, char* out) {
+  RPR_REQUIRE(t && out, "NULL argument");
+  std::memcpy(out, t->keys.data(), t->keys.size());
+  return RPR_OK;
+}
+
+int rpr_trie_set_vocab(rpr_trie* t, int32_t V) {
+  RPR_REQUIRE(t, "NULL trie");
+  RPR_REQUIRE(V >= 1 && V <= 65536, "V out of range");
+  uint16_t mx = 0;
+  for (uint16_t v : t->host_sorted) mx = v > mx ? v : mx;
+  RPR_REQUIRE((int)mx < V, "a code of the trie is >= the requested vocab size");
+  t->V = V;
   return RPR_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <string>
 #include <thread>
 #include <cstring>
@@ -166,40 +167,91 @@ int read_docid_to_smtid(const char* path, std::vector<uint16_t>& codes, std::str
   return 0;
 }
 
-static const char kMagic[8] = {'R', 'P', 'R', 'T', 'R', 'I', 'E', '1'};
+// ---- binary trie file -----------------------------------------------------------------------------------------------
+// "RPRTRIE2" | int64 N, L, V, key_bytes, src_size, src_mtime_ns | sorted codes uint16[N*L] | perm int64[N] | keys
+// keys = the docid strings in ORIGINAL row order joined by '\n' (key_bytes may be 0: no docids stored);
+// src_size / src_mtime_ns identify the docid_to_smtid.json the file was built from (0 = unknown), so that a caller can
+// tell a stale cache from a fresh one without parsing the JSON.
+static const char kMagic[8] = {'R', 'P', 'R', 'T', 'R', 'I', 'E', '2'};
 
 int save_trie_file(const char* path, const std::vector<uint16_t>& sorted, const std::vector<int64_t>& perm,
-                   int64_t N, int L, int V) {
+                   int64_t N, int L, int V, const std::string& keys, int64_t src_size, int64_t src_mtime_ns) {
   FILE* f = std::fopen(path, "wb");
   if (!f) return -1;
-  int64_t hdr[3] = {N, L, V};
-  bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int64_t), 3, f) == 3 &&
+  int64_t hdr[6] = {N, L, V, (int64_t)keys.size(), src_size, src_mtime_ns};
+  bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int64_t), 6, f) == 6 &&
             std::fwrite(sorted.data(), sizeof(uint16_t), sorted.size(), f) == sorted.size() &&
-            std::fwrite(perm.data(), sizeof(int64_t), perm.size(), f) == perm.size();
+            std::fwrite(perm.data(), sizeof(int64_t), perm.size(), f) == perm.size() &&
+            (keys.empty() || std::fwrite(keys.data(), 1, keys.size(), f) == keys.size());
   ok = (std::fclose(f) == 0) && ok;
   return ok ? 0 : -1;
 }
 
-int load_trie_file(const char* path, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm, int64_t& N, int& L,
-                   int& V) {
+int trie_file_info(const char* path, int64_t hdr_out[6]) {
   FILE* f = std::fopen(path, "rb");
   if (!f) return -1;
   char magic[8];
-  int64_t hdr[3];
-  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kMagic, 8) == 0 &&
-            std::fread(hdr, sizeof(int64_t), 3, f) == 3;
-  if (ok) {
-    N = hdr[0]; L = (int)hdr[1]; V = (int)hdr[2];
-    ok = N > 0 && L > 0 && L <= 4096 && V > 0 && V <= 65536;
-  }
-  if (ok) {
-    sorted.resize((size_t)N * L);
-    perm.resize((size_t)N);
-    ok = std::fread(sorted.data(), sizeof(uint16_t), sorted.size(), f) == sorted.size() &&
-         std::fread(perm.data(), sizeof(int64_t), perm.size(), f) == perm.size();
-  }
+  const bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kMagic, 8) == 0 &&
+                  std::fread(hdr_out, sizeof(int64_t), 6, f) == 6;
   std::fclose(f);
   return ok ? 0 : -1;
+}
+
+// Nothing in the file is trusted: sizes are checked against the file length before any allocation, codes against V,
+// rows against the sorted order the kernels' binary searches rely on, perm against [0, N) and for duplicates.
+int load_trie_file(const char* path, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm, int64_t& N, int& L,
+                   int& V, std::string& keys, std::string& err) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { err = "cannot open file"; return -1; }
+  auto fail = [&](const char* m) { err = m; std::fclose(f); return -1; };
+  char magic[8];
+  int64_t hdr[6];
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kMagic, 8) != 0) return fail("not an RPRTRIE2 file");
+  if (std::fread(hdr, sizeof(int64_t), 6, f) != 6) return fail("truncated header");
+  N = hdr[0];
+  const int64_t kb = hdr[3];
+  if (!(N > 0 && N < ((int64_t)1 << 31) - 1)) return fail("N out of range");
+  if (!(hdr[1] > 0 && hdr[1] <= 4096 && hdr[2] > 0 && hdr[2] <= 65536)) return fail("L or V out of range");
+  if (kb < 0 || kb > ((int64_t)1 << 40)) return fail("key_bytes out of range");
+  L = (int)hdr[1]; V = (int)hdr[2];
+  const int64_t want = 8 + 6 * 8 + N * L * 2 + N * 8 + kb;
+  if (std::fseek(f, 0, SEEK_END) != 0) return fail("seek failed");
+  const int64_t have = (int64_t)std::ftell(f);
+  if (have != want) return fail("file size does not match its header");
+  if (std::fseek(f, 8 + 6 * 8, SEEK_SET) != 0) return fail("seek failed");
+  try {
+    sorted.resize((size_t)N * L);
+    perm.resize((size_t)N);
+    keys.resize((size_t)kb);
+  } catch (const std::exception&) {
+    return fail("out of host memory");
+  }
+  if (std::fread(sorted.data(), sizeof(uint16_t), sorted.size(), f) != sorted.size() ||
+      std::fread(perm.data(), sizeof(int64_t), perm.size(), f) != perm.size() ||
+      (kb && std::fread(&keys[0], 1, (size_t)kb, f) != (size_t)kb))
+    return fail("short read");
+  std::fclose(f);
+  for (size_t i = 0; i < sorted.size(); ++i)
+    if (sorted[i] >= V) { err = "code >= V"; return -1; }
+  for (int64_t i = 1; i < N; ++i) {
+    const uint16_t* a = &sorted[(size_t)(i - 1) * L];
+    const uint16_t* b = a + L;
+    int l = 0;
+    while (l < L && a[l] == b[l]) ++l;
+    if (l < L && a[l] > b[l]) { err = "rows are not sorted"; return -1; }
+  }
+  std::vector<bool> seen((size_t)N, false);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t p = perm[(size_t)i];
+    if (p < 0 || p >= N || seen[(size_t)p]) { err = "perm is not a permutation of [0, N)"; return -1; }
+    seen[(size_t)p] = true;
+  }
+  if (kb) {
+    int64_t lines = 1;
+    for (char c : keys) lines += c == '\n';
+    if (lines != N) { err = "docid key count differs from N"; return -1; }
+  }
+  return 0;
 }
 
 }  // namespace rpr

@@ -126,6 +126,34 @@ def read_docid_to_smtid(path: str):
     return docids, codes
 
 
+def build_trie_file(codes: np.ndarray, V: int, path: str, docids: Optional[Sequence[str]] = None,
+                    source_path: Optional[str] = None) -> None:
+    """HOST ONLY (no GPU, no ctx): sort the docid code matrix and write the binary trie cache (``rpr_trie_build_file``),
+    optionally with the docid strings and the identity (size, mtime) of the JSON the codes came from."""
+    import os
+    lib = _lib.load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint16)
+    N, L = codes.shape
+    keys = "\n".join(docids).encode("utf-8") if docids is not None else b""
+    if docids is not None and len(docids) != N:
+        raise ValueError("one docid per code row expected")
+    size = mtime = 0
+    if source_path is not None:
+        st = os.stat(source_path)
+        size, mtime = st.st_size, st.st_mtime_ns
+    check(lib.rpr_trie_build_file(codes.ctypes.data_as(C.c_void_p), N, L, int(V), keys, len(keys), size, mtime,
+                                  path.encode()), "rpr_trie_build_file")
+
+
+def trie_file_info(path: str) -> dict:
+    """Header of a binary trie file (host only): N, L, V, key_bytes, src_size, src_mtime_ns."""
+    lib = _lib.load()
+    n, l, v, kb, ss, sm = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.rpr_trie_file_info(path.encode(), C.byref(n), C.byref(l), C.byref(v), C.byref(kb), C.byref(ss), C.byref(sm)),
+          "rpr_trie_file_info")
+    return dict(N=n.value, L=l.value, V=v.value, key_bytes=kb.value, src_size=ss.value, src_mtime_ns=sm.value)
+
+
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr
@@ -259,10 +287,34 @@ class DeviceTrie:
         return cls(ctx, h, L, V)
 
     @classmethod
-    def load(cls, ctx: Context, path: str, L: int, V: int) -> "DeviceTrie":
+    def load(cls, ctx: Context, path: str, L: Optional[int] = None, V: Optional[int] = None) -> "DeviceTrie":
+        """Load a binary trie file (``rpr_trie_load`` validates it). The depth is the FILE's; ``V`` (the model's decoder
+        vocab size) may widen the file's vocab (a cache is built without knowing the model). ``L`` is accepted for
+        backward compatibility and only checked against the file."""
         h = C.c_void_p()
         check(ctx.lib.rpr_trie_load(ctx.handle, path.encode(), C.byref(h)), "rpr_trie_load")
-        return cls(ctx, h, L, V)
+        n, fl, fv, kb = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64()
+        check(ctx.lib.rpr_trie_dims(h, C.byref(n), C.byref(fl), C.byref(fv), C.byref(kb)), "rpr_trie_dims")
+        try:
+            if L is not None and L > fl.value:
+                raise RiporHipError(f"{path} holds {fl.value} code columns, {L} requested")
+            if V is not None and V != fv.value:
+                check(ctx.lib.rpr_trie_set_vocab(h, V), "rpr_trie_set_vocab")
+        except Exception:
+            ctx.lib.rpr_free_trie(h)
+            raise
+        t = cls(ctx, h, fl.value, V if V is not None else fv.value)
+        t.key_bytes = kb.value
+        return t
+
+    def docids(self) -> Optional[List[str]]:
+        """docid strings in original row order when the trie came from a file that stores them, else None."""
+        kb = getattr(self, "key_bytes", 0)
+        if not kb:
+            return None
+        buf = C.create_string_buffer(kb)
+        check(self.ctx.lib.rpr_trie_keys(self.handle, buf), "rpr_trie_keys")
+        return buf.raw[:kb].decode("utf-8").split("\n")
 
     def save(self, path: str):
         check(self.ctx.lib.rpr_trie_save(self.handle, path.encode()), "rpr_trie_save")

@@ -205,10 +205,45 @@ def build_smtid_to_docids(docid_to_smtids: Dict[str, Sequence[int]], max_new_tok
     return out
 
 
-def load_docid_table(docid_to_smtid_path: str, vocab_size: int, max_new_token: int):
-    """Reads ``docid_to_smtid.json`` ({"docid": [-1, c1..cL]}) and returns (processor, DocidTable).
-    The code matrix is truncated to ``max_new_token`` columns (sub-smtid retrieval, evaluate.py:442)."""
+def trie_cache_path(docid_to_smtid_path: str) -> str:
+    return os.path.join(os.path.dirname(docid_to_smtid_path), "list_smtid_to_nextids.rprtrie")
+
+
+def fresh_trie_cache(docid_to_smtid_path: str) -> Optional[str]:
+    """Path of the binary trie cache if it exists, stores the docids and was built from the JSON as it is now (same
+    size and mtime as recorded at build time), else None. Host only."""
+    from .engine import trie_file_info
+    cache = trie_cache_path(docid_to_smtid_path)
+    if not (os.path.exists(cache) and os.path.exists(docid_to_smtid_path)):
+        return None
+    try:
+        info = trie_file_info(cache)
+    except RiporHipError:
+        return None
+    st = os.stat(docid_to_smtid_path)
+    if info["key_bytes"] and info["src_size"] == st.st_size and info["src_mtime_ns"] == st.st_mtime_ns:
+        return cache
+    return None
+
+
+def load_docid_table(docid_to_smtid_path: str, vocab_size: int, max_new_token: int, device=None):
+    """Returns (processor, DocidTable) for ``docid_to_smtid.json`` ({"docid": [-1, c1..cL]}).
+
+    Fast path (replaces the reference's pickle cache, evaluate.py:404-408,428-432): when
+    ``list_smtid_to_nextids.rprtrie`` next to the JSON is fresh (written by ``python -m
+    t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids``), the sorted code matrix, the permutation and the docid
+    strings come from it — no JSON parse, no sort. A search over ``max_new_token`` < L positions walks the first
+    ``max_new_token`` columns of the same trie (sub-smtid retrieval, evaluate.py:442).
+    Otherwise the JSON is parsed (streaming C++ reader) and the code matrix truncated to ``max_new_token`` columns."""
     from .engine import read_docid_to_smtid
+    cache = fresh_trie_cache(docid_to_smtid_path)
+    if cache is not None:
+        proc = PrefixConstrainLogitProcessorFastSparse.from_trie_cache(cache, vocab_size)
+        assert proc.max_len >= max_new_token, (proc.max_len, max_new_token)
+        print(f"trie cache: {cache}")
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        return proc, DocidTable(proc.trie(device).docids())
     try:  # streaming C++ reader: seconds and ~0.6 GB for the 8.8 M-doc MS MARCO file
         docids, full = read_docid_to_smtid(docid_to_smtid_path)
     except RiporHipError as e:  # e.g. escaped characters in a docid: the general (slow) JSON path
@@ -305,7 +340,8 @@ def t5seq_aq_retrieve_docids(args):
     if len(set(model.config.decoder_vocab_sizes)) != 1:
         raise ValueError("not valid decoder_vocab_size")
     max_new_token = args.max_new_token_for_docid
-    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], max_new_token)
+    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], max_new_token,
+                                        device=local_rank)
     if rank == 0:
         print("max_new_token: ", max_new_token)
         os.makedirs(args.out_dir, exist_ok=True)
@@ -374,7 +410,8 @@ def t5seq_aq_get_qid_to_smtid_rankdata(args):
     if len(set(model.config.decoder_vocab_sizes)) != 1:
         raise ValueError("not valid decoder_vocab_size")
     assert args.max_new_token in [4, 8, 16, 32], args.max_new_token
-    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], args.max_new_token)
+    processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], args.max_new_token,
+                                        device=local_rank)
     os.makedirs(args.out_dir, exist_ok=True)
     tokenizer = AutoTokenizer.from_pretrained(args.pretrained_path)
     coll = QueryCollection(args.train_query_dir)

@@ -47,6 +47,17 @@ class PrefixConstrainLogitProcessorFastSparse:
                  _codes: Optional[np.ndarray] = None, _trie_cache: Optional[str] = None):
         self.vocab_size = int(vocab_size)
         self.list_smtid_to_next_smtids = list_smtid_to_nextids
+        self._tries: Dict[int, E.DeviceTrie] = {}
+        self._trie_cache = _trie_cache
+        if _trie_cache is not None and _codes is None and list_smtid_to_nextids is None:
+            # binary cache written by aq_preprocess.build_list_smtid_to_nextids (sorted codes + permutation + docids):
+            # nothing is parsed or sorted here, trie() loads the file per device (rpr_trie_load validates it)
+            info = E.trie_file_info(_trie_cache)
+            if info["V"] > self.vocab_size:
+                raise ValueError("smtid token >= vocab_size")
+            self.codes = None
+            self.max_len = info["L"]
+            return
         if _codes is None:
             _codes = self._codes_from_dicts(list_smtid_to_nextids)
         self.codes = np.ascontiguousarray(_codes, dtype=np.uint16)
@@ -55,14 +66,18 @@ class PrefixConstrainLogitProcessorFastSparse:
         if int(self.codes.max()) >= self.vocab_size:
             raise ValueError("smtid token >= vocab_size")
         self.max_len = self.codes.shape[1]
-        self._tries: Dict[int, E.DeviceTrie] = {}
-        self._trie_cache = _trie_cache
 
     # -- constructors -------------------------------------------------------------------------
     @classmethod
-    def from_codes(cls, codes: np.ndarray, vocab_size: int, trie_cache: Optional[str] = None):
+    def from_codes(cls, codes: np.ndarray, vocab_size: int):
         """codes ``[N, L]``: row i = smtid of docid index i."""
-        return cls(None, vocab_size, _codes=codes, _trie_cache=trie_cache)
+        return cls(None, vocab_size, _codes=codes)
+
+    @classmethod
+    def from_trie_cache(cls, path: str, vocab_size: int):
+        """The binary cache next to ``docid_to_smtid.json`` (replaces the reference's ``list_smtid_to_nextids.pkl``,
+        evaluate.py:404-408): see :func:`ripor_amd.engine.build_trie_file`."""
+        return cls(None, vocab_size, _trie_cache=path)
 
     @classmethod
     def from_docid_to_smtid(cls, docid_to_smtids: Dict[str, Sequence[int]], vocab_size: int):
@@ -100,7 +115,10 @@ class PrefixConstrainLogitProcessorFastSparse:
         ctx = E.Context.get(device)
         idx = ctx.device.index
         if idx not in self._tries:
-            self._tries[idx] = E.DeviceTrie.from_codes(ctx, self.codes, self.vocab_size)
+            if self.codes is None:
+                self._tries[idx] = E.DeviceTrie.load(ctx, self._trie_cache, V=self.vocab_size)
+            else:
+                self._tries[idx] = E.DeviceTrie.from_codes(ctx, self.codes, self.vocab_size)
         return self._tries[idx]
 
     def docid_rows(self, device, lo: int, hi: int) -> np.ndarray:
