@@ -235,6 +235,10 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
     g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
     g.resid_h = O.resid_h; g.r_ps = O.ps; g.ldrh = O.ldh; g.ssq_out = O.ssq_out;
+    // timing ablations (results are wrong with any bit set): 1 = no row-sum atomics, 2 = no consumer row scale
+    static const int dbg = [] { const char* e = getenv("RPR_DEBUG_FUSED"); return e ? atoi(e) : 0; }();
+    if (dbg & 1) g.ssq_out = nullptr;
+    if (dbg & 2) g.row_ssq = nullptr;
     g.sat = L.c->status;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {

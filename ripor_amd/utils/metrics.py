@@ -2,8 +2,20 @@
 
 Mirrors the call surface of reference t5_pretrainer/utils/metrics.py (``truncate_run`` :9-15,
 ``mrr_k`` :18-25, ``load_and_evaluate`` :63-79) for the metrics the generative-retrieval branch of
-full_evaluate_t5seq_aq_encoder.sh asks for (mrr_10, recall, ndcg_cut). trec_eval's ranking rule is
-kept: documents are ordered by score descending, ties by docid descending (string order).
+full_evaluate_t5seq_aq_encoder.sh asks for (mrr_10, recall, ndcg_cut).
+
+Rules restated from trec_eval 9.0 (the C library pytrec_eval wraps; not available offline, so these are pinned by
+hand-computed vectors in tests/test_host_logic.py rather than by running it):
+  * ranking (trec_eval form_res_rels.c, comp_sim_docno): documents of a query are ordered by score DESCENDING and,
+    at equal score, by docno DESCENDING (byte-wise string compare); the score field is a C float (trec_eval.h
+    TEXT_RESULTS.sim), so scores are compared after rounding to float32;
+  * only queries present in BOTH the run and the qrels are evaluated and averaged (pytrec_eval RelevanceEvaluator);
+  * recip_rank (m_recip_rank.c): 1 / rank of the first document with relevance >= 1, 0 if none is retrieved;
+  * recall_k (m_recall.c): relevant documents among the first k / all documents with relevance >= 1 in the qrels,
+    k in 5, 10, 15, 20, 30, 100, 200, 500, 1000;
+  * ndcg_cut_k (m_ndcg_cut.c): gain = the relevance level itself (linear), discount log2(rank + 1), ideal DCG from the
+    qrels' positive levels sorted descending and cut at k; same cutoffs.
+``truncate_run`` is the reference's own helper (stable sort by score only, so a tie AT the cut keeps run-file order).
 """
 from __future__ import annotations
 
@@ -24,7 +36,8 @@ def truncate_run(run: Dict[str, Dict[str, float]], k: int):
 
 
 def _trec_rank(docs: Dict[str, float]):
-    return [d for d, _ in sorted(docs.items(), key=lambda it: (it[1], it[0]), reverse=True)]
+    import numpy as np
+    return [d for d, _ in sorted(docs.items(), key=lambda it: (float(np.float32(it[1])), it[0]), reverse=True)]
 
 
 def mrr_k(run, qrel, k: int, agg: bool = True):

@@ -316,3 +316,154 @@ def test_trie_file_validation_rejects_corrupt_files(tmp_path):
     bad(lambda b: b.__setitem__(slice(off, off + 8), bytes(b[off + 8:off + 16])), "perm duplicate")
     with pytest.raises(E.RiporHipError):
         E.build_trie_file(codes, 16, str(tmp_path / "x.rprtrie"))                                   # code >= V
+
+
+# ---- evaluator pinned to trec_eval's documented rules, query front-end edge cases --------------------
+def _trec_vectors():
+    """Small run/qrels with score ties, a tie at the truncation cut, graded relevance, an unjudged-only query, queries
+    missing on either side and more than k retrieved documents. Expected values are worked out by hand below."""
+    run = {
+        # tie d1/d2 at the top: docno descending puts d2 first -> ranking d2, d1, d3, d4
+        "q1": {"d1": 3.0, "d2": 3.0, "d3": 2.0, "d4": 1.0},
+        # 12 documents, the only relevant one at rank 11
+        "q2": {f"a{i:02d}": float(13 - i) for i in range(1, 13)},
+        "q3": {"x": 1.0},                                   # not judged: ignored
+        # 11 documents, ranks 10 and 11 tie; "z" was written to the run first, so truncate_run(10) keeps z, drops y
+        "q5": {**{f"b{i}": float(20 - i) for i in range(9)}, "z": 5.0, "y": 5.0},
+        "q6": {"m": 2.0, "n": 1.0},                         # nothing relevant retrieved
+    }
+    qrel = {
+        "q1": {"d1": 0, "d2": 1, "d3": 2, "d9": 1},
+        "q2": {"a11": 1},
+        "q4": {"w": 1},                                     # not in the run: ignored
+        "q5": {"y": 1},
+        "q6": {"k": 3, "n": 0},
+    }
+    return run, qrel
+
+
+def test_metrics_follow_trec_eval_rules():
+    import math
+    from ripor_amd.utils import metrics as M
+    run, qrel = _trec_vectors()
+    # recip_rank after truncate_run(10): q1 -> d2 at rank 1 = 1; q2 -> relevant doc at rank 11 is cut = 0;
+    # q5 -> y dropped by the stable truncation = 0; q6 -> 0. Mean over the 4 judged queries of the run.
+    per_q = M.mrr_k(run, qrel, 10, agg=False)
+    assert per_q == {"q1": {"recip_rank": 1.0}, "q2": {"recip_rank": 0.0}, "q5": {"recip_rank": 0.0}, "q6": {"recip_rank": 0.0}}
+    assert M.mrr_k(run, qrel, 10) == pytest.approx(0.25)
+    # with y written first it survives the cut; inside the truncated list trec_eval ranks it 10th (b0..b8 precede it)
+    run2 = dict(run)
+    run2["q5"] = {**{f"b{i}": float(20 - i) for i in range(9)}, "y": 5.0, "z": 5.0}
+    assert M.mrr_k(run2, qrel, 10, agg=False)["q5"]["recip_rank"] == pytest.approx(0.1)
+    # untruncated, the tie y/z is ordered z, y (docno descending): y is 11th
+    assert M._trec_rank(run["q5"])[-2:] == ["z", "y"]
+    # scores are compared as float32 (trec_eval's sim field): 1 + 1e-9 ties with 1 -> docno descending
+    assert M._trec_rank({"a": 1.0, "b": 1.0 + 1e-9, "c": 0.5}) == ["b", "a", "c"]
+    assert M._trec_rank({"b": 1.0, "a": 1.0 + 1e-9, "c": 0.5}) == ["b", "a", "c"]
+
+    rec = M.evaluate(run, qrel, "recall", agg=False)
+    assert rec["q1"]["recall_5"] == pytest.approx(2 / 3)        # d2, d3 of {d2, d3, d9}
+    assert rec["q2"]["recall_10"] == 0.0 and rec["q2"]["recall_15"] == 1.0
+    assert rec["q5"]["recall_10"] == 0.0 and rec["q5"]["recall_15"] == 1.0   # untruncated run: y is 11th
+    assert rec["q6"]["recall_1000"] == 0.0
+    assert set(rec) == {"q1", "q2", "q5", "q6"}
+    agg = M.evaluate(run, qrel, "recall")
+    assert agg["recall_5"] == pytest.approx((2 / 3 + 0 + 0 + 0) / 4)
+    assert agg["recall_15"] == pytest.approx((2 / 3 + 1 + 1 + 0) / 4)
+    assert sorted(agg) == sorted(f"recall_{c}" for c in (5, 10, 15, 20, 30, 100, 200, 500, 1000))
+
+    nd = M.evaluate(run, qrel, "ndcg_cut", agg=False)
+    # q1 ranking d2(1) d1(0) d3(2) d4(-): DCG = 1/log2(2) + 2/log2(4) = 2; ideal 2, 1, 1: 2 + 1/log2(3) + 1/2
+    assert nd["q1"]["ndcg_cut_5"] == pytest.approx(2.0 / (2.0 + 1.0 / math.log2(3) + 0.5))
+    # q2: gain 1 at rank 11: ndcg@10 = 0, ndcg@15 = (1/log2(12)) / 1
+    assert nd["q2"]["ndcg_cut_10"] == 0.0 and nd["q2"]["ndcg_cut_15"] == pytest.approx(1.0 / math.log2(12))
+    assert nd["q6"]["ndcg_cut_5"] == 0.0                     # ideal DCG 3 (doc k), nothing retrieved
+    # graded gain is linear (trec_eval), not 2^rel - 1: one document of level 3 at rank 2 under an ideal [3]
+    assert M.evaluate({"q": {"u": 2.0, "v": 1.0}}, {"q": {"v": 3}}, "ndcg_cut", agg=False)["q"]["ndcg_cut_5"] == \
+        pytest.approx((3 / math.log2(3)) / 3)
+
+
+def test_load_and_evaluate_reference_call_surface(tmp_path):
+    from ripor_amd.utils import metrics as M
+    run, qrel = _trec_vectors()
+    d = tmp_path / "TREC_DL_2019"
+    d.mkdir()
+    json.dump(qrel, open(d / "qrel.json", "w")); json.dump(qrel, open(d / "qrel_binary.json", "w"))
+    json.dump(run, open(tmp_path / "run.json", "w"))
+    assert M.load_and_evaluate(str(d / "qrel_binary.json"), str(tmp_path / "run.json"), "mrr_10") == {"mrr_10": pytest.approx(0.25)}
+    assert "ndcg_cut_10" in M.load_and_evaluate(str(d / "qrel.json"), str(tmp_path / "run.json"), "ndcg_cut")
+    with pytest.raises(AssertionError):   # reference utils/metrics.py:70-71: graded qrels for ndcg only, binary for the rest
+        M.load_and_evaluate(str(d / "qrel.json"), str(tmp_path / "run.json"), "recall")
+
+
+def test_evaluate_cli_defaults_match_the_reference_script(tmp_path):
+    """the stock script passes five qrels and no --eval_metric; the default must pair each with its metrics
+    (reference arguments.py:170-175) and a shorter list must be refused instead of silently truncating."""
+    args = EV.get_args([])
+    assert args.eval_metric == [["mrr_10", "recall"], ["ndcg_cut"], ["mrr_10", "recall"], ["ndcg_cut"], ["mrr_10", "recall"]]
+    run, qrel = _trec_vectors()
+    names = ["dev_qrel", "TREC_DL_2019", "TREC_DL_2019b", "TREC_DL_2020", "TREC_DL_2020b"]
+    qpaths = []
+    for i, n in enumerate(names):
+        sub = tmp_path / n
+        sub.mkdir()
+        fn = "qrel.json" if i in (1, 3) else ("qrel_binary.json" if i else "dev_qrel.json")
+        json.dump(qrel, open(sub / fn, "w"))
+        qpaths.append(str(sub / fn))
+        out = tmp_path / "out" / EV.get_dataset_name(str(sub / fn))
+        out.mkdir(parents=True, exist_ok=True)
+        json.dump(run, open(out / "run.json", "w"))
+    a = EV.get_args(["--out_dir", str(tmp_path / "out"), "--eval_qrel_path"] + qpaths)
+    res = EV.evaluate(a)
+    assert len(res) >= 3 and all(("mrr_10" in v) or ("ndcg_cut_10" in v) for v in res.values())
+    b = EV.get_args(["--out_dir", str(tmp_path / "out"), "--eval_qrel_path"] + qpaths + ["--eval_metric", '[["mrr_10"]]'])
+    with pytest.raises(ValueError, match="eval_metric"):
+        EV.evaluate(b)
+
+
+def test_query_collection_reader_edge_cases(tmp_path):
+    """raw.tsv reader against the reference's parsing rule (dataset/dataset.py:279-288: split on tabs, remaining fields
+    joined by one space, line breaks removed, lines of length <= 1 skipped, prefix "query: ")."""
+    d = tmp_path / "queries"
+    d.mkdir()
+    with open(d / "raw.tsv", "w") as f:
+        f.write("7\twhat is a  tab\tseparated query\n")     # extra tab inside the text -> joined by a space
+        f.write("\n")                                        # empty line: skipped
+        f.write("12 \t trailing and leading spaces \n")      # id is stripped, text is not (reference keeps it)
+        f.write("3\tlast line without newline")
+    coll = EV.QueryCollection(str(d))
+    assert coll.ids == ["7", "12", "3"]
+    assert coll.texts == ["query: what is a  tab separated query", "query:  trailing and leading spaces ",
+                          "query: last line without newline"]
+    # reference restatement of the same lines
+    ref = []
+    for line in open(d / "raw.tsv"):
+        if len(line) > 1:
+            id_, *data = line.split("\t")
+            ref.append((id_.strip(), "query: " + " ".join(" ".join(data).splitlines())))
+    assert list(zip(coll.ids, coll.texts)) == ref
+
+
+def test_query_batches_pad_to_longest_and_truncate(tmp_path):
+    """query_batches vs the reference collate (dataset/dataloader.py:62-79): pad to the longest of the batch, truncate
+    at max_length (256 in evaluate.py:466), attention mask, int64 ids from the id column."""
+    class Tok:   # whitespace tokenizer with the HF call signature the collate uses
+        def __call__(self, texts, add_special_tokens=True, padding="longest", truncation="longest_first", max_length=256,
+                     return_attention_mask=True):
+            assert padding == "longest" and truncation == "longest_first" and add_special_tokens
+            ids = [[(hash(w) % 97) + 3 for w in t.split()][: max_length - 1] + [1] for t in texts]
+            m = max(len(x) for x in ids)
+            return {"input_ids": [x + [0] * (m - len(x)) for x in ids], "attention_mask": [[1] * len(x) + [0] * (m - len(x)) for x in ids]}
+
+    d = tmp_path / "q"
+    d.mkdir()
+    with open(d / "raw.tsv", "w") as f:
+        f.write("1\tshort one\n2\t" + " ".join(["w"] * 400) + "\n3\tthree words here\n")
+    coll = EV.QueryCollection(str(d))
+    batches = list(EV.query_batches(coll, Tok(), [0, 1, 2], batch_size=2, max_length=256))
+    assert [b["id"].tolist() for b in batches] == [[1, 2], [3]]
+    b0 = batches[0]
+    assert b0["input_ids"].shape == (2, 256) and b0["attention_mask"].dtype == torch.int64     # truncated at 256 incl. </s>
+    assert int(b0["attention_mask"][0].sum()) == 4 and int(b0["attention_mask"][1].sum()) == 256   # "query:" + 2 words + </s>
+    assert b0["input_ids"][0, 4:].eq(0).all() and b0["input_ids"][1, -1] == 1
+    assert batches[1]["input_ids"].shape == (1, 5)
