@@ -244,15 +244,18 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
 template <bool FULL, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
-                                                int lane, int bm, int bn, int wm, int wn) {
+                                                int lane, int bm, int bn, int wm, int wn, const float* rs_tile) {
   constexpr int BM = 256, BN = 256;
   // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
   // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
   // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
   // operand LDS and streams them out row-wise with 16-byte accesses. The epilogue is bound by the NUMBER of
-  // store instructions, not by their bytes (measured: adding two 8-byte plane stores per float4 tripled it), so
-  // the f16-plane outputs give a lane 8 consecutive columns = one 16-byte store per plane.
+  // memory instructions and by its VALU work, not by bytes (measured: two extra 8-byte plane stores per float4
+  // tripled it; ~20 VALU ops per plane element cost ~5 us per tile; a global load of the fused-RMSNorm row scales
+  // cost a full memory latency per half), so the f16-plane outputs give a lane 8 consecutive columns = one 16-byte
+  // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
+  // one max per element plus one compare per half.
   __syncthreads();                                   // all waves are done reading operand tiles
   const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
@@ -277,40 +280,44 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       const int n0 = bn + wn * (BN / WN) + rc8;
       const bool ncol_ok = FULL || (n0 < g.N);          // N % 32 == 0
       uint4 rh[NK], rl_[NK];
-      float rsc[NK];
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int m = mrow0 + k * RPI + rrow;
         const bool ok = ncol_ok && (FULL || m < Mlim);
-        rsc[k] = (g.row_ssq && (FULL || m < Mlim)) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
         if (g.resid_h) {
           rh[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
           rl_[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + g.r_ps + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
         }
       }
-      const float ps = g.plane_scale, ips = 1.0f / g.plane_scale;
+      const float ps = g.plane_scale;
+      float amax = 0.f;                                 // split_f16's range check: one max per element, one compare per half
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         const bool ok = ncol_ok && (FULL || m < Mlim);
+        const float sc = rs_tile ? g.acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : g.acc_scale;
         float v[8];
         *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
         *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
         __half h[8], l[8];
-        float ss = 0.f;
+        float ss = 0.f, am = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float x = v[e] * g.acc_scale;
-          if (g.row_ssq) x *= rsc[k];
+          float x = v[e] * sc;
           if (g.relu) x = fmaxf(x, 0.f);
-          if (g.resid_h) x += x_from_planes(reinterpret_cast<const __half*>(&rh[k])[e], reinterpret_cast<const __half*>(&rl_[k])[e]);
-          split_f16(x * ps, h[e], l[e], ok ? g.sat : nullptr);
-          const float xr = (__half2float(h[e]) + __half2float(l[e])) * ips;   // what the planes carry
-          ss += xr * xr;
+          if (g.resid_h) x += __half2float(reinterpret_cast<const __half*>(&rh[k])[e]) +
+                              __half2float(reinterpret_cast<const __half*>(&rl_[k])[e]);   // X_PLANE_SCALE == 1
+          ss = fmaf(x, x, ss);
+          float xs = x * ps;
+          am = fmaxf(am, fabsf(xs));
+          xs = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
+          h[e] = __float2half_rn(xs);
+          l[e] = __float2half_rn(xs - __half2float(h[e]));
         }
         if (ok) {
           *reinterpret_cast<uint4*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(h);
           *reinterpret_cast<uint4*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(l);
+          amax = fmaxf(amax, am);
         }
         if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
           if (!ok) ss = 0.f;
@@ -319,6 +326,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
           if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
         }
       }
+      if (amax > 65504.f && g.sat) *g.sat = 1u;
     } else {
       // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes)
       constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = 64 / RPI;   // lanes per staged row, rows per read instruction
@@ -329,14 +337,6 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       float* outp = g.out[oi];
       const int ldo = g.ldo[oi];
       float4 res[NK];
-      float rsc[NK];
-      if (g.row_ssq) {   // fused RMSNorm: per-row scale of the consumer
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const int m = mrow0 + k * RPI + rrow;
-          rsc[k] = (FULL || m < Mlim) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
-        }
-      }
       if (g.resid) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -349,8 +349,8 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-        v.x *= g.acc_scale; v.y *= g.acc_scale; v.z *= g.acc_scale; v.w *= g.acc_scale;
-        if (g.row_ssq) { v.x *= rsc[k]; v.y *= rsc[k]; v.z *= rsc[k]; v.w *= rsc[k]; }
+        const float sc = rs_tile ? g.acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : g.acc_scale;   // fused RMSNorm row scale
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
         if (ncol_ok && (FULL || m < Mlim)) *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
   constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
+  __shared__ float rs_tile[BM];                      // fused RMSNorm: rsqrt(mean(x^2) + eps) of the tile's rows
 
   int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -394,6 +395,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  if (g.row_ssq && tid < BM) {   // one dependent load + rsqrt per row, hidden behind the first K-tile's DMA; the epilogue
+    const int m = bm + tid;      // (after the K-loop's barriers) reads the scales from LDS instead of global memory
+    rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+  }
 
   const __half* src[PER_WAVE];
 #pragma unroll
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 #undef PP_M_END
 #undef PP_STAMP
 
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn);
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr);
 }
 
 // ---- skinny variant: M <= 400 rows (one to a few dozen queries in flight) ---------------------------------------
