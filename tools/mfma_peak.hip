@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(const _Float16* __restrict
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i + it) & 3], acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
   }
   float s = 0.f;
   for (int i = 0; i < NACC; ++i)
