@@ -332,7 +332,7 @@ def main():
             if os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
                 try:
                     pmc = json.load(open(pmc_path))
-                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel<true" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
                     if key:
                         # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
                         traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
@@ -340,9 +340,11 @@ def main():
                                        "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
                         # the counters come from an earlier profiled run of tools/profile_round.sh: refuse them when that
                         # run's launch count per step no longer matches this build's (kernels changed since)
-                        n_pmc = pmc["FETCH_SIZE"][key[0]]["launches"]
-                        if n_pmc != g["launches"]:
-                            traffic_src = (f"stale: profiles/latest_hbm_pmc.json has {n_pmc} launches of the kernel per step, "
+                        kn = "gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel"
+                        n_pmc = sum(v["launches"] for k, v in pmc["FETCH_SIZE"].items() if isinstance(v, dict) and kn in k)
+                        n_pmc /= float(pmc.get("_meta", {}).get("steps_in_pmc_pass", 1))
+                        if abs(n_pmc - g["launches"]) > 0.5:
+                            traffic_src = (f"stale: profiles/latest_hbm_pmc.json has {n_pmc:g} launches of the kernel per step, "
                                            f"this build {g['launches']}; re-run tools/profile_round.sh")
                             traffic = None
                 except Exception:
@@ -367,7 +369,7 @@ def main():
                 sa_traffic = None
                 try:
                     pmc = json.load(open(os.path.join(REPO, "profiles", "latest_hbm_pmc.json")))
-                    ks = [k for k in pmc["FETCH_SIZE"] if "dec_self_attn_fast_kernel" in k]
+                    ks = [k for k in pmc["FETCH_SIZE"] if "dec_self_attn_fast_kernel" in k or "dec_self_attn_kv3_kernel" in k]
                     tot_b = sum((2.0 * pmc["FETCH_SIZE"][k]["sum"] + pmc["WRITE_SIZE"][k]["sum"]) * 1024.0 for k in ks)
                     n = sum(pmc["FETCH_SIZE"][k]["launches"] for k in ks)
                     sa_traffic = tot_b / n if n else None
