@@ -209,9 +209,7 @@ struct LinOut {                                                              // 
   int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
   float plane_scale;                                                         //   scale of the planes written to h (0 = 1)
   const __half* resid_h; unsigned long long* ssq_out;                        //   fused RMSNorm producer: residual read from the
-                                                                             //   planes h (in place), row sums accumulated
-  __half* kv_hi[2]; uint8_t* kv_lo[2];                                       //   3-byte K/V cache rows for column blocks 1, 2
-};
+};                                                                           //   planes h (in place), row sums accumulated
 
 LinOut out_f32(float* p, int ld, int N, const float* resid = nullptr, int relu = 0) {
   LinOut o{};
@@ -237,7 +235,6 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
     g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
     g.resid_h = O.resid_h; g.r_ps = O.ps; g.ldrh = O.ldh; g.ssq_out = O.ssq_out;
-    g.kv_hi[0] = O.kv_hi[0]; g.kv_hi[1] = O.kv_hi[1]; g.kv_lo[0] = O.kv_lo[0]; g.kv_lo[1] = O.kv_lo[1];
     // timing ablations (results are wrong with any bit set): 1 = no row-sum atomics, 2 = no consumer row scale
     static const int dbg = [] { const char* e = getenv("RPR_DEBUG_FUSED"); return e ? atoi(e) : 0; }();
     if (dbg & 1) g.ssq_out = nullptr;
@@ -437,8 +434,6 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // Off when debug taps are requested (they expect [Q*B, V] logits per step) or RPR_STEP0_SHARED=0.
   static const bool step0_env = [] { const char* e = getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
   const bool shared0 = step0_env && !taps && B > 1;
-  static const bool kv3_env = [] { const char* e = getenv("RPR_KV3"); return !(e && atoi(e) == 0); }();
-  const bool kv3 = h2 && kv3_env && kv_layout == 2;   // 3-byte K/V cache (split-precision mode, head-major layout)
   int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
   const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
   auto norm = [&](const float* wgt, float post_scale = 1.0f) {   // exact-fp32 mode only (see XStream)
@@ -455,34 +450,21 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
                               h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
     });
     for (int i = 0; i < nd; ++i) {
-      // exact-fp32 mode: fp32 K/V rows. Split-precision mode: the 3-byte kv3 format (common.h) — per layer an f16 hi
-      // plane and a byte lo plane with the same element offsets, inside the same allocation (hi planes of all layers
-      // first, then the lo planes): the HBM-bound self-attention reads 25 % fewer bytes.
       float* kc = P<float>(w.kcache) + i * layer_stride;
       float* vc = P<float>(w.vcache) + i * layer_stride;
-      __half* kh = P<__half>(w.kcache) + i * layer_stride;
-      __half* vh = P<__half>(w.vcache) + i * layer_stride;
-      uint8_t* kl = reinterpret_cast<uint8_t*>(P<__half>(w.kcache) + (size_t)nd * layer_stride) + i * layer_stride;
-      uint8_t* vl = reinterpret_cast<uint8_t*>(P<__half>(w.vcache) + (size_t)nd * layer_stride) + i * layer_stride;
       if (!h2) norm(m->dec_ln0[i]);
       {  // q -> qb, k/v -> cache row block of position t
         LinOut o{};
         o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
         o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
         o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
-        if (kv3) {
-          o.f[1] = o.f[2] = nullptr;
-          o.kv_hi[0] = kh + (size_t)t * kv_pos; o.kv_lo[0] = kl + (size_t)t * kv_pos;
-          o.kv_hi[1] = vh + (size_t)t * kv_pos; o.kv_lo[1] = vl + (size_t)t * kv_pos;
-        }
         linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o);
       }
       {
-        DecSelfAttnArgs a{qb, kv3 ? nullptr : kc, kv3 ? nullptr : vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias,
-                          m->dec_bucket, attn, Q, Bt, H, t, h2 ? attn_h : nullptr, ps_i, c->status,
-                          kv3 ? kh : nullptr, kv3 ? kl : nullptr, kv3 ? vh : nullptr, kv3 ? vl : nullptr};
+        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
+                          h2 ? attn_h : nullptr, ps_i, c->status};
         Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Rt * H * (double)(t + 1) * DKV,
-               4.0 * (double)Rt * inner * 2 + (kv3 ? 3.0 : 4.0) * 2.0 * Rt * (double)(t + 1) * inner, [&] { return launch_dec_self_attn(a, s); });
+               4.0 * ((double)Rt * inner * 2 + 2.0 * Rt * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
       }
       linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x));
       if (!h2) norm(m->dec_ln1[i]);

@@ -44,30 +44,6 @@ __device__ __forceinline__ void split_f16(float x, __half& hi, __half& lo, unsig
   lo = __float2half_rn(x - __half2float(hi));
 }
 
-// ---- "kv3": 3-byte storage of the self-attention K/V cache (split-precision mode) -----------------------------------
-// x ~ hi + (lo - 128) * 2^-18 * 2^floor(log2|hi|): hi = f16(x) (11 significant bits), lo = the residual x - hi in
-// units of 1/128 of half an ulp of hi, as a biased byte: 18-19 significant bits in 3 bytes. The self-attention kernel
-// is HBM-bound on exactly these bytes (every beam re-reads its whole ancestry every step), so 3 instead of 4 bytes per
-// element is 25 % less traffic; measured in the oracle on the t5-base golden model (tools/kv_format_probe.py): logits
-// move by <= 3.9e-5, beam scores by <= 2.4e-6. The exact-fp32 mode keeps fp32 K/V.
-__device__ __forceinline__ void kv3_encode(float x, __half& hi, uint8_t& lo, unsigned int* sat) {
-  if (!(fabsf(x) <= 65504.f)) {
-    if (sat) *sat = 1u;
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
-  }
-  hi = __float2half_rn(x);
-  const unsigned short eb = (unsigned short)(__half_as_ushort(hi) & 0x7C00u);
-  const float p = __half2float(__ushort_as_half(eb));                          // 2^floor(log2|hi|); 0 for subnormal hi
-  const float inv = __int_as_float((254 << 23) - __float_as_int(p));           // 1 / p (p is a power of two)
-  float q = p > 0.f ? rintf((x - __half2float(hi)) * inv * 262144.f) : 0.f;    // |residual| <= p * 2^-11  ->  |q| <= 128
-  q = fminf(fmaxf(q, -127.f), 127.f);
-  lo = (uint8_t)((int)q + 128);
-}
-__device__ __forceinline__ float kv3_decode(__half hi, unsigned int lo_byte) {
-  const float p = __half2float(__ushort_as_half((unsigned short)(__half_as_ushort(hi) & 0x7C00u)));
-  return fmaf((float)lo_byte - 128.f, p * 3.814697265625e-06f, __half2float(hi));
-}
-
 // Row sum of squares in fixed point (2^-20 units, int64): partial sums from different blocks are combined with
 // integer atomics, so the total does not depend on the order of arrival (bitwise-reproducible RMSNorm scale).
 constexpr float SSQ_FIX = 1048576.0f;
@@ -116,9 +92,6 @@ struct GemmH2Args {
   // written back as planes (out_h) and the tile's part of every row's sum of squares is added to ssq_out.
   const unsigned long long* row_ssq; float inv_d_fix, eps;
   const __half* resid_h; size_t r_ps; int ldrh; unsigned long long* ssq_out;
-  // kv3 K/V cache (non-null: output blocks 1 and 2 go to kv_hi[i-1] / kv_lo[i-1] in the 3-byte format through the
-  // same element map (rm_*) instead of fp32 rows at out[i])
-  __half* kv_hi[2]; uint8_t* kv_lo[2];
   unsigned int* sat;                       // sticky saturation word of the ctx (split_f16)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
@@ -205,8 +178,6 @@ struct DecSelfAttnArgs {
   int Q, B, H, t;
   __half* out_h; size_t o_ps;
   unsigned int* sat;
-  const __half* k_hi; const uint8_t* k_lo;   // kv3 cache (split-precision mode; kcache / vcache are null then):
-  const __half* v_hi; const uint8_t* v_lo;   //   same element offsets into the f16 hi plane and the byte lo plane
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 

@@ -221,11 +221,6 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
             g.out_h[(size_t)m * g.ldoh + n] = hi;
             g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
             v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;   // the value the planes carry (row sums below)
-          } else if (g.kv_hi[0] && oi) {   // K / V row of the 3-byte cache
-            __half hi; uint8_t lo;
-            kv3_encode(v, hi, lo, g.sat);
-            const size_t o = out_off(g, oi, m, ldo, on);
-            g.kv_hi[oi - 1][o] = hi; g.kv_lo[oi - 1][o] = lo;
           } else {
             outp[out_off(g, oi, m, ldo, on)] = v;
           }
@@ -329,45 +324,6 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 #pragma unroll
           for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
           if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
-        }
-      }
-      if (amax > 65504.f && g.sat) *g.sat = 1u;
-    } else if (g.kv_hi[0]) {
-      // ---- q (fp32) | K | V (3-byte cache rows) of the self-attention projection: 8 columns per lane, so a K/V row
-      //      piece is one 16-byte hi store + one 8-byte lo store (same store count per element as float4 rows)
-      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = 64 / RPI;
-      const int rrow = lane / LPR, rc8 = (lane % LPR) * 8;
-      const int n0 = bn + wn * (BN / WN) + rc8;
-      const bool ncol_ok = FULL || (n0 < g.N);
-      const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;   // a 256-wide tile lies in one block
-      float amax = 0.f;
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int rl = k * RPI + rrow, m = mrow0 + rl;
-        const bool ok = ncol_ok && (FULL || m < Mlim);
-        const float sc = rs_tile ? g.acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : g.acc_scale;
-        float v[8];
-        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
-        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= sc;
-        if (!ok) continue;
-        const size_t o = out_off(g, oi, m, g.ldo[oi], on);
-        if (oi == 0) {
-          *reinterpret_cast<float4*>(g.out[0] + o) = *reinterpret_cast<const float4*>(v);
-          *reinterpret_cast<float4*>(g.out[0] + o + 4) = *reinterpret_cast<const float4*>(v + 4);
-        } else {
-          __half h[8];
-          unsigned int lw[2] = {0u, 0u};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            amax = fmaxf(amax, fabsf(v[e]));
-            uint8_t lo;
-            kv3_encode(__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f), h[e], lo, nullptr);
-            lw[e >> 2] |= (unsigned int)lo << (8 * (e & 3));
-          }
-          *reinterpret_cast<uint4*>(g.kv_hi[oi - 1] + o) = *reinterpret_cast<uint4*>(h);
-          *reinterpret_cast<uint2*>(g.kv_lo[oi - 1] + o) = make_uint2(lw[0], lw[1]);
         }
       }
       if (amax > 65504.f && g.sat) *g.sat = 1u;
@@ -693,11 +649,6 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
         g.out_h[(size_t)m * g.ldoh + n] = hi;
         g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
         v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;
-      } else if (g.kv_hi[0] && oi) {   // K / V row of the 3-byte cache
-        __half hi; uint8_t lo;
-        kv3_encode(v, hi, lo, g.sat);
-        const size_t o = out_off(g, oi, m, ldo, on);
-        g.kv_hi[oi - 1][o] = hi; g.kv_lo[oi - 1][o] = lo;
       } else {
         outp[out_off(g, oi, m, ldo, on)] = v;
       }

@@ -495,135 +495,10 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   }
 }
 
-// ---- kv3 variant: K/V as f16 hi + biased-byte lo (common.h), 3 bytes per element -----------------------------------
-// Same work split (one wave per (beam, head), everything requested up front, no LDS), but a cache row is 128 B of hi +
-// 64 B of lo, so the wave is 8 groups of 8 lanes: a lane owns 8 consecutive dims (one 16-B hi load + one 8-B lo load
-// per row) and a wave instruction covers 8 key rows. MAXIT = groups of 8 keys held in registers (12 VGPRs per group for
-// K and V together, against 16 per 4 keys of the fp32 kernel).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-template <int MAXIT>
-__global__ __launch_bounds__(256) void dec_self_attn_kv3_kernel(DecSelfAttnArgs a) {
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7, k = bid >> 3;
-    bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + k;
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int B = a.B, H = a.H, t = a.t;
-  const int w = bid * 4 + wave;
-  const int R = a.Q * B, inner = H * DKV;
-  if (w >= R * H) return;
-  const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
-  const int r = qi * B + b;
-  const int g = lane >> 3, li = lane & 7;
-  const int nkeys = t + 1;
-  const uint16_t* ancr = a.anc + (size_t)r * a.anc_ld;
-
-  size_t off[MAXIT];
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int p = it * 8 + g;
-    const int pc = p < nkeys ? p : t;
-    const int slot = (pc == t) ? b : (int)ancr[pc];
-    off[it] = (size_t)qi * a.q_stride + (size_t)h * a.h_stride + (size_t)pc * a.pos_stride + (size_t)slot * a.slot_stride + li * 8;
-  }
-  float q[8];
-  *reinterpret_cast<float4*>(q) = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 8);
-  *reinterpret_cast<float4*>(q + 4) = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 8 + 4);
-  u32x4 kh[MAXIT], vh[MAXIT];
-  u32x2 kl[MAXIT], vl[MAXIT];
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it * 8 < nkeys) {
-      kh[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.k_hi + off[it]));
-      kl[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(a.k_lo + off[it]));
-    }
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it * 8 < nkeys) {
-      vh[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.v_hi + off[it]));
-      vl[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(a.v_lo + off[it]));
-    }
-  auto dec = [](const u32x4& hi4, const u32x2& lo2, int e) -> float {   // element e (0..7) of a lane's 8
-    const unsigned int hw = hi4[e >> 1];
-    const __half hv = __ushort_as_half((unsigned short)((e & 1) ? (hw >> 16) : (hw & 0xffffu)));
-    const unsigned int lb = (lo2[e >> 2] >> (8 * (e & 3))) & 0xffu;
-    return kv3_decode(hv, lb);
-  };
-
-  float sc[MAXIT];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    sc[it] = -INFINITY;
-    if (it * 8 < nkeys) {  // wave-uniform
-      const int p = it * 8 + g;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d = fmaf(q[e], dec(kh[it], kl[it], e), d);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-      if (p < nkeys) sc[it] = d + a.rel_bias[a.bucket[t - p] * H + h];
-      mx = fmaxf(mx, sc[it]);
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    sc[it] = (sc[it] == -INFINITY) ? 0.f : expf(sc[it] - mx);
-    sum += sc[it];
-  }
-  sum += __shfl_xor(sum, 8, 64);
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    if (it * 8 < nkeys) {
-      const float wgt = sc[it] / sum;
-      if (wgt != 0.f) {  // lanes past nkeys hold a clamped duplicate row with weight 0
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, dec(vh[it], vl[it], e), acc[e]);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 8; o <= 32; o <<= 1)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  if (g == 0) {
-    const size_t oidx = (size_t)r * inner + h * DKV + li * 8;
-    if (a.out_h) {
-      store_planes4(a.out_h, a.o_ps, oidx, make_float4(acc[0], acc[1], acc[2], acc[3]), a.sat);
-      store_planes4(a.out_h, a.o_ps, oidx + 4, make_float4(acc[4], acc[5], acc[6], acc[7]), a.sat);
-    } else {
-      *reinterpret_cast<float4*>(a.out + oidx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4*>(a.out + oidx + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    }
-  }
-}
-
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
   const dim3 grid((items + 3) / 4), blk(256);
   const int nk = a.t + 1;
-  if (a.k_hi) {
-    if (nk <= 8) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<1>, grid, blk, 0, s, a);
-    else if (nk <= 16) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<2>, grid, blk, 0, s, a);
-    else if (nk <= 24) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<3>, grid, blk, 0, s, a);
-    else if (nk <= 32) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<4>, grid, blk, 0, s, a);
-    else if (nk <= 40) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<5>, grid, blk, 0, s, a);
-    else if (nk <= 64) hipLaunchKernelGGL(dec_self_attn_kv3_kernel<8>, grid, blk, 0, s, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-  }
   if (nk <= 8) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<2>, grid, blk, 0, s, a); return hipGetLastError(); }
   if (nk <= 16) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<4>, grid, blk, 0, s, a); return hipGetLastError(); }
   if (nk <= 24) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<6>, grid, blk, 0, s, a); return hipGetLastError(); }

@@ -22,16 +22,32 @@ def q3(x: torch.Tensor) -> torch.Tensor:
     return hif + q * step
 
 
+def q3row(x: torch.Tensor) -> torch.Tensor:
+    """Row-scaled variant: hi = f16(x); lo = int8 of (x - hi) in units of s = 2^(Emax - 18), Emax = exponent of the
+    largest |hi| of the 64-element head row (last dim)."""
+    hi = x.to(torch.float16).to(torch.float32)
+    r = x - hi
+    _, ex = torch.frexp(hi.abs().amax(dim=-1, keepdim=True))     # max = m * 2^ex, m in [0.5, 1)
+    step = torch.ldexp(torch.ones_like(r[..., :1]), ex - 1 - 18)
+    q = torch.clamp(torch.round(r / step), -127, 127)
+    return hi + q * step
+
+
+MODE = q3
+
+
 class Q3Cached(t5_ref.T5RefCached):
     def step(self, last_tokens, R):
         out = super().step(last_tokens, R)
         for i in range(len(self.k_cache)):        # requantise only the newest position (earlier ones are already q3)
-            self.k_cache[i][:, :, -1:] = q3(self.k_cache[i][:, :, -1:])
-            self.v_cache[i][:, :, -1:] = q3(self.v_cache[i][:, :, -1:])
+            self.k_cache[i][:, :, -1:] = MODE(self.k_cache[i][:, :, -1:])
+            self.v_cache[i][:, :, -1:] = MODE(self.v_cache[i][:, :, -1:])
         return out
 
 
 name = sys.argv[1] if len(sys.argv) > 1 else "g2_base_b10_l32"
+if len(sys.argv) > 2 and sys.argv[2] == "row":
+    MODE = q3row
 g = conftest.Golden(name)
 pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(g.codes)), g.V)
 torch.set_num_threads(8)
