@@ -63,13 +63,16 @@ def test_shell_pipeline_end_to_end(tmp_path):
     ckpt, d2s_path, qdir, codes, queries, dims = _make_world(str(tmp_path))
     out_dir = os.path.join(str(tmp_path), "out")
     B, L = 5, 8
-    _run(["-m", "t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids", "--docid_to_smtid_path", d2s_path])
+    # the preprocess step is host only: it must work with every GPU hidden
+    _run(["-m", "t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids", "--docid_to_smtid_path", d2s_path],
+         env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
     assert os.path.exists(os.path.join(os.path.dirname(d2s_path), "list_smtid_to_nextids.rprtrie"))
     # one process per GPU through torch.distributed.run, like the script's torch.distributed.launch
-    _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+    out_txt = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
           "--master-port", "29533", "-m", "t5_pretrainer.evaluate", f"--pretrained_path={ckpt}", f"--out_dir={out_dir}",
           "--task=t5seq_aq_retrieve_docids", f"--docid_to_smtid_path={d2s_path}",
           "--q_collection_paths=" + json.dumps([qdir]), "--batch_size=4", f"--max_new_token_for_docid={L}", f"--topk={B}"])
+    assert "trie cache:" in out_txt, "the retrieval task did not take the binary trie cache written by the preprocess step"
     run_part = os.path.join(out_dir, "MSMARCO", "run_0.json")
     assert os.path.exists(run_part)
     run = json.load(open(run_part))

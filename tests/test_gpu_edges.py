@@ -251,3 +251,110 @@ def test_long_docids_beyond_the_register_attention_path(setup):
     torch.cuda.synchronize()
     assert np.array_equal(res.tokens.cpu().numpy(), seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:])
     np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
+
+
+# ---- saturation guard of the split-precision planes -------------------------------------------------
+def _sat_world(v_scale=1.0, weight_spike=None, seed=31):
+    from ripor_amd.modeling.t5_generative_retriever import T5forDocIDConfig, T5ForDocIDGeneration
+    from ripor_amd.tasks.generation import PrefixConstrainLogitProcessorFastSparse
+    from ripor_amd.utils import synth
+    L, V, B = 6, 256, 4
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    sd = synth.make_state_dict(dims, seed=seed)
+    # v.weight * 2^k and o.weight * 2^-k of one attention: the same function exactly (powers of two), but the attention
+    # output of that layer is 2^k times larger
+    a = "decoder.block.1.layer.0.SelfAttention"
+    sd[a + ".v.weight"] = (sd[a + ".v.weight"] * v_scale).astype(np.float32)
+    sd[a + ".o.weight"] = (sd[a + ".o.weight"] / v_scale).astype(np.float32)
+    if weight_spike is not None:
+        key, val = weight_spike
+        sd[key] = sd[key].copy()
+        sd[key][3, 5] = val
+    codes = synth.make_codes(300, L, V, seed=seed)
+    ids, mask = synth.make_queries(4, vocab_size=dims.vocab_size, seed=seed, max_len=12)
+    model = T5ForDocIDGeneration(T5forDocIDConfig.from_dims(dims), sd).to(0)
+    proc = PrefixConstrainLogitProcessorFastSparse.from_codes(codes, V)
+    return dims, sd, codes, ids, mask, model, proc, B, L, V
+
+
+def _oracle(dims, sd, codes, ids, mask, B, L, V):
+    from oracle import beam_ref, t5_ref
+    from ripor_amd.utils import synth
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    return beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
+
+
+def test_activation_outside_the_f16_planes_is_flagged_and_recomputed_in_fp32():
+    """An attention whose value projection is scaled by 2048 (and its output projection by 1/2048: the same model)
+    produces attention outputs of several thousand, beyond the +-4094 range of the activation planes (65504 / 2^4): the
+    raw engine call must raise the sticky saturation flag, and the reference-shaped entry point must return the
+    exact-fp32 result (== oracle) with a warning instead of rankings computed from clipped tensors."""
+    import warnings
+    from ripor_amd import _lib, engine as E
+    from ripor_amd.tasks.generation import generate_for_constrained_prefix_beam_search
+    dims, sd, codes, ids, mask, model, proc, B, L, V = _sat_world(v_scale=2048.0)
+    ctx = E.Context.get(0)
+    assert ctx.get_precision() == "f16x2" and not model.engine_model().f32_only
+    ctx.status(clear=True)
+    E.search(model.engine_model(), proc.trie(0), torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    assert ctx.status(clear=True) & _lib.STATUS_SATURATED, "clamped activations were not reported"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = generate_for_constrained_prefix_beam_search(
+            model, proc, input_ids=torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda(),
+            max_new_tokens=L, output_scores=True, return_dict_in_generate=True, num_beams=B, num_return_sequences=B)
+    assert any("f16 plane range" in str(x.message) for x in w)
+    assert ctx.get_precision() == "f16x2"                       # the retry does not leave the ctx in fp32 mode
+    seqs, sc = _oracle(dims, sd, codes, ids, mask, B, L, V)
+    assert (out.sequences.cpu().numpy() == seqs.numpy()).all()
+    np.testing.assert_allclose(out.sequences_scores.cpu().numpy(), sc.numpy(), atol=1e-4, rtol=0)
+    # sane inputs right after: no flag, no warning
+    dims2, sd2, codes2, ids2, mask2, model2, proc2, *_ = _sat_world()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        generate_for_constrained_prefix_beam_search(model2, proc2, input_ids=torch.from_numpy(ids2).cuda(),
+                                                    attention_mask=torch.from_numpy(mask2).cuda(), max_new_tokens=L,
+                                                    num_beams=B, num_return_sequences=B)
+    assert not [x for x in w if "f16 plane range" in str(x.message)]
+
+
+def test_weight_outside_the_f16_planes_pins_the_model_to_fp32():
+    """A weight of 300 (x 2^8 plane scale > 65504) cannot be carried by the weight planes: rpr_load_model pins the model
+    to the exact-fp32 kernels, and the search still matches the oracle."""
+    from ripor_amd import engine as E
+    dims, sd, codes, ids, mask, model, proc, B, L, V = _sat_world(
+        weight_spike=("decoder.block.2.layer.2.DenseReluDense.wi.weight", 300.0))
+    em = model.engine_model()
+    assert em.f32_only
+    ctx = E.Context.get(0)
+    ctx.status(clear=True)
+    res = E.search(em, proc.trie(0), torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    torch.cuda.synchronize()
+    assert ctx.status() == 0 and ctx.get_precision() == "f16x2"
+    seqs, sc = _oracle(dims, sd, codes, ids, mask, B, L, V)
+    assert (res.tokens.cpu().numpy() == seqs.numpy().reshape(len(ids), B, L + 1)[:, :, 1:]).all()
+    np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(len(ids), B), atol=1e-4, rtol=0)
+
+
+def test_query_without_attended_tokens_is_reported():
+    """an all-zero attention-mask row has no packed encoder rows; the cross-attention used to read the next
+    query's K/V. Now: defined output (zeros), sticky flag, ValueError from the reference-shaped entry point; the other
+    queries of the batch are unaffected."""
+    from ripor_amd import _lib, engine as E
+    from ripor_amd.tasks.generation import generate_for_constrained_prefix_beam_search
+    dims, sd, codes, ids, mask, model, proc, B, L, V = _sat_world()
+    ctx = E.Context.get(0)
+    ref = E.search(model.engine_model(), proc.trie(0), torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+    mask2 = mask.copy()
+    mask2[1] = 0
+    ctx.status(clear=True)
+    res = E.search(model.engine_model(), proc.trie(0), torch.from_numpy(ids), torch.from_numpy(mask2), B, L)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & _lib.STATUS_EMPTY_QUERY
+    assert torch.isfinite(res.scores).all()
+    keep = [0, 2, 3]
+    assert torch.equal(res.tokens[keep], ref.tokens[keep]) and torch.allclose(res.scores[keep], ref.scores[keep], atol=1e-5)
+    with pytest.raises(ValueError, match="all-zero attention_mask"):
+        generate_for_constrained_prefix_beam_search(model, proc, input_ids=torch.from_numpy(ids).cuda(),
+                                                    attention_mask=torch.from_numpy(mask2).cuda(), max_new_tokens=L,
+                                                    num_beams=B, num_return_sequences=B)
