@@ -480,7 +480,31 @@ def train_batch(name, dims, bz, L, V, seed):
     return ids, mask, pos, neg, teacher
 
 
-@torch.no_grad()
+def grad_samples(name, shape, n=48):
+    """Seeded flat indices at which a gradient tensor is sampled for the fixture (the whole tensor would be too big to
+    commit for the 768x3072 matrices); tests recompute the same indices from the tensor's name and shape."""
+    numel = int(np.prod(shape))
+    if numel <= 4096:
+        return np.arange(numel, dtype=np.int64)
+    return np.sort(synth.randint(f"gradidx/{name}", (n,), 0, numel, seed=7)).astype(np.int64)
+
+
+def train_step_reference(m, inputs, names_in_order):
+    """One training step the way the reference runs it (tasks/trainer.py:203-275 + HF Trainer defaults used by
+    main.py:131-155): total loss = sum of the task losses (ln_to_weight = 1 each, arguments.py:109-119), backward,
+    clip_grad_norm_(1.0), AdamW(lr, betas (0.9, 0.999), eps 1e-8, weight_decay 0). fp32 here (the reference trains
+    under bf16 autocast; the fixture pins the arithmetic the step implements, not bf16 rounding)."""
+    params = {k: p for k, p in m.base_model.named_parameters() if p.requires_grad}
+    for p in params.values():
+        p.grad = None
+    losses = m(**inputs)
+    total = sum(losses[k] for k in names_in_order)
+    total.backward()
+    grads = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    return losses, float(total), grads, gnorm, params
+
+
 def make_train_case(name, spec, gen, mod, utils, shim):
     kind, bz, L, V, seed = spec["kind"], spec["bz"], spec["L"], spec["V"], spec["seed"]
     dims = synth.mini_dims(L=L, V=V) if kind == "mini" else synth.t5_base_dims(L=L, V=V, vocab_size=2048)
@@ -503,18 +527,48 @@ def make_train_case(name, spec, gen, mod, utils, shim):
     inputs = {"pos_tokenized_query": tq(pos), "neg_tokenized_query": tq(neg),
               "pos_doc_encoding": torch.from_numpy(pos), "neg_doc_encoding": torch.from_numpy(neg)}
     inputs.update({k: torch.from_numpy(v) for k, v in teacher.items()})
-    losses = m(**inputs)
-    # per-position student scores from the reference's own hidden states and codebooks (diagnostic granularity)
-    ph = base(**tq(pos)).decoder_last_hidden_state
-    nh = base(**tq(neg)).decoder_last_hidden_state
-    pos_pp = (ph * m.decode(torch.from_numpy(pos))).sum(-1).numpy()
-    neg_pp = (nh * m.decode(torch.from_numpy(neg))).sum(-1).numpy()
+    with torch.no_grad():
+        losses = m(**inputs)
+        # per-position student scores from the reference's own hidden states and codebooks (diagnostic granularity)
+        ph = base(**tq(pos)).decoder_last_hidden_state
+        nh = base(**tq(neg)).decoder_last_hidden_state
+        pos_pp = (ph * m.decode(torch.from_numpy(pos))).sum(-1).numpy()
+        neg_pp = (nh * m.decode(torch.from_numpy(neg))).sum(-1).numpy()
+    # ---- backward + one optimizer step of the reference (second half)
+    extra = {}
+    if spec.get("backward", kind == "mini"):
+        loss_names = sorted(losses.keys())
+        _, total, grads, gnorm, params = train_step_reference(m, inputs, loss_names)
+        keep = {k: g for k, g in grads.items() if "decoder.embed_tokens" not in k}   # transformers-5.x-only unused table
+        # the encoder's token table is the shared one (tied in 4.17): its gradient is reported under shared.weight
+        gn = sorted(keep)
+        extra["grad_names"] = np.array(gn)
+        extra["grad_norms"] = np.array([float(keep[k].double().norm()) for k in gn])
+        extra["grad_samples"] = np.concatenate([keep[k].reshape(-1)[torch.from_numpy(grad_samples(k, keep[k].shape))].numpy()
+                                                for k in gn]).astype(np.float32)
+        extra["grad_sample_counts"] = np.array([len(grad_samples(k, keep[k].shape)) for k in gn])
+        extra["total_loss"] = np.float64(total)
+        extra["grad_global_norm"] = np.float64(gnorm)
+        # one AdamW step at lr 1e-4 after clipping to norm 1.0, then the loss on the same batch again
+        lr = spec.get("lr", 2e-6)   # small enough that the random-weight model stays in the linear regime of one step
+        opt = torch.optim.AdamW([p for p in params.values()], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        torch.nn.utils.clip_grad_norm_([p for p in params.values()], 1.0)
+        before = {k: params[k].detach().clone() for k in gn}
+        opt.step()
+        extra["step_lr"] = np.float64(lr)
+        extra["param_delta_samples"] = np.concatenate(
+            [(params[k].detach() - before[k]).reshape(-1)[torch.from_numpy(grad_samples(k, before[k].shape))].numpy()
+             for k in gn]).astype(np.float32)
+        with torch.no_grad():
+            after = m(**inputs)
+        extra["losses_after_step"] = np.array([float(after[k]) for k in loss_names], dtype=np.float64)
     out = dict(spec=json.dumps(dict(spec, name=name, dims=dims.__dict__)), input_ids=ids, attention_mask=mask,
                pos_doc_encoding=pos, neg_doc_encoding=neg, pos_position_scores=pos_pp.astype(np.float32),
                neg_position_scores=neg_pp.astype(np.float32),
                loss_names=np.array(sorted(losses.keys())),
                losses=np.array([float(losses[k]) for k in sorted(losses.keys())], dtype=np.float64))
     out.update(teacher)
+    out.update(extra)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"[golden] {name}: {time.time() - t0:.1f}s losses {dict((k, float(v)) for k, v in losses.items())} -> {path}")

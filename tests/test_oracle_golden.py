@@ -123,6 +123,69 @@ class TrainGolden:
         return synth.make_state_dict(self.dims, seed=self.seed)
 
 
+def grad_sample_indices(name, shape, n=48):
+    """The seeded sample positions tests/golden/make_golden.py::grad_samples used for this tensor."""
+    numel = int(np.prod(shape))
+    if numel <= 4096:
+        return np.arange(numel, dtype=np.int64)
+    return np.sort(synth.randint(f"gradidx/{name}", (n,), 0, numel, seed=7)).astype(np.int64)
+
+
+def check_grads_against_fixture(g, grads, rel=2e-4, label=""):
+    """grads: name -> numpy array (reference state-dict names). Every gradient tensor of the reference must match in
+    Frobenius norm and at the sampled positions; the tolerance is relative to the tensor's largest sampled magnitude."""
+    names = [str(x) for x in g.z["grad_names"]]
+    norms, counts, samples = g.z["grad_norms"], g.z["grad_sample_counts"], g.z["grad_samples"]
+    off, worst = 0, (0.0, None)
+    for n, nr, c in zip(names, norms, counts):
+        ref = samples[off:off + c]
+        off += c
+        key = "shared.weight" if n == "encoder.embed_tokens.weight" else n
+        arr = np.asarray(grads[key], dtype=np.float64)
+        got = arr.reshape(-1)[grad_sample_indices(n, arr.shape)]
+        scale = max(np.abs(ref).max(), nr / np.sqrt(arr.size), 1e-12)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, (err, n))
+        assert err <= rel * 10, f"{g.name}{label} gradient of {n}: sampled entries differ by {err:.2e} of its scale"
+        gnr = np.sqrt((arr ** 2).sum())
+        assert abs(gnr - nr) <= rel * max(nr, 1e-12), f"{g.name}{label} gradient norm of {n}: {gnr} vs {nr}"
+    return worst
+
+
+def test_train_step_oracle_reproduces_reference_gradients():
+    """Backward + one AdamW step: autograd through the oracle's own forward vs the gradients of the
+    imported reference module, the clipped AdamW update and the losses after the step."""
+    from conftest import train_golden_names
+    from oracle import train_ref
+    for name in [n for n in train_golden_names() if "mini" in n]:
+        g = TrainGolden(name)
+        assert "grad_names" in g.z.files
+        torch.set_num_threads(8)
+        model = t5_ref.T5Ref(g.state_dict, g.dims)
+        before = {k: v.clone() for k, v in model.sd.items()}
+        lr = float(g.z["step_lr"])
+        losses, total, grads, gnorm = train_ref.train_step(model, g.z["input_ids"], g.z["attention_mask"],
+                                                           g.z["pos_doc_encoding"], g.z["neg_doc_encoding"], g.teacher, lr=lr)
+        assert abs(total - float(g.z["total_loss"])) <= 1e-5 * abs(total)
+        assert abs(gnorm - float(g.z["grad_global_norm"])) <= 1e-4 * gnorm
+        worst = check_grads_against_fixture(g, {k: v.numpy() for k, v in grads.items()}, label=" (oracle)")
+        # parameter update of the clipped AdamW step at the sampled positions
+        names = [str(x) for x in g.z["grad_names"]]
+        off = 0
+        for n, c in zip(names, g.z["grad_sample_counts"]):
+            ref = g.z["param_delta_samples"][off:off + c]
+            off += c
+            key = "shared.weight" if n == "encoder.embed_tokens.weight" else n
+            d = (model.sd[key] - before[key]).numpy().reshape(-1)[grad_sample_indices(n, before[key].shape)]
+            np.testing.assert_allclose(d, ref, atol=2e-2 * lr, rtol=0, err_msg=f"{name} update of {n}")
+        with torch.no_grad():
+            after = train_ref.lng_knp_margin_mse(model, g.z["input_ids"], g.z["attention_mask"], g.z["pos_doc_encoding"],
+                                                 g.z["neg_doc_encoding"], g.teacher)
+        for k, v in zip(sorted(g.losses), g.z["losses_after_step"]):
+            assert abs(float(after[k]) - v) <= 2e-3 * max(1.0, abs(v)), (name, k, float(after[k]), v)
+        print(f"[train-oracle] {name}: worst sampled-gradient error {worst[0]:.2e} of scale ({worst[1]})")
+
+
 def test_train_forward_oracle_reproduces_reference_losses():
     from conftest import train_golden_names
     from oracle import train_ref
@@ -131,8 +194,9 @@ def test_train_forward_oracle_reproduces_reference_losses():
     for name in names:
         g = TrainGolden(name)
         torch.set_num_threads(8)
-        out = train_ref.lng_knp_margin_mse(t5_ref.T5Ref(g.state_dict, g.dims), g.z["input_ids"], g.z["attention_mask"],
-                                           g.z["pos_doc_encoding"], g.z["neg_doc_encoding"], g.teacher)
+        with torch.no_grad():
+            out = train_ref.lng_knp_margin_mse(t5_ref.T5Ref(g.state_dict, g.dims), g.z["input_ids"], g.z["attention_mask"],
+                                               g.z["pos_doc_encoding"], g.z["neg_doc_encoding"], g.teacher)
         assert set(g.losses) == set(train_ref.LOSS_NAMES[g.L])
         np.testing.assert_allclose(out["pos_position_scores"].numpy(), g.z["pos_position_scores"], atol=2e-5, rtol=1e-5)
         np.testing.assert_allclose(out["neg_position_scores"].numpy(), g.z["neg_position_scores"], atol=2e-5, rtol=1e-5)
