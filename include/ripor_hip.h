@@ -222,12 +222,44 @@ int rpr_search(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, const int32_t* in
  *   prefix_lens: [dev] int32 [n_prefix]
  *   out_losses:  [dev] float [n_prefix]        mean_b (student_margin - teacher_margin)^2   (torch.nn.MSELoss)
  *   out_position_scores: [dev] float [bz, n_docs, L], nullable
- * Forward only in this version (no gradients): the backward pass, the optimizer and the RCCL gradient all-reduce of
- * config 5 are not built yet. Eager launches on `stream`; asynchronous. */
+ * Inference-style forward (split-precision GEMMs, nothing kept for a backward pass); the training step is
+ * rpr_lngknp_backward + rpr_adamw_step below. Eager launches on `stream`; asynchronous. */
 int rpr_lngknp_forward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask,
                        int32_t bz, int32_t Lq, const int32_t* doc_codes, int32_t n_docs, int32_t L,
                        const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens, int32_t n_prefix,
                        float* out_losses, float* out_position_scores, void* stream);
+
+/* ---- the training step of the same model (config 5): backward pass + optimizer --------------------------------
+ * Replaces, for loss_type t5seq_aq_encoder_lng_knp_margin_mse, what HF Trainer does per step around the forward above
+ * (tasks/trainer.py:203-275 training_step: loss = sum of the task losses, loss.backward(); Trainer defaults behind
+ * main.py:131-155: clip_grad_norm_(1.0), torch.optim.AdamW(lr, betas (0.9, 0.999), eps 1e-8, weight_decay 0)).
+ *
+ * Trainable tensors and the flat buffers. The model's tensors (the device pointers of rpr_model_desc: fp32, caller
+ * owned) are updated IN PLACE by rpr_adamw_step. Gradients and the two AdamW moments live in caller-owned flat fp32
+ * buffers of rpr_param_total(model) elements; tensor i occupies [offset_i, offset_i + numel_i) in each of them and
+ * rpr_param_info returns its device pointer (so the host can map it back to a checkpoint name), numel and offset.
+ * Order: shared, encoder / decoder relative bias, final layer norms, start embedding, stacked input codebooks, stacked
+ * output codebooks (absent when shared with the input ones), stacked cross-attention k/v, then per encoder layer
+ * ln0, qkv, o, ln1, wi, wo and per decoder layer ln0, qkv, o, ln1, xq, xo, ln2, wi, wo (the concatenated layouts of
+ * rpr_model_desc). The flat gradient buffer is what a data-parallel caller all-reduces (RCCL) between the two calls.
+ *
+ * rpr_lngknp_backward: forward (activations kept in library-owned memory) + backward of the sum of the n_prefix
+ *   margin-MSE losses; same batch arguments as rpr_lngknp_forward with n_docs = 2; writes out_losses [dev, n_prefix]
+ *   and overwrites flat_grads [dev, rpr_param_total]. fp32 activations and gradients, exact-fp32 MFMA products,
+ *   deterministic reductions. Lq <= 128, L <= the model's decoder length.
+ * rpr_adamw_step: global L2 norm of flat_grads (-> out_grad_norm [dev, 1], nullable), clip coefficient
+ *   min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no clipping), AdamW update of every tensor with the
+ *   bias corrections of `step` (1-based), then the f16 weight planes of the search path are refreshed (synchronises
+ *   the stream). exp_avg / exp_avg_sq: [dev, rpr_param_total], zero before the first step. */
+int64_t rpr_param_count(rpr_model* model);
+int64_t rpr_param_total(rpr_model* model);
+int rpr_param_info(rpr_model* model, int64_t index, const float** ptr, int64_t* numel, int64_t* offset);
+int rpr_lngknp_backward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,
+                        int32_t Lq, const int32_t* doc_codes, int32_t L, const float* teacher_pos, const float* teacher_neg,
+                        const int32_t* prefix_lens, int32_t n_prefix, float* out_losses, float* flat_grads, void* stream);
+int rpr_adamw_step(rpr_ctx* ctx, rpr_model* model, const float* flat_grads, float* exp_avg, float* exp_avg_sq, int64_t step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                   float* out_grad_norm, void* stream);
 
 /* ---- sticky status of a ctx ------------------------------------------------------------------------
  * RPR_STATUS_SATURATED: in RPR_PREC_F16X2 mode an activation left the range of the f16 planes (|x| > 65504 after

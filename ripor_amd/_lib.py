@@ -93,6 +93,13 @@ SIGNATURES = {
     "rpr_lngknp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "rpr_param_count": (C.c_int64, [C.c_void_p]),
+    "rpr_param_total": (C.c_int64, [C.c_void_p]),
+    "rpr_param_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rpr_lngknp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rpr_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rpr_get_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "rpr_model_f32_only": (C.c_int, [C.c_void_p]),
     "rpr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

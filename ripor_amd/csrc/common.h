@@ -252,5 +252,29 @@ hipError_t launch_gold_scores(const float* x, const float* ln, const float* out_
                               const __half* x_h = nullptr, size_t x_ps = 0);
 hipError_t launch_margin_mse(const float* scores, const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens,
                              int n_prefix, int bz, int L, float* losses, float* margins, hipStream_t s);
+// ---- backward pass + optimizer of the same step (train_kernels.hip) ------------------------------------------------
+hipError_t init_train_kernel_attributes();
+hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
+hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
+hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
+                              float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s);
+size_t self_attn_bwd_smem(int Ls, int buckets);
+hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias, const int32_t* bucket,
+                                float* dqkv, float* dbias_part, float* dbias, int S, int Ls, int H, int buckets, int causal,
+                                hipStream_t s);
+size_t cross_attn_bwd_smem(int n, int Lq);
+hipError_t launch_cross_attn_bwd(const float* q, const float* xk, const float* xv, int xld, const int32_t* mask, const float* dO,
+                                 float* dq, float* dxk, float* dxv, int bz, int n, int Lq, int H, hipStream_t s);
+hipError_t launch_scatter_rows_fix(const float* src, const int32_t* idx, unsigned long long* acc, int rows, int d, hipStream_t s);
+hipError_t launch_fix_flush(unsigned long long* acc, float* dst, size_t n, hipStream_t s);
+hipError_t launch_train_indices(const int32_t* codes, int32_t* in_idx, int32_t* out_idx, int S, int L, int V, hipStream_t s);
+hipError_t launch_sum_selected_rows(const float* src, const int32_t* sel, float* out, int rows, int d, hipStream_t s);
+hipError_t launch_margin_mse_bwd(const float* margins, const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens,
+                                 int n_prefix, int bz, int L, float* dscores, hipStream_t s);
+hipError_t launch_gold_score_bwd(const float* x, const float* ln, const float* out_embeds, const int32_t* out_idx, const float* dscores,
+                                 float* dh, float* de, int rows, int d, float eps, float post, hipStream_t s);
+hipError_t launch_grad_norm(const float* g, size_t n, double* part, int nparts, float max_norm, float* out, hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* clip, float lr, float b1, float b2,
+                        float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
 
 }  // namespace rpr

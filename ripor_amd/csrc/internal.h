@@ -1,0 +1,176 @@
+// Internal declarations shared by the translation units behind the C ABI (api.hip: search path, train_api.hip: the
+// training step). Not part of the ABI: include/ripor_hip.h is.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "trie.h"
+
+namespace rpr {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace rpr
+
+using rpr::DevBuf;
+
+struct rpr_model {
+  rpr_ctx* ctx;
+  rpr_model_desc d;
+  std::vector<const float*> enc_ln0, enc_qkv, enc_o, enc_ln1, enc_wi, enc_wo;
+  std::vector<const float*> dec_ln0, dec_qkv, dec_o, dec_ln1, dec_xq, dec_xo, dec_ln2, dec_wi, dec_wo;
+  int32_t* enc_bucket = nullptr;  // [2*MAX_LQ-1]
+  int32_t* dec_bucket = nullptr;  // [MAX_DEC_LEN]
+  // f16 hi/lo planes of every GEMM weight (split once at load; [2][N][K], plane stride N*K)
+  std::vector<__half*> h_enc_qkv, h_enc_o, h_enc_wi, h_enc_wo;
+  std::vector<__half*> h_dec_qkv, h_dec_o, h_dec_xq, h_dec_xo, h_dec_wi, h_dec_wo;
+  __half* h_dec_xkv = nullptr;
+  __half* h_out_embeds = nullptr;  // [2][L*V][d]
+  // Fused RMSNorm: the planes of every projection that consumes a normalised input hold W * diag(ln_weight)
+  // (enc_qkv: ln0, enc_wi: ln1, dec_qkv: ln0, dec_xq: ln1, dec_wi: ln2, out_embeds: final ln * scaleup factor);
+  // the fp32 weights of the caller stay untouched and serve the exact-fp32 mode.
+  bool f32_only = false;           // a weight does not fit the f16 planes: every search of this model runs exact fp32
+  std::vector<void*> owned;
+  // how every plane buffer was produced (replayed by refresh_weight_planes after an optimizer step changed the weights)
+  struct PlaneJob { const float* w; size_t n; __half* dst; const float* ln; float pre; };
+  std::vector<PlaneJob> plane_jobs;
+  // trainable tensors in the order of the flat gradient / optimizer-state buffers (train_api.hip)
+  struct ParamRef { int kind; int layer; float* ptr; size_t numel; size_t offset; };
+  std::vector<ParamRef> params;
+  size_t params_total = 0;
+  int inner() const { return d.num_heads * d.d_kv; }
+  ~rpr_model() {   // device memory goes with the object, also on the error paths of rpr_load_model
+    if (enc_bucket) (void)hipFree(enc_bucket);
+    if (dec_bucket) (void)hipFree(dec_bucket);
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
+struct rpr_trie {
+  rpr_ctx* ctx;
+  int64_t N;
+  int L, V;
+  uint16_t* codes = nullptr;  // [dev] sorted [N, L]
+  std::vector<int64_t> perm;
+  std::vector<uint16_t> host_sorted;
+  std::string keys;           // docid strings in original row order, '\n'-joined (only when loaded from a file that has them)
+  ~rpr_trie() { if (codes) (void)hipFree(codes); }
+};
+
+struct rpr_d2s {
+  std::vector<uint16_t> codes;
+  std::string keys;
+  int64_t N = 0;
+  int L = 0;
+};
+
+struct GraphKey {
+  const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(m, t, Q, Lq, B, L, flags) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags);
+  }
+};
+
+struct Workspace {
+  // encoder
+  DevBuf ids, mask, last, offs, row_src, ex, eh, eqkv, eattn, eff, enc_out, xkv;
+  // decoder
+  DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
+  // beam state (2 ping-pong buffers)
+  DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
+  // staged outputs
+  DevBuf o_tokens, o_scores, o_lo, o_hi;
+  // f16 hi/lo planes of the GEMM inputs (split-precision mode): attention outputs, FF intermediates, the final
+  // encoder states, and the UN-normalised residual streams (fused RMSNorm) with their row sums of squares
+  DevBuf eattn_h, eff_h, enc_out_h, attn_h, ff_h, ex_h, x_h, ssq_e, ssq_d;
+  DevBuf tr_x, tr_misc;   // rpr_train_forward scratch (teacher-forced decoder)
+};
+
+struct rpr_ctx {
+  int device;
+  int precision = RPR_PREC_F16X2;
+  unsigned int* status = nullptr;       // [dev] sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing
+  unsigned int* status_host = nullptr;  // pinned mirror filled by rpr_get_status
+  struct TrainWs* tws = nullptr;        // activations / scratch of the training step (train_api.hip), freed by free_train_ws
+  unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
+  Workspace ws;
+  size_t ws_bytes = 0;
+  int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)
+  hipStream_t cap_stream = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  // profiling
+  bool profiling = false;
+  struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  rpr_kernel_stats done[RPR_K_COUNT];
+};
+
+namespace rpr {
+
+// re-split every GEMM weight into its f16 planes (api.hip); sets model->f32_only if a weight no longer fits
+int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s);
+void free_train_ws(rpr_ctx* c);   // train_api.hip
+
+inline int ensure(rpr_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    RPR_HIP(hipFree(b.p));
+    c->ws_bytes -= b.cap;
+    b.p = nullptr; b.cap = 0;
+    // graphs captured against the old pointers are stale
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+  }
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  RPR_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  c->ws_bytes += want;
+  return 0;
+}
+
+template <class T> T* P(const DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+// scoped temporary device buffer (test hooks): freed on every return path
+struct DevTmp {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Launch wrapper: optional hipEvent timing per kernel class (bench.py roofline leg).
+struct Launcher {
+  rpr_ctx* c;
+  hipStream_t s;
+  int err = 0;
+  hipEvent_t get_event() {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  template <class F> void run(int cls, double flops, double bytes, F&& f, const int* cls_after = nullptr) {
+    if (err) return;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (c->profiling) {
+      ea = get_event(); eb = get_event();
+      if (ea) (void)hipEventRecord(ea, s);
+    }
+    hipError_t e = f();
+    if (e != hipSuccess) { err = hip_fail(e, "kernel launch", __FILE__, __LINE__); return; }
+    if (c->profiling && ea && eb) {
+      (void)hipEventRecord(eb, s);
+      c->recs.push_back({cls_after ? *cls_after : cls, ea, eb, flops, bytes});
+    }
+  }
+};
+
+}  // namespace rpr

@@ -1,0 +1,410 @@
+// Training step of the prefix-oriented ranking fine-tune (BASELINE config 5) behind the C ABI:
+//   rpr_lngknp_backward  = forward (activations kept) + backward of T5SeqAQEncoderForLngKnpMarginMSE
+//                          (reference modeling/t5_generative_retriever.py:902-966; loss.backward() in
+//                          tasks/trainer.py:203-275) into one flat fp32 gradient buffer,
+//   rpr_adamw_step       = clip_grad_norm_ + torch.optim.AdamW as HF Trainer configures them for main.py:131-155,
+//   rpr_param_*          = the layout of the flat buffers (so the host can all-reduce them over RCCL and map them back
+//                          to the checkpoint's tensor names).
+// Arithmetic: fp32 activations and gradients, every matrix product on the exact-fp32 MFMA GEMM kernel
+// (gemm_f32.hip, v_mfma_f32_32x32x2_f32) — gradients span ten orders of magnitude, which the f16 planes of the search
+// path's split-precision GEMM cannot carry without per-tensor scales; the reference trains under bf16 autocast, so fp32
+// is the more precise side. The backward products reuse the forward kernel on explicitly transposed operands
+// (train_kernels.hip); the reductions are deterministic (fixed-order partials, fixed-point integer atomics).
+#include <cmath>
+#include <cstring>
+
+#include "internal.h"
+
+using namespace rpr;
+
+struct TrainWs {
+  // saved forward activations
+  DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
+  // scratch
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, wT, w_part, bias_part, fix, gn_part, gn_out;
+  size_t bytes = 0;
+};
+
+namespace {
+
+enum { K_SHARED, K_ENC_REL, K_DEC_REL, K_ENC_FLN, K_DEC_FLN, K_START, K_IN_EMB, K_OUT_EMB, K_XKV, K_ENC_LN0, K_ENC_QKV, K_ENC_O,
+       K_ENC_LN1, K_ENC_WI, K_ENC_WO, K_DEC_LN0, K_DEC_QKV, K_DEC_O, K_DEC_LN1, K_DEC_XQ, K_DEC_XO, K_DEC_LN2, K_DEC_WI, K_DEC_WO };
+
+void build_params(rpr_model* m) {
+  if (!m->params.empty()) return;
+  const auto& d = m->d;
+  const size_t dm = d.d_model, inner = m->inner(), dff = d.d_ff, nd = d.num_decoder_layers;
+  size_t off = 0;
+  auto add = [&](int kind, int layer, const float* p, size_t n) {
+    m->params.push_back({kind, layer, const_cast<float*>(p), n, off});
+    off += n;
+  };
+  add(K_SHARED, -1, d.shared, (size_t)d.vocab_size * dm);
+  add(K_ENC_REL, -1, d.enc_rel_bias, (size_t)d.rel_buckets * d.num_heads);
+  add(K_DEC_REL, -1, d.dec_rel_bias, (size_t)d.rel_buckets * d.num_heads);
+  add(K_ENC_FLN, -1, d.enc_final_ln, dm);
+  add(K_DEC_FLN, -1, d.dec_final_ln, dm);
+  add(K_START, -1, d.start_embed, dm);
+  add(K_IN_EMB, -1, d.in_embeds, (size_t)d.L * d.V * dm);
+  if (d.out_embeds != d.in_embeds) add(K_OUT_EMB, -1, d.out_embeds, (size_t)d.L * d.V * dm);
+  add(K_XKV, -1, d.dec_xkv, nd * 2 * inner * dm);
+  for (int i = 0; i < d.num_layers; ++i) {
+    add(K_ENC_LN0, i, m->enc_ln0[i], dm); add(K_ENC_QKV, i, m->enc_qkv[i], 3 * inner * dm); add(K_ENC_O, i, m->enc_o[i], dm * inner);
+    add(K_ENC_LN1, i, m->enc_ln1[i], dm); add(K_ENC_WI, i, m->enc_wi[i], dff * dm); add(K_ENC_WO, i, m->enc_wo[i], dm * dff);
+  }
+  for (int i = 0; i < (int)nd; ++i) {
+    add(K_DEC_LN0, i, m->dec_ln0[i], dm); add(K_DEC_QKV, i, m->dec_qkv[i], 3 * inner * dm); add(K_DEC_O, i, m->dec_o[i], dm * inner);
+    add(K_DEC_LN1, i, m->dec_ln1[i], dm); add(K_DEC_XQ, i, m->dec_xq[i], inner * dm); add(K_DEC_XO, i, m->dec_xo[i], dm * inner);
+    add(K_DEC_LN2, i, m->dec_ln2[i], dm); add(K_DEC_WI, i, m->dec_wi[i], dff * dm); add(K_DEC_WO, i, m->dec_wo[i], dm * dff);
+  }
+  m->params_total = off;
+}
+
+size_t param_offset(const rpr_model* m, int kind, int layer) {
+  for (const auto& p : m->params)
+    if (p.kind == kind && p.layer == layer) return p.offset;
+  return (size_t)-1;
+}
+
+int tensure(rpr_ctx* c, DevBuf& b, size_t bytes) {   // like ensure(), without touching the search graphs
+  if (bytes <= b.cap) return 0;
+  if (b.p) { RPR_HIP(hipFree(b.p)); c->tws->bytes -= b.cap; b.p = nullptr; b.cap = 0; }
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  RPR_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  c->tws->bytes += want;
+  return 0;
+}
+
+inline int pad32(int n) { return (n + 31) & ~31; }
+
+struct Dims {
+  int bz, Lq, L, S, R, T, dm, inner, dff, H, ne, nd, V, xld, buckets;
+  float eps, post;
+  size_t enc_stride, dec_stride;   // floats per saved layer
+};
+
+// C[M, N] = act(A[M, K] B[N, K]^T) (+ resid), exact fp32 MFMA
+void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+          const float* resid = nullptr, int relu = 0) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = B; g.ldw = ldb; g.resid = resid; g.ldr = ldc;
+  g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
+  g.M = M; g.N = N; g.K = K; g.relu = relu;
+  Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm(g, Ln.s); });
+}
+
+struct Bwd {
+  Launcher& Ln; rpr_ctx* c; TrainWs& w; const Dims& D;
+  // dX[M, K] = dY[M, N] W[N, K]
+  void dx(const float* dY, const float* W, float* dX, int M, int N, int K) {
+    Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_transpose_pad(W, P<float>(w.wT), N, K, K, N, Ln.s); });
+    gemm(Ln, dY, N, P<float>(w.wT), N, dX, K, M, K, N);
+  }
+  // dW[N, K] (+)= dY[M, N]^T X[M, K]
+  void dw(const float* dY, const float* X, float* dW, int M, int N, int K, bool accumulate = false) {
+    const int Mp = pad32(M);
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, Ln.s); });
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB), M, K, K, Mp, Ln.s); });
+    gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB), Mp, dW, K, N, K, Mp, accumulate ? dW : nullptr);
+  }
+  void norm(const float* x, const float* ln, int rows, float post = 1.0f) {   // recompute the normalised input into w.h
+    Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * D.dm, [&] { return launch_rmsnorm(x, ln, P<float>(w.h), rows, D.dm, D.eps, Ln.s, post); });
+  }
+  void norm_bwd(const float* x, const float* ln, const float* dh, const float* dres, float* dx_out, float* dln, int rows,
+                float post = 1.0f) {
+    Ln.run(RPR_K_RMSNORM, 0, 16.0 * rows * D.dm, [&] {
+      return launch_rmsnorm_bwd(x, ln, dh, dres, dx_out, P<float>(w.w_part), dln, rows, D.dm, D.eps, post, 0, Ln.s);
+    });
+  }
+};
+
+int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
+  if (!c->tws) c->tws = new TrainWs();
+  TrainWs& w = *c->tws;
+  const size_t f = sizeof(float), R = D.R, T = D.T, dm = D.dm, inner = D.inner, dff = D.dff;
+  const size_t rows = std::max(R, T), rp = pad32((int)rows);
+  const size_t wide = std::max<size_t>(std::max<size_t>(dff, 3 * inner), (size_t)D.xld);
+  int e = 0;
+  auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = tensure(c, b, bytes); };
+  E(w.enc_act, (size_t)D.ne * D.enc_stride * f + T * dm * f);     // + the encoder's last stream
+  E(w.dec_act, (size_t)D.nd * D.dec_stride * f);
+  E(w.enc_out, T * dm * f); E(w.xkv, T * (size_t)D.xld * f); E(w.x_last, R * dm * f);
+  E(w.scores, R * f); E(w.margins, 8 * (size_t)D.bz * f); E(w.dscores, R * f);
+  E(w.in_idx, R * 4); E(w.out_idx, R * 4); E(w.tok_idx, T * 4);
+  E(w.h, rows * dm * f); E(w.dxa, rows * dm * f); E(w.dxb, rows * dm * f); E(w.dbig, rows * wide * f);
+  E(w.dattn, rows * inner * f); E(w.dxkv, T * (size_t)D.xld * f); E(w.denc, T * dm * f);
+  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f);
+  E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
+  E(w.w_part, ((rows + 3) / 4) * dm * f);
+  E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
+  E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
+  E(w.gn_part, 1024 * 8); E(w.gn_out, 16);
+  return e;
+}
+
+// saved activations of one layer (floats, row-major)
+struct EncAct { float *x, *qkv, *attn, *xm, *ff; };
+struct DecAct { float *x0, *qkv, *a0, *x1, *qx, *a1, *x2, *ff; };
+EncAct enc_act(const TrainWs& w, const Dims& D, int i) {
+  float* b = P<float>(w.enc_act) + (size_t)i * D.enc_stride;
+  const size_t T = D.T;
+  EncAct a; a.x = b; a.qkv = a.x + T * D.dm; a.attn = a.qkv + T * 3 * D.inner; a.xm = a.attn + T * D.inner; a.ff = a.xm + T * D.dm;
+  return a;
+}
+DecAct dec_act(const TrainWs& w, const Dims& D, int i) {
+  float* b = P<float>(w.dec_act) + (size_t)i * D.dec_stride;
+  const size_t R = D.R;
+  DecAct a; a.x0 = b; a.qkv = a.x0 + R * D.dm; a.a0 = a.qkv + R * 3 * D.inner; a.x1 = a.a0 + R * D.inner; a.qx = a.x1 + R * D.dm;
+  a.a1 = a.qx + R * D.inner; a.x2 = a.a1 + R * D.inner; a.ff = a.x2 + R * D.dm;
+  return a;
+}
+
+void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const int32_t* ids, const int32_t* mask,
+             const int32_t* codes, int32_t* last) {
+  TrainWs& w = *c->tws;
+  const auto& d = m->d;
+  hipStream_t s = Ln.s;
+  const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff;
+  float* h = P<float>(w.h);
+  auto norm = [&](const float* x, const float* ln, float* out, int rows, float post = 1.0f) {
+    Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * dm, [&] { return launch_rmsnorm(x, ln, out, rows, dm, D.eps, s, post); });
+  };
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(mask, last, D.bz, D.Lq, s, c->status + 1); });
+  // ---- encoder over the padded [bz, Lq] layout (padded positions get no gradient: nothing downstream reads them)
+  float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
+  Ln.run(RPR_K_OTHER, 0, 8.0 * T * dm, [&] { return launch_embed_rows(d.shared, ids, enc_act(w, D, 0).x, T, dm, d.vocab_size, s); });
+  for (int i = 0; i < D.ne; ++i) {
+    EncAct a = enc_act(w, D, i);
+    float* xnext = i + 1 < D.ne ? enc_act(w, D, i + 1).x : xe_last;
+    norm(a.x, m->enc_ln0[i], h, T);
+    gemm(Ln, h, dm, m->enc_qkv[i], dm, a.qkv, 3 * inner, T, 3 * inner, dm);
+    EncAttnArgs ea{a.qkv, mask, d.enc_rel_bias, m->enc_bucket, a.attn, D.bz, D.Lq, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
+                   nullptr, 0};
+    Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(ea, s); });
+    gemm(Ln, a.attn, inner, m->enc_o[i], inner, a.xm, dm, T, dm, inner, a.x);
+    norm(a.xm, m->enc_ln1[i], h, T);
+    gemm(Ln, h, dm, m->enc_wi[i], dm, a.ff, dff, T, dff, dm, nullptr, 1);
+    gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm);
+  }
+  norm(xe_last, d.enc_final_ln, P<float>(w.enc_out), T);
+  gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, dm, P<float>(w.xkv), D.xld, T, D.xld, dm);
+  // ---- teacher-forced decoder over all positions of the positive and the negative smtid
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_train_indices(codes, P<int32_t>(w.in_idx), P<int32_t>(w.out_idx), D.S, D.L, D.V, s); });
+  Ln.run(RPR_K_OTHER, 0, 8.0 * R * dm, [&] { return launch_train_dec_embed(d.start_embed, d.in_embeds, codes, dec_act(w, D, 0).x0, D.S, D.L, dm, D.V, s); });
+  for (int i = 0; i < D.nd; ++i) {
+    DecAct a = dec_act(w, D, i);
+    float* xnext = i + 1 < D.nd ? dec_act(w, D, i + 1).x0 : P<float>(w.x_last);
+    norm(a.x0, m->dec_ln0[i], h, R);
+    gemm(Ln, h, dm, m->dec_qkv[i], dm, a.qkv, 3 * inner, R, 3 * inner, dm);
+    EncAttnArgs sa{a.qkv, nullptr, d.dec_rel_bias, m->dec_bucket, a.a0, D.S, D.L, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
+                   nullptr, 1};
+    Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(sa, s); });
+    gemm(Ln, a.a0, inner, m->dec_o[i], inner, a.x1, dm, R, dm, inner, a.x0);
+    norm(a.x1, m->dec_ln1[i], h, R);
+    gemm(Ln, h, dm, m->dec_xq[i], dm, a.qx, inner, R, inner, dm);
+    const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+    DecCrossAttnArgs ca{a.qx, xk, xk + inner, D.xld, mask, a.a1, D.bz, 2 * D.L, D.H, D.Lq, nullptr, 0, last, nullptr, 0, nullptr};
+    Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] { return launch_dec_cross_attn(ca, s); });
+    gemm(Ln, a.a1, inner, m->dec_xo[i], inner, a.x2, dm, R, dm, inner, a.x1);
+    norm(a.x2, m->dec_ln2[i], h, R);
+    gemm(Ln, h, dm, m->dec_wi[i], dm, a.ff, dff, R, dff, dm, nullptr, 1);
+    gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2);
+  }
+  Ln.run(RPR_K_OTHER, 0, 0, [&] {
+    return launch_gold_scores(P<float>(w.x_last), d.dec_final_ln, d.out_embeds, codes, P<float>(w.scores), D.S, D.L, dm, D.V, D.eps,
+                              D.post, s);
+  });
+}
+
+void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32_t* ids, const int32_t* mask, float* G) {
+  TrainWs& w = *c->tws;
+  const auto& d = m->d;
+  hipStream_t s = Ln.s;
+  const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff, H = D.H;
+  Bwd B{Ln, c, w, D};
+  auto g = [&](int kind, int layer = -1) { return G + param_offset(m, kind, layer); };
+  float *dxa = P<float>(w.dxa), *dxb = P<float>(w.dxb), *dbig = P<float>(w.dbig), *dattn = P<float>(w.dattn), *h = P<float>(w.h);
+  unsigned long long* fix = P<unsigned long long>(w.fix);
+
+  // ---- gold scores: dscore -> (dE rows, dhF) -> final RMSNorm backward
+  Ln.run(RPR_K_OTHER, 0, 0, [&] {   // dE rows go to dxb, dhF to dxa
+    return launch_gold_score_bwd(P<float>(w.x_last), d.dec_final_ln, d.out_embeds, P<int32_t>(w.out_idx), P<float>(w.dscores), dxa, dxb,
+                                 R, dm, D.eps, D.post, s);
+  });
+  float* g_out = d.out_embeds != d.in_embeds ? g(K_OUT_EMB) : g(K_IN_EMB);
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dxb, P<int32_t>(w.out_idx), fix, R, dm, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_fix_flush(fix, g_out, (size_t)d.L * D.V * dm, s); });
+  B.norm_bwd(P<float>(w.x_last), d.dec_final_ln, dxa, nullptr, dxb, g(K_DEC_FLN), R, D.post);
+  float *dx = dxb, *dx2 = dxa;   // dx = gradient w.r.t. the current layer's output stream
+  // ---- decoder layers, last to first
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return hipMemsetAsync(w.dxkv.p, 0, (size_t)T * D.xld * sizeof(float), s); });
+  for (int i = D.nd - 1; i >= 0; --i) {
+    DecAct a = dec_act(w, D, i);
+    // feed-forward: x3 = x2 + relu(norm(x2) Wi^T) Wo^T
+    B.dx(dx, m->dec_wo[i], dbig, R, dm, dff);
+    B.dw(dx, a.ff, g(K_DEC_WO, i), R, dm, dff);
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
+    B.norm(a.x2, m->dec_ln2[i], R);
+    B.dw(dbig, h, g(K_DEC_WI, i), R, dff, dm);
+    B.dx(dbig, m->dec_wi[i], h, R, dff, dm);                       // dh into the (now free) h buffer
+    B.norm_bwd(a.x2, m->dec_ln2[i], h, dx, dx2, g(K_DEC_LN2, i), R);
+    std::swap(dx, dx2);                                            // dx = gradient w.r.t. x2
+    // cross-attention: x2 = x1 + CrossAttn(norm(x1) Wq^T, Kx, Vx) Wo^T
+    B.dx(dx, m->dec_xo[i], dattn, R, dm, inner);
+    B.dw(dx, a.a1, g(K_DEC_XO, i), R, dm, inner);
+    {
+      const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+      float* dxk = P<float>(w.dxkv) + (size_t)i * 2 * inner;
+      Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] {   // dq into dbig (as [R, inner])
+        return launch_cross_attn_bwd(a.qx, xk, xk + inner, D.xld, mask, dattn, dbig, dxk, dxk + inner, D.bz, 2 * D.L, D.Lq, H, s);
+      });
+    }
+    B.norm(a.x1, m->dec_ln1[i], R);
+    B.dw(dbig, h, g(K_DEC_XQ, i), R, inner, dm);
+    B.dx(dbig, m->dec_xq[i], h, R, inner, dm);
+    B.norm_bwd(a.x1, m->dec_ln1[i], h, dx, dx2, g(K_DEC_LN1, i), R);
+    std::swap(dx, dx2);                                            // dx = gradient w.r.t. x1
+    // self-attention: x1 = x0 + SelfAttn(norm(x0) Wqkv^T) Wo^T
+    B.dx(dx, m->dec_o[i], dattn, R, dm, inner);
+    B.dw(dx, a.a0, g(K_DEC_O, i), R, dm, inner);
+    Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
+      return launch_self_attn_bwd(a.qkv, dattn, nullptr, d.dec_rel_bias, m->dec_bucket, dbig, P<float>(w.bias_part), g(K_DEC_REL), D.S,
+                                  D.L, H, d.rel_buckets, 1, s);
+    });
+    B.norm(a.x0, m->dec_ln0[i], R);
+    B.dw(dbig, h, g(K_DEC_QKV, i), R, 3 * inner, dm);
+    B.dx(dbig, m->dec_qkv[i], h, R, 3 * inner, dm);
+    B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
+    std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
+  }
+  // decoder input embeddings: codebook rows and the start embedding
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, P<int32_t>(w.in_idx), fix, R, dm, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_fix_flush(fix, g(K_IN_EMB), (size_t)d.L * D.V * dm, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_sum_selected_rows(dx, P<int32_t>(w.in_idx), g(K_START), R, dm, s); });
+  // ---- cross K/V projection and the encoder's final norm
+  float* denc = P<float>(w.denc);
+  B.dx(P<float>(w.dxkv), d.dec_xkv, denc, T, D.xld, dm);
+  B.dw(P<float>(w.dxkv), P<float>(w.enc_out), g(K_XKV), T, D.xld, dm);
+  float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
+  B.norm_bwd(xe_last, d.enc_final_ln, denc, nullptr, dxa, g(K_ENC_FLN), T);
+  dx = dxa; dx2 = dxb;
+  for (int i = D.ne - 1; i >= 0; --i) {
+    EncAct a = enc_act(w, D, i);
+    B.dx(dx, m->enc_wo[i], dbig, T, dm, dff);
+    B.dw(dx, a.ff, g(K_ENC_WO, i), T, dm, dff);
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
+    B.norm(a.xm, m->enc_ln1[i], T);
+    B.dw(dbig, h, g(K_ENC_WI, i), T, dff, dm);
+    B.dx(dbig, m->enc_wi[i], h, T, dff, dm);
+    B.norm_bwd(a.xm, m->enc_ln1[i], h, dx, dx2, g(K_ENC_LN1, i), T);
+    std::swap(dx, dx2);
+    B.dx(dx, m->enc_o[i], dattn, T, dm, inner);
+    B.dw(dx, a.attn, g(K_ENC_O, i), T, dm, inner);
+    Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
+      return launch_self_attn_bwd(a.qkv, dattn, mask, d.enc_rel_bias, m->enc_bucket, dbig, P<float>(w.bias_part), g(K_ENC_REL), D.bz,
+                                  D.Lq, H, d.rel_buckets, 0, s);
+    });
+    B.norm(a.x, m->enc_ln0[i], T);
+    B.dw(dbig, h, g(K_ENC_QKV, i), T, 3 * inner, dm);
+    B.dx(dbig, m->enc_qkv[i], h, T, 3 * inner, dm);
+    B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
+    std::swap(dx, dx2);
+  }
+  // token embeddings (the encoder's table is the shared one)
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, ids, fix, T, dm, s); });
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_fix_flush(fix, g(K_SHARED), (size_t)d.vocab_size * dm, s); });
+}
+
+}  // namespace
+
+void rpr::free_train_ws(rpr_ctx* c) {
+  if (!c->tws) return;
+  TrainWs& w = *c->tws;
+  DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
+                   &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
+                   &w.fix, &w.gn_part, &w.gn_out};
+  for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  delete c->tws;
+  c->tws = nullptr;
+}
+
+extern "C" {
+
+int64_t rpr_param_count(rpr_model* m) { if (!m) return 0; build_params(m); return (int64_t)m->params.size(); }
+int64_t rpr_param_total(rpr_model* m) { if (!m) return 0; build_params(m); return (int64_t)m->params_total; }
+int rpr_param_info(rpr_model* m, int64_t index, const float** ptr, int64_t* numel, int64_t* offset) {
+  RPR_REQUIRE(m, "NULL model");
+  build_params(m);
+  RPR_REQUIRE(index >= 0 && index < (int64_t)m->params.size(), "parameter index out of range");
+  const auto& p = m->params[(size_t)index];
+  if (ptr) *ptr = p.ptr;
+  if (numel) *numel = (int64_t)p.numel;
+  if (offset) *offset = (int64_t)p.offset;
+  return RPR_OK;
+}
+
+int rpr_lngknp_backward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz, int32_t Lq,
+                        const int32_t* doc_codes, int32_t L, const float* teacher_pos, const float* teacher_neg,
+                        const int32_t* prefix_lens, int32_t n_prefix, float* out_losses, float* flat_grads, void* stream) {
+  RPR_REQUIRE(c && m && input_ids && attention_mask && doc_codes && teacher_pos && teacher_neg && prefix_lens && out_losses &&
+                  flat_grads, "NULL argument");
+  RPR_REQUIRE(m->ctx == c, "model belongs to another ctx");
+  RPR_REQUIRE(bz >= 1 && Lq >= 1 && Lq <= 128, "bz or Lq out of range (the training kernels hold Lq <= 128 keys in LDS)");
+  RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= MAX_DEC_LEN, "smtid length exceeds the model's decoder length");
+  RPR_REQUIRE(n_prefix >= 1 && n_prefix <= 8, "n_prefix out of range (1..8)");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  build_params(m);
+  const auto& d = m->d;
+  Dims D{};
+  D.bz = bz; D.Lq = Lq; D.L = L; D.S = bz * 2; D.R = D.S * L; D.T = bz * Lq; D.dm = d.d_model; D.inner = m->inner(); D.dff = d.d_ff;
+  D.H = d.num_heads; D.ne = d.num_layers; D.nd = d.num_decoder_layers; D.V = d.V; D.xld = D.nd * 2 * D.inner; D.buckets = d.rel_buckets;
+  D.eps = d.layer_norm_eps; D.post = d.scaleup_output_hidden ? (float)pow((double)D.dm, -0.5) : 1.0f;
+  D.enc_stride = (size_t)D.T * (2 * D.dm + 4 * D.inner + D.dff);
+  D.dec_stride = (size_t)D.R * (3 * D.dm + 6 * D.inner + D.dff);
+  RPR_REQUIRE(self_attn_bwd_smem(std::max(L, Lq), d.rel_buckets) <= 160 * 1024 && cross_attn_bwd_smem(2 * L, Lq) <= 160 * 1024,
+              "sequence lengths too large for the LDS-resident attention backward");
+  int e = alloc_train(c, m, D);
+  if (e) return e;
+  // the forward's cross-attention kernel needs the per-query key counts: reuse the search workspace's small buffers
+  e = ensure(c, c->ws.last, (size_t)bz * 4);
+  if (e) return e;
+  TrainWs& w = *c->tws;
+  RPR_HIP(hipMemsetAsync(flat_grads, 0, m->params_total * sizeof(float), s));
+  RPR_HIP(hipMemsetAsync(w.fix.p, 0, w.fix.cap, s));
+  Launcher Ln{c, s};
+  forward(Ln, c, m, D, input_ids, attention_mask, doc_codes, P<int32_t>(c->ws.last));
+  if (Ln.err) return Ln.err;
+  RPR_HIP(launch_margin_mse(P<float>(w.scores), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, out_losses, P<float>(w.margins), s));
+  // total loss = sum of the task losses with weight 1 (reference arguments.py:109-119, trainer.py:228-240)
+  RPR_HIP(launch_margin_mse_bwd(P<float>(w.margins), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, P<float>(w.dscores), s));
+  backward(Ln, c, m, D, input_ids, attention_mask, flat_grads);
+  return Ln.err;
+}
+
+int rpr_adamw_step(rpr_ctx* c, rpr_model* m, const float* flat_grads, float* exp_avg, float* exp_avg_sq, int64_t step, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, float* out_grad_norm,
+                   void* stream) {
+  RPR_REQUIRE(c && m && flat_grads && exp_avg && exp_avg_sq, "NULL argument");
+  RPR_REQUIRE(m->ctx == c && step >= 1, "bad model or step (1-based)");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  build_params(m);
+  if (!c->tws) c->tws = new TrainWs();
+  TrainWs& w = *c->tws;
+  int e = tensure(c, w.gn_part, 1024 * 8);
+  if (!e) e = tensure(c, w.gn_out, 16);
+  if (e) return e;
+  RPR_HIP(launch_grad_norm(flat_grads, m->params_total, P<double>(w.gn_part), 1024, max_grad_norm, P<float>(w.gn_out), s));
+  const float bc1 = 1.0f - (float)pow((double)beta1, (double)step);
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  for (const auto& p : m->params)
+    RPR_HIP(launch_adamw(p.ptr, flat_grads + p.offset, exp_avg + p.offset, exp_avg_sq + p.offset, p.numel, P<float>(w.gn_out), lr, beta1,
+                         beta2, eps, weight_decay, bc1, bc2s, s));
+  if (out_grad_norm) RPR_HIP(hipMemcpyAsync(out_grad_norm, w.gn_out.p, 4, hipMemcpyDeviceToDevice, s));
+  // the search / forward paths read the f16 planes of the weights: refresh them (synchronises the stream)
+  return refresh_weight_planes(c, m, s);
+}
+
+}  // extern "C"

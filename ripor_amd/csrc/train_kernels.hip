@@ -153,4 +153,480 @@ hipError_t launch_margin_mse(const float* scores, const float* teacher_pos, cons
   return hipGetLastError();
 }
 
+
+// ====================================================================================================================
+// Backward pass of the ranking fine-tune step (reference: loss.backward() in tasks/trainer.py:203-275 over
+// T5SeqAQEncoderForLngKnpMarginMSE.forward). Activations are fp32 here; every matrix product of the backward pass is
+// the forward GEMM kernel on explicitly transposed operands (dX = dY W -> dY (W^T)^T, dW = dY^T X -> (dY^T)(X^T)^T), so
+// the only new arithmetic kernels are the row-wise / per-(sequence, head) ones below. Everything is deterministic:
+// cross-row sums go through per-block partials reduced in a fixed order, scatter-adds into embedding tables through
+// 2^-32 fixed-point integer atomics.
+// ====================================================================================================================
+
+// out[C, ldo] = in[R, C]^T, columns r >= R of the output zero-filled up to Rpad (the K dimension of a dW product must
+// be a multiple of the GEMM's K-tile)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
+                                                             int ldi, int Rpad) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? in[(size_t)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < Rpad) out[(size_t)c * Rpad + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((C + 31) / 32, (Rpad + 31) / 32), dim3(256), 0, s, in, out, R, C, ldi, Rpad);
+  return hipGetLastError();
+}
+
+// y[i] = (mask[i] > 0) ? y[i] : 0     (ReLU backward on the stored post-activation)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ act, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 d = *reinterpret_cast<float4*>(dy + i);
+  const float4 a = *reinterpret_cast<const float4*>(act + i);
+  d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+  *reinterpret_cast<float4*>(dy + i) = d;
+}
+hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, act, n);
+  return hipGetLastError();
+}
+
+// RMSNorm backward. h = post * w * x * rs, rs = rsqrt(mean(x^2) + eps). Given dh:
+//   g = dh * post * w;  dx = rs * g - x * rs^3 * mean(g * x);  dw += dh * post * x * rs (summed over rows)
+// dx_out[row] = dx (+ dres[row]: the gradient arriving through the residual connection). One wave per row; the 4 rows
+// of a block leave one partial dw row (w_part[blk][d]); colsum_kernel adds the partials in block order.
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ dh, const float* __restrict__ dres,
+                                                           float* __restrict__ dx_out, float* __restrict__ w_part, int rows,
+                                                           int d, float eps, float post) {
+  extern __shared__ float part[];   // [4][d]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  const int n4 = d >> 2;
+  float* mypart = part + wave * d;
+  if (row < rows) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    const float4* gr = reinterpret_cast<const float4*>(dh + (size_t)row * d);
+    const float4* wr = reinterpret_cast<const float4*>(w);
+    float ss = 0.f;
+    for (int i = lane; i < n4; i += 64) { const float4 v = xr[i]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    ss = wave_sum_f(ss);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    float gx = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+      const float4 v = xr[i], g = gr[i], ww = wr[i];
+      gx += (g.x * ww.x) * v.x + (g.y * ww.y) * v.y + (g.z * ww.z) * v.z + (g.w * ww.w) * v.w;
+    }
+    gx = wave_sum_f(gx) * post;
+    const float c = gx * rs * rs * rs / (float)d;
+    for (int i = lane; i < n4; i += 64) {
+      const float4 v = xr[i], g = gr[i], ww = wr[i];
+      float4 o = make_float4(rs * post * g.x * ww.x - v.x * c, rs * post * g.y * ww.y - v.y * c,
+                             rs * post * g.z * ww.z - v.z * c, rs * post * g.w * ww.w - v.w * c);
+      if (dres) { const float4 r = reinterpret_cast<const float4*>(dres + (size_t)row * d)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+      reinterpret_cast<float4*>(dx_out + (size_t)row * d)[i] = o;
+      reinterpret_cast<float4*>(mypart)[i] = make_float4(g.x * post * v.x * rs, g.y * post * v.y * rs, g.z * post * v.z * rs, g.w * post * v.w * rs);
+    }
+  } else {
+    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(mypart)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < d; k += 256)
+    w_part[(size_t)blockIdx.x * d + k] = (part[k] + part[d + k]) + (part[2 * d + k] + part[3 * d + k]);
+}
+
+// out[k] (+)= sum over p of part[p][k], p in increasing order (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int d,
+                                                      int accumulate) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= d) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * d + k];
+  out[k] = accumulate ? out[k] + s : s;
+}
+
+hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
+                              float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const int nblk = (rows + 3) / 4;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), s, x, w, dh, dres, dx_out, w_part, rows, d,
+                     eps, post);
+  hipLaunchKernelGGL(colsum_kernel, dim3((d + 255) / 256), dim3(256), 0, s, w_part, dw, nblk, d, accumulate_dw);
+  return hipGetLastError();
+}
+
+// ---- attention backward, one block per (sequence, head), everything in LDS -----------------------------------------
+// Self-attention (encoder: bidirectional buckets + key padding mask; decoder, teacher-forced: causal, unidirectional
+// buckets). qkv: [S*Ls, 3*inner]; dO: [S*Ls, inner]; outputs dqkv [S*Ls, 3*inner] and this block's part of the
+// relative-bias gradient dbias_part[(s * H + h)][buckets]. Recomputes P from q, k (nothing but q, k, v was saved).
+__global__ __launch_bounds__(256) void self_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                             const int32_t* __restrict__ mask, const float* __restrict__ rel_bias,
+                                                             const int32_t* __restrict__ bucket, float* __restrict__ dqkv,
+                                                             float* __restrict__ dbias_part, int S, int Ls, int H, int buckets,
+                                                             int causal) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int s = blockIdx.x / H, h = blockIdx.x - s * H, inner = H * DKV, ld = 3 * inner, tid = threadIdx.x;
+  const int PL = Ls + 1;
+  float* Qs = sm;                       // [Ls][64]
+  float* Ks = Qs + Ls * DKV;
+  float* Vs = Ks + Ls * DKV;
+  float* Ds = Vs + Ls * DKV;            // dO
+  float* Ps = Ds + Ls * DKV;            // [Ls][PL]  probabilities
+  float* Gs = Ps + Ls * PL;             // [Ls][PL]  dP, then dS
+  float* Bs = Gs + Ls * PL;             // [buckets]
+  const size_t row0 = (size_t)s * Ls;
+  for (int i = tid; i < Ls * 16; i += 256) {
+    const int r = i >> 4, c = (i & 15) * 4;
+    const float* base = qkv + (row0 + r) * ld + h * DKV + c;
+    *reinterpret_cast<float4*>(Qs + r * DKV + c) = *reinterpret_cast<const float4*>(base);
+    *reinterpret_cast<float4*>(Ks + r * DKV + c) = *reinterpret_cast<const float4*>(base + inner);
+    *reinterpret_cast<float4*>(Vs + r * DKV + c) = *reinterpret_cast<const float4*>(base + 2 * inner);
+    *reinterpret_cast<float4*>(Ds + r * DKV + c) = *reinterpret_cast<const float4*>(dO + (row0 + r) * inner + h * DKV + c);
+  }
+  if (tid < buckets) Bs[tid] = rel_bias[tid * H + h];
+  __syncthreads();
+  const int32_t* mrow = mask ? mask + (size_t)s * Ls : nullptr;
+  for (int p = tid; p < Ls * Ls; p += 256) {      // scores and dP = dO V^T
+    const int i = p / Ls, j = p - i * Ls;
+    const bool ok = causal ? (j <= i) : (mrow[j] != 0);
+    float sc = 0.f, dp = 0.f;
+    if (ok) {
+      for (int d = 0; d < DKV; ++d) { sc = fmaf(Qs[i * DKV + d], Ks[j * DKV + d], sc); dp = fmaf(Ds[i * DKV + d], Vs[j * DKV + d], dp); }
+      sc += Bs[causal ? bucket[i - j] : bucket[j - i + (MAX_LQ - 1)]];
+    }
+    Ps[i * PL + j] = ok ? sc : -INFINITY;
+    Gs[i * PL + j] = dp;
+  }
+  __syncthreads();
+  for (int i = tid; i < Ls; i += 256) {            // softmax row i, then dS = P * (dP - sum_j dP P)
+    float mx = -INFINITY;
+    for (int j = 0; j < Ls; ++j) mx = fmaxf(mx, Ps[i * PL + j]);
+    float sum = 0.f;
+    for (int j = 0; j < Ls; ++j) { const float e = (Ps[i * PL + j] == -INFINITY) ? 0.f : expf(Ps[i * PL + j] - mx); Ps[i * PL + j] = e; sum += e; }
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float c = 0.f;
+    for (int j = 0; j < Ls; ++j) { const float pj = Ps[i * PL + j] * inv; Ps[i * PL + j] = pj; c = fmaf(Gs[i * PL + j], pj, c); }
+    for (int j = 0; j < Ls; ++j) Gs[i * PL + j] = Ps[i * PL + j] * (Gs[i * PL + j] - c);
+  }
+  __syncthreads();
+  for (int it = tid; it < Ls * 16; it += 256) {    // dQ_i = sum_j dS_ij K_j ; dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i
+    const int r = it >> 4, c = (it & 15) * 4;
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dk = dq, dv = dq;
+    for (int j = 0; j < Ls; ++j) {
+      const float g = Gs[r * PL + j];
+      const float4 k4 = *reinterpret_cast<const float4*>(Ks + j * DKV + c);
+      dq.x = fmaf(g, k4.x, dq.x); dq.y = fmaf(g, k4.y, dq.y); dq.z = fmaf(g, k4.z, dq.z); dq.w = fmaf(g, k4.w, dq.w);
+      const float gt = Gs[j * PL + r], pt = Ps[j * PL + r];
+      const float4 q4 = *reinterpret_cast<const float4*>(Qs + j * DKV + c), o4 = *reinterpret_cast<const float4*>(Ds + j * DKV + c);
+      dk.x = fmaf(gt, q4.x, dk.x); dk.y = fmaf(gt, q4.y, dk.y); dk.z = fmaf(gt, q4.z, dk.z); dk.w = fmaf(gt, q4.w, dk.w);
+      dv.x = fmaf(pt, o4.x, dv.x); dv.y = fmaf(pt, o4.y, dv.y); dv.z = fmaf(pt, o4.z, dv.z); dv.w = fmaf(pt, o4.w, dv.w);
+    }
+    float* ob = dqkv + (row0 + r) * ld + h * DKV + c;
+    *reinterpret_cast<float4*>(ob) = dq;
+    *reinterpret_cast<float4*>(ob + inner) = dk;
+    *reinterpret_cast<float4*>(ob + 2 * inner) = dv;
+  }
+  if (tid < buckets) {                               // bias gradient of this block, bucket by bucket (fixed order)
+    float acc = 0.f;
+    for (int i = 0; i < Ls; ++i)
+      for (int j = 0; j < Ls; ++j) {
+        const bool ok = causal ? (j <= i) : (mrow[j] != 0);
+        if (ok && (causal ? bucket[i - j] : bucket[j - i + (MAX_LQ - 1)]) == tid) acc += Gs[i * PL + j];
+      }
+    dbias_part[(size_t)blockIdx.x * buckets + tid] = acc;
+  }
+}
+
+// dbias[bucket][h] += sum over sequences s of part[(s*H + h)][bucket], in s order
+__global__ __launch_bounds__(64) void bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int S, int H,
+                                                          int buckets) {
+  const int h = blockIdx.x, b = threadIdx.x;
+  if (b >= buckets) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += part[((size_t)s * H + h) * buckets + b];
+  dbias[b * H + h] += acc;
+}
+
+size_t self_attn_bwd_smem(int Ls, int buckets) { return ((size_t)4 * Ls * DKV + 2 * (size_t)Ls * (Ls + 1) + buckets) * sizeof(float); }
+
+hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias, const int32_t* bucket,
+                                float* dqkv, float* dbias_part, float* dbias, int S, int Ls, int H, int buckets, int causal,
+                                hipStream_t s) {
+  const size_t smem = self_attn_bwd_smem(Ls, buckets);
+  if (smem > 160 * 1024 || buckets > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(self_attn_bwd_kernel, dim3(S * H), dim3(256), smem, s, qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part, S, Ls,
+                     H, buckets, causal);
+  hipLaunchKernelGGL(bias_reduce_kernel, dim3(H), dim3(64), 0, s, dbias_part, dbias, S, H, buckets);
+  return hipGetLastError();
+}
+
+// Cross-attention backward, block per (query, head): the n = ndoc*L decoder rows of the query against its Lq encoder
+// keys. q: [bz*n, inner]; K/V of this layer: rows (query, j) at xk/xv + (query*Lq + j) * xld; dO: [bz*n, inner].
+// Outputs dq [bz*n, inner] and dK/dV into dxk/dxv (same layout as xk/xv): every (query, head) block owns its rows
+// and columns, so there is no accumulation across blocks.
+__global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ xk,
+                                                              const float* __restrict__ xv, int xld, const int32_t* __restrict__ mask,
+                                                              const float* __restrict__ dO, float* __restrict__ dq,
+                                                              float* __restrict__ dxk, float* __restrict__ dxv, int n, int Lq, int H) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int qi = blockIdx.x / H, h = blockIdx.x - qi * H, inner = H * DKV, tid = threadIdx.x;
+  const int PL = Lq + 1;
+  float* Qs = sm;                     // [n][64]
+  float* Ds = Qs + n * DKV;           // dO [n][64]
+  float* Ks = Ds + n * DKV;           // [Lq][64]
+  float* Vs = Ks + Lq * DKV;
+  float* Ps = Vs + Lq * DKV;          // [n][PL]
+  float* Gs = Ps + n * PL;            // [n][PL]
+  const int32_t* mrow = mask + (size_t)qi * Lq;
+  for (int i = tid; i < n * 16; i += 256) {
+    const int r = i >> 4, c = (i & 15) * 4;
+    const size_t o = ((size_t)qi * n + r) * inner + h * DKV + c;
+    *reinterpret_cast<float4*>(Qs + r * DKV + c) = *reinterpret_cast<const float4*>(q + o);
+    *reinterpret_cast<float4*>(Ds + r * DKV + c) = *reinterpret_cast<const float4*>(dO + o);
+  }
+  for (int i = tid; i < Lq * 16; i += 256) {
+    const int j = i >> 4, c = (i & 15) * 4;
+    const size_t o = ((size_t)qi * Lq + j) * xld + h * DKV + c;
+    *reinterpret_cast<float4*>(Ks + j * DKV + c) = *reinterpret_cast<const float4*>(xk + o);
+    *reinterpret_cast<float4*>(Vs + j * DKV + c) = *reinterpret_cast<const float4*>(xv + o);
+  }
+  __syncthreads();
+  for (int p = tid; p < n * Lq; p += 256) {
+    const int i = p / Lq, j = p - i * Lq;
+    const bool ok = mrow[j] != 0;
+    float sc = 0.f, dp = 0.f;
+    if (ok)
+      for (int d = 0; d < DKV; ++d) { sc = fmaf(Qs[i * DKV + d], Ks[j * DKV + d], sc); dp = fmaf(Ds[i * DKV + d], Vs[j * DKV + d], dp); }
+    Ps[i * PL + j] = ok ? sc : -INFINITY;
+    Gs[i * PL + j] = dp;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    float mx = -INFINITY;
+    for (int j = 0; j < Lq; ++j) mx = fmaxf(mx, Ps[i * PL + j]);
+    float sum = 0.f;
+    for (int j = 0; j < Lq; ++j) { const float e = (Ps[i * PL + j] == -INFINITY) ? 0.f : expf(Ps[i * PL + j] - mx); Ps[i * PL + j] = e; sum += e; }
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float c = 0.f;
+    for (int j = 0; j < Lq; ++j) { const float pj = Ps[i * PL + j] * inv; Ps[i * PL + j] = pj; c = fmaf(Gs[i * PL + j], pj, c); }
+    for (int j = 0; j < Lq; ++j) Gs[i * PL + j] = Ps[i * PL + j] * (Gs[i * PL + j] - c);
+  }
+  __syncthreads();
+  for (int it = tid; it < n * 16; it += 256) {      // dq_i = sum_j dS_ij K_j
+    const int r = it >> 4, c = (it & 15) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Lq; ++j) {
+      const float g = Gs[r * PL + j];
+      const float4 k4 = *reinterpret_cast<const float4*>(Ks + j * DKV + c);
+      a.x = fmaf(g, k4.x, a.x); a.y = fmaf(g, k4.y, a.y); a.z = fmaf(g, k4.z, a.z); a.w = fmaf(g, k4.w, a.w);
+    }
+    *reinterpret_cast<float4*>(dq + ((size_t)qi * n + r) * inner + h * DKV + c) = a;
+  }
+  for (int it = tid; it < Lq * 16; it += 256) {     // dK_j = sum_i dS_ij q_i ; dV_j = sum_i P_ij dO_i
+    const int j = it >> 4, c = (it & 15) * 4;
+    float4 dk = make_float4(0.f, 0.f, 0.f, 0.f), dv = dk;
+    for (int i = 0; i < n; ++i) {
+      const float g = Gs[i * PL + j], pp = Ps[i * PL + j];
+      const float4 q4 = *reinterpret_cast<const float4*>(Qs + i * DKV + c), o4 = *reinterpret_cast<const float4*>(Ds + i * DKV + c);
+      dk.x = fmaf(g, q4.x, dk.x); dk.y = fmaf(g, q4.y, dk.y); dk.z = fmaf(g, q4.z, dk.z); dk.w = fmaf(g, q4.w, dk.w);
+      dv.x = fmaf(pp, o4.x, dv.x); dv.y = fmaf(pp, o4.y, dv.y); dv.z = fmaf(pp, o4.z, dv.z); dv.w = fmaf(pp, o4.w, dv.w);
+    }
+    const size_t o = ((size_t)qi * Lq + j) * xld + h * DKV + c;
+    *reinterpret_cast<float4*>(dxk + o) = dk;
+    *reinterpret_cast<float4*>(dxv + o) = dv;
+  }
+}
+
+size_t cross_attn_bwd_smem(int n, int Lq) { return ((size_t)2 * n * DKV + 2 * (size_t)Lq * DKV + 2 * (size_t)n * (Lq + 1)) * sizeof(float); }
+
+hipError_t launch_cross_attn_bwd(const float* q, const float* xk, const float* xv, int xld, const int32_t* mask, const float* dO,
+                                 float* dq, float* dxk, float* dxv, int bz, int n, int Lq, int H, hipStream_t s) {
+  const size_t smem = cross_attn_bwd_smem(n, Lq);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(bz * H), dim3(256), smem, s, q, xk, xv, xld, mask, dO, dq, dxk, dxv, n, Lq, H);
+  return hipGetLastError();
+}
+
+// ---- scatter-add of rows into an embedding-table gradient, deterministic ---------------------------------------------
+// acc: int64 [table_rows, d], 2^-32 fixed point. Row r of src goes to table row idx(r) (< 0: skipped).
+constexpr double GRAD_FIX = 4294967296.0;
+__global__ __launch_bounds__(256) void scatter_rows_fix_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                                unsigned long long* __restrict__ acc, int rows, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int t = idx[row];
+  if (t < 0) return;
+  for (int k = lane; k < d; k += 64)
+    atomicAdd(acc + (size_t)t * d + k, (unsigned long long)(long long)llrint((double)src[(size_t)row * d + k] * GRAD_FIX));
+}
+// dst[i] += acc[i] * 2^-32 ; acc[i] = 0
+__global__ __launch_bounds__(256) void fix_flush_kernel(unsigned long long* __restrict__ acc, float* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long v = (long long)acc[i];
+  if (v != 0) { dst[i] += (float)((double)v / GRAD_FIX); acc[i] = 0ull; }
+}
+hipError_t launch_scatter_rows_fix(const float* src, const int32_t* idx, unsigned long long* acc, int rows, int d, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_rows_fix_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, idx, acc, rows, d);
+  return hipGetLastError();
+}
+hipError_t launch_fix_flush(unsigned long long* acc, float* dst, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(fix_flush_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, dst, n);
+  return hipGetLastError();
+}
+
+// row r = (s, i) of the teacher-forced decoder -> index of its input-embedding row in the stacked [L, V] tables
+// (i = 0: the start embedding, index -1) and of its gold code's output-codebook row
+__global__ __launch_bounds__(256) void train_indices_kernel(const int32_t* __restrict__ codes, int32_t* __restrict__ in_idx,
+                                                             int32_t* __restrict__ out_idx, int S, int L, int V) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= S * L) return;
+  const int s = r / L, i = r - s * L;
+  auto clampv = [&](int t) { return t < 0 ? 0 : (t >= V ? V - 1 : t); };
+  in_idx[r] = i == 0 ? -1 : (i - 1) * V + clampv(codes[(size_t)s * L + i - 1]);
+  out_idx[r] = i * V + clampv(codes[(size_t)s * L + i]);
+}
+hipError_t launch_train_indices(const int32_t* codes, int32_t* in_idx, int32_t* out_idx, int S, int L, int V, hipStream_t s) {
+  hipLaunchKernelGGL(train_indices_kernel, dim3((S * L + 255) / 256), dim3(256), 0, s, codes, in_idx, out_idx, S, L, V);
+  return hipGetLastError();
+}
+
+// out[k] += sum over rows r with sel[r] < 0 of src[r][k], rows in increasing order (gradient of the start embedding)
+__global__ __launch_bounds__(256) void sum_selected_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ sel,
+                                                                 float* __restrict__ out, int rows, int d) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= d) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) if (sel[r] < 0) a += src[(size_t)r * d + k];
+  out[k] += a;
+}
+hipError_t launch_sum_selected_rows(const float* src, const int32_t* sel, float* out, int rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(sum_selected_rows_kernel, dim3((d + 255) / 256), dim3(256), 0, s, src, sel, out, rows, d);
+  return hipGetLastError();
+}
+
+// ---- loss and gold-score backward -------------------------------------------------------------------------------------
+// dscore[b][side][i] = sum_p [i < k_p] * sign(side) * 2 / bz * (student_margin[p][b] - teacher_margin[p][b])
+__global__ __launch_bounds__(256) void margin_mse_bwd_kernel(const float* __restrict__ margins, const float* __restrict__ teacher_pos,
+                                                              const float* __restrict__ teacher_neg, const int32_t* __restrict__ prefix_lens,
+                                                              int n_prefix, int bz, int L, float* __restrict__ dscores) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= bz * 2 * L) return;
+  const int b = idx / (2 * L), rem = idx - b * 2 * L, side = rem / L, i = rem - side * L;
+  float g = 0.f;
+  for (int p = 0; p < n_prefix; ++p)
+    if (i < prefix_lens[p]) {
+      const float tm = teacher_pos[(size_t)p * bz + b] - teacher_neg[(size_t)p * bz + b];
+      g += 2.0f / (float)bz * (margins[(size_t)p * bz + b] - tm);
+    }
+  dscores[idx] = side == 0 ? g : -g;
+}
+hipError_t launch_margin_mse_bwd(const float* margins, const float* teacher_pos, const float* teacher_neg, const int32_t* prefix_lens,
+                                 int n_prefix, int bz, int L, float* dscores, hipStream_t s) {
+  hipLaunchKernelGGL(margin_mse_bwd_kernel, dim3((bz * 2 * L + 255) / 256), dim3(256), 0, s, margins, teacher_pos, teacher_neg,
+                     prefix_lens, n_prefix, bz, L, dscores);
+  return hipGetLastError();
+}
+
+// score_r = <hF_r, E_r>, hF = post * w * x * rs. Given dscore_r: dE_r = dscore * hF (scattered into the output codebook
+// gradient by the caller: dE rows written to de[r]), dhF = dscore * E_r -> dh[r] (the caller runs rmsnorm_bwd on it).
+__global__ __launch_bounds__(256) void gold_score_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ln,
+                                                              const float* __restrict__ out_embeds, const int32_t* __restrict__ out_idx,
+                                                              const float* __restrict__ dscores, float* __restrict__ dh,
+                                                              float* __restrict__ de, int rows, int d, float eps, float post) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+  const float4* wr = reinterpret_cast<const float4*>(ln);
+  const float4* er = reinterpret_cast<const float4*>(out_embeds + (size_t)out_idx[row] * d);
+  const int n4 = d >> 2;
+  float ss = 0.f;
+  for (int k = lane; k < n4; k += 64) { const float4 v = xr[k]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+  ss = wave_sum_f(ss);
+  const float rs = rsqrtf(ss / (float)d + eps), g = dscores[row];
+  for (int k = lane; k < n4; k += 64) {
+    const float4 v = xr[k], w = wr[k], e = er[k];
+    reinterpret_cast<float4*>(de + (size_t)row * d)[k] = make_float4(g * post * w.x * (v.x * rs), g * post * w.y * (v.y * rs),
+                                                                     g * post * w.z * (v.z * rs), g * post * w.w * (v.w * rs));
+    reinterpret_cast<float4*>(dh + (size_t)row * d)[k] = make_float4(g * e.x, g * e.y, g * e.z, g * e.w);
+  }
+}
+hipError_t launch_gold_score_bwd(const float* x, const float* ln, const float* out_embeds, const int32_t* out_idx, const float* dscores,
+                                 float* dh, float* de, int rows, int d, float eps, float post, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gold_score_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ln, out_embeds, out_idx, dscores, dh, de, rows, d,
+                     eps, post);
+  return hipGetLastError();
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------------------------
+// sum of squares of a flat buffer: block partials in double, then one block adds them in order (deterministic)
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, size_t n, double* __restrict__ part) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += (double)g[i] * (double)g[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void sumsq_final_kernel(const double* __restrict__ part, int n, float max_norm, float* __restrict__ out /*[2]: norm, clip*/) {
+  double a = 0.0;
+  for (int i = 0; i < n; ++i) a += part[i];
+  const double nrm = sqrt(a);
+  out[0] = (float)nrm;
+  // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+  const double c = max_norm > 0.f ? (double)max_norm / (nrm + 1e-6) : 1.0;
+  out[1] = (float)(c < 1.0 ? c : 1.0);
+}
+hipError_t launch_grad_norm(const float* g, size_t n, double* part, int nparts, float max_norm, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_part_kernel, dim3(nparts), dim3(256), 0, s, g, n, part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1), 0, s, part, nparts, max_norm, out);
+  return hipGetLastError();
+}
+
+// torch.optim.AdamW (decoupled weight decay, no amsgrad), gradient scaled by the clip coefficient on the device:
+//   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, size_t n, const float* __restrict__ clip, float lr,
+                                                     float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * clip[1];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  float pi = p[i] * (1.f - lr * wd);
+  pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  p[i] = pi;
+}
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* clip, float lr, float b1, float b2,
+                        float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, clip, lr, b1, b2, eps, wd, bc1,
+                     bc2_sqrt);
+  return hipGetLastError();
+}
+
+hipError_t init_train_kernel_attributes() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(self_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 }  // namespace rpr

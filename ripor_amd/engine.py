@@ -180,50 +180,69 @@ class DeviceModel:
             raise ValueError("not valid decoder_vocab_size")  # reference evaluate.py:433-436
         shared_embeds = bool(cfg.shared_output_input_embeds)
         keep: List[torch.Tensor] = []
+        # (checkpoint tensor name, packed device tensor, slice of it or None): how the packed tensors map back to names
+        self._names: List[tuple] = []
 
         def K(t):
             keep.append(t)
             return t
 
+        def N(name, t, sl=None):
+            self._names.append((name, t, sl))
+            return t
+
         def attn_qkv(prefix):
-            return K(torch.cat([g(prefix + ".q.weight"), g(prefix + ".k.weight"), g(prefix + ".v.weight")], 0).contiguous())
+            t = K(torch.cat([g(prefix + ".q.weight"), g(prefix + ".k.weight"), g(prefix + ".v.weight")], 0).contiguous())
+            n = t.shape[0] // 3
+            for j, w in enumerate("qkv"):
+                N(f"{prefix}.{w}.weight", t, slice(j * n, (j + 1) * n))
+            return t
 
         ne, nd = cfg.num_layers, cfg.num_decoder_layers
         enc = dict(ln0=[], qkv=[], o=[], ln1=[], wi=[], wo=[])
         for i in range(ne):
             p = f"encoder.block.{i}.layer"
-            enc["ln0"].append(K(g(p + ".0.layer_norm.weight")))
+            enc["ln0"].append(N(p + ".0.layer_norm.weight", K(g(p + ".0.layer_norm.weight"))))
             enc["qkv"].append(attn_qkv(p + ".0.SelfAttention"))
-            enc["o"].append(K(g(p + ".0.SelfAttention.o.weight")))
-            enc["ln1"].append(K(g(p + ".1.layer_norm.weight")))
-            enc["wi"].append(K(g(p + ".1.DenseReluDense.wi.weight")))
-            enc["wo"].append(K(g(p + ".1.DenseReluDense.wo.weight")))
+            enc["o"].append(N(p + ".0.SelfAttention.o.weight", K(g(p + ".0.SelfAttention.o.weight"))))
+            enc["ln1"].append(N(p + ".1.layer_norm.weight", K(g(p + ".1.layer_norm.weight"))))
+            enc["wi"].append(N(p + ".1.DenseReluDense.wi.weight", K(g(p + ".1.DenseReluDense.wi.weight"))))
+            enc["wo"].append(N(p + ".1.DenseReluDense.wo.weight", K(g(p + ".1.DenseReluDense.wo.weight"))))
         dec = dict(ln0=[], qkv=[], o=[], ln1=[], xq=[], xo=[], ln2=[], wi=[], wo=[])
         xkv = []
         for i in range(nd):
             p = f"decoder.block.{i}.layer"
-            dec["ln0"].append(K(g(p + ".0.layer_norm.weight")))
+            dec["ln0"].append(N(p + ".0.layer_norm.weight", K(g(p + ".0.layer_norm.weight"))))
             dec["qkv"].append(attn_qkv(p + ".0.SelfAttention"))
-            dec["o"].append(K(g(p + ".0.SelfAttention.o.weight")))
-            dec["ln1"].append(K(g(p + ".1.layer_norm.weight")))
-            dec["xq"].append(K(g(p + ".1.EncDecAttention.q.weight")))
+            dec["o"].append(N(p + ".0.SelfAttention.o.weight", K(g(p + ".0.SelfAttention.o.weight"))))
+            dec["ln1"].append(N(p + ".1.layer_norm.weight", K(g(p + ".1.layer_norm.weight"))))
+            dec["xq"].append(N(p + ".1.EncDecAttention.q.weight", K(g(p + ".1.EncDecAttention.q.weight"))))
             xkv += [g(p + ".1.EncDecAttention.k.weight"), g(p + ".1.EncDecAttention.v.weight")]
-            dec["xo"].append(K(g(p + ".1.EncDecAttention.o.weight")))
-            dec["ln2"].append(K(g(p + ".2.layer_norm.weight")))
-            dec["wi"].append(K(g(p + ".2.DenseReluDense.wi.weight")))
-            dec["wo"].append(K(g(p + ".2.DenseReluDense.wo.weight")))
-        self.shared = K(g("shared.weight"))
-        self.enc_rel = K(g("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"))
-        self.dec_rel = K(g("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"))
-        self.enc_fln = K(g("encoder.final_layer_norm.weight"))
-        self.dec_fln = K(g("decoder.final_layer_norm.weight"))
-        self.start = K(g("start_token_embed").reshape(-1).contiguous())
+            dec["xo"].append(N(p + ".1.EncDecAttention.o.weight", K(g(p + ".1.EncDecAttention.o.weight"))))
+            dec["ln2"].append(N(p + ".2.layer_norm.weight", K(g(p + ".2.layer_norm.weight"))))
+            dec["wi"].append(N(p + ".2.DenseReluDense.wi.weight", K(g(p + ".2.DenseReluDense.wi.weight"))))
+            dec["wo"].append(N(p + ".2.DenseReluDense.wo.weight", K(g(p + ".2.DenseReluDense.wo.weight"))))
+        self.shared = N("shared.weight", K(g("shared.weight")))
+        self.enc_rel = N("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", K(g("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight")))
+        self.dec_rel = N("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", K(g("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight")))
+        self.enc_fln = N("encoder.final_layer_norm.weight", K(g("encoder.final_layer_norm.weight")))
+        self.dec_fln = N("decoder.final_layer_norm.weight", K(g("decoder.final_layer_norm.weight")))
+        self.start = N("start_token_embed", K(g("start_token_embed").reshape(-1).contiguous()))
         self.in_embeds = K(torch.stack([g(f"list_decoder_embeds.{i}.weight") for i in range(L)], 0).contiguous())
         if shared_embeds:
             self.out_embeds = self.in_embeds
         else:
             self.out_embeds = K(torch.stack([g(f"list_output_embeds.{i}.weight") for i in range(L)], 0).contiguous())
         self.dec_xkv = K(torch.cat(xkv, 0).contiguous())
+        inner = cfg.num_heads * cfg.d_kv
+        for i in range(nd):
+            for j, w in enumerate("kv"):
+                N(f"decoder.block.{i}.layer.1.EncDecAttention.{w}.weight", self.dec_xkv,
+                  slice((2 * i + j) * inner, (2 * i + j + 1) * inner))
+        for i in range(L):
+            N(f"list_decoder_embeds.{i}.weight", self.in_embeds, i)
+            if not shared_embeds:
+                N(f"list_output_embeds.{i}.weight", self.out_embeds, i)
         self._keep = keep
         self._arrays = {}
         d = _lib.ModelDesc()
@@ -257,6 +276,18 @@ class DeviceModel:
                 self.handle = None
         except Exception:
             pass
+
+    def named_device_params(self):
+        """(checkpoint tensor name, packed device tensor, index / slice of it or None) for every tensor of the model."""
+        return list(self._names)
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The model's current device weights under the reference checkpoint's names (after training steps)."""
+        out = {}
+        for name, t, sl in self._names:
+            v = t if sl is None else t[sl]
+            out[name] = v.reshape(1, 1, -1).clone() if name == "start_token_embed" else v.clone()
+        return out
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         dev = self.ctx.device
@@ -424,3 +455,91 @@ def lngknp_forward(model: DeviceModel, input_ids: torch.Tensor, attention_mask: 
                                      losses.data_ptr() if n_prefix else None, pos_scores.data_ptr(), _stream_ptr(dev)),
           "rpr_lngknp_forward")
     return losses, pos_scores
+
+
+# ---- training step of the ranking fine-tune: flat gradient / optimizer buffers -----------------------
+_PARAM_KINDS = ["shared", "enc_rel", "dec_rel", "enc_fln", "dec_fln", "start", "in_emb", "out_emb", "xkv",
+                "enc_ln0", "enc_qkv", "enc_o", "enc_ln1", "enc_wi", "enc_wo",
+                "dec_ln0", "dec_qkv", "dec_o", "dec_ln1", "dec_xq", "dec_xo", "dec_ln2", "dec_wi", "dec_wo"]
+
+
+class TrainState:
+    """Flat fp32 buffers of one model replica: gradients and the two AdamW moments, laid out as ``rpr_param_info``
+    says (the tensors of ``DeviceModel`` in a fixed order). ``grads`` is what data-parallel ranks all-reduce."""
+
+    def __init__(self, model: DeviceModel):
+        self.model = model
+        lib, h = model.ctx.lib, model.handle
+        self.total = int(lib.rpr_param_total(h))
+        n = int(lib.rpr_param_count(h))
+        self.layout = []   # (device pointer, numel, offset)
+        for i in range(n):
+            p, ne, off = C.c_void_p(), C.c_int64(), C.c_int64()
+            check(lib.rpr_param_info(h, i, C.byref(p), C.byref(ne), C.byref(off)), "rpr_param_info")
+            self.layout.append((int(p.value), int(ne.value), int(off.value)))
+        dev = model.ctx.device
+        self.grads = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.step = 0
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference checkpoint's tensor names (q/k/v, the cross k/v and the codebooks un-stacked)."""
+        out = {}
+        by_ptr = {ptr: (ne, off) for ptr, ne, off in self.layout}
+        for name, t, sl in self.model.named_device_params():
+            ne, off = by_ptr[t.data_ptr()]
+            g = self.grads[off:off + ne].view(t.shape)
+            out[name] = g[sl] if sl is not None else g
+        return out
+
+
+def lngknp_backward(model: DeviceModel, state: TrainState, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg,
+                    prefix_lens: Sequence[int]) -> torch.Tensor:
+    """Forward + backward of the sum of the margin-MSE losses (``rpr_lngknp_backward``): fills ``state.grads`` and
+    returns the losses ``[n_prefix]`` (device tensor). Asynchronous on the current stream."""
+    ctx = model.ctx
+    dev = ctx.device
+    ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
+    mask = attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+    codes = doc_codes.to(device=dev, dtype=torch.int32).contiguous()
+    bz, Lq = ids.shape
+    assert codes.shape[0] == bz and codes.shape[1] == 2
+    L = codes.shape[2]
+    n_prefix = len(prefix_lens)
+    tp = teacher_pos.to(device=dev, dtype=torch.float32).contiguous()
+    tn = teacher_neg.to(device=dev, dtype=torch.float32).contiguous()
+    assert tuple(tp.shape) == (n_prefix, bz) and tuple(tn.shape) == (n_prefix, bz)
+    pl = torch.tensor(list(prefix_lens), dtype=torch.int32, device=dev)
+    losses = torch.empty((n_prefix,), dtype=torch.float32, device=dev)
+    check(ctx.lib.rpr_lngknp_backward(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq, codes.data_ptr(), L,
+                                      tp.data_ptr(), tn.data_ptr(), pl.data_ptr(), n_prefix, losses.data_ptr(),
+                                      state.grads.data_ptr(), _stream_ptr(dev)), "rpr_lngknp_backward")
+    return losses
+
+
+def allreduce_grads(state: TrainState, bucket_elems: int = 64 << 20) -> None:
+    """Data-parallel gradient exchange (the reference wraps the model in DDP: an NCCL ring all-reduce of ~0.94 GB fp32
+    per step for t5-base): sum ``state.grads`` over the ranks in a few large chunks and divide by the world size
+    (DDP's gradient averaging). RCCL ("nccl" backend) on GPUs; any torch.distributed backend works. The MI355X xGMI
+    mesh is point-to-point, so few large messages are what RCCL's ring needs: 256 MB chunks by default."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    g = state.grads
+    for s in range(0, g.numel(), bucket_elems):
+        dist.all_reduce(g[s:s + bucket_elems], op=dist.ReduceOp.SUM)
+    g.div_(world)
+
+
+def adamw_step(model: DeviceModel, state: TrainState, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+               weight_decay: float = 0.0, max_grad_norm: float = 1.0) -> None:
+    """``clip_grad_norm_(max_grad_norm)`` + ``torch.optim.AdamW`` on the model's device tensors, in place
+    (``rpr_adamw_step``); ``state.grad_norm`` receives the pre-clip global norm."""
+    ctx = model.ctx
+    state.step += 1
+    check(ctx.lib.rpr_adamw_step(ctx.handle, model.handle, state.grads.data_ptr(), state.exp_avg.data_ptr(),
+                                 state.exp_avg_sq.data_ptr(), state.step, lr, betas[0], betas[1], eps, weight_decay,
+                                 max_grad_norm, state.grad_norm.data_ptr(), _stream_ptr(ctx.device)), "rpr_adamw_step")

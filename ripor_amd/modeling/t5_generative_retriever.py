@@ -272,3 +272,44 @@ class T5SeqAQEncoderForLngKnpMarginMSE(T5SeqAQEncoder):
         return {n: losses[i] for i, n in enumerate(names)}
 
     __call__ = forward
+
+    # ---- training (backward pass + optimizer on the device; reference: HF Trainer around this forward) -----------------
+    def _batch(self, inputs):
+        pos_q, neg_q = inputs["pos_tokenized_query"], inputs["neg_tokenized_query"]
+        pos_codes, neg_codes = inputs["pos_doc_encoding"], inputs["neg_doc_encoding"]
+        L = pos_codes.size(1)
+        if L not in self._PREFIXES:
+            raise ValueError("not valid length: {}".format(L))
+        if not torch.equal(pos_q["input_ids"], neg_q["input_ids"]):
+            raise ValueError("pos_tokenized_query and neg_tokenized_query must carry the same query tokens")
+        names = ["rank" if k == L else f"rank_{k}" for k, _ in self._PREFIXES[L]]
+        tp = torch.stack([inputs[p + "teacher_pos_scores"] for _, p in self._PREFIXES[L]]).float()
+        tn = torch.stack([inputs[p + "teacher_neg_scores"] for _, p in self._PREFIXES[L]]).float()
+        return pos_q, torch.stack([pos_codes, neg_codes], dim=1), tp, tn, [k for k, _ in self._PREFIXES[L]], names
+
+    def train_state(self):
+        from .. import engine as E
+        if getattr(self, "_train_state", None) is None or self._train_state.model is not self.base_model.engine_model():
+            self._train_state = E.TrainState(self.base_model.engine_model())
+        return self._train_state
+
+    def backward(self, **inputs):
+        """loss = sum of the task losses (ln_to_weight 1, reference arguments.py:109-119; tasks/trainer.py:228-240),
+        loss.backward(): fills ``train_state().grads``; returns the task losses like ``forward``."""
+        from .. import engine as E
+        pos_q, codes, tp, tn, prefix_lens, names = self._batch(inputs)
+        losses = E.lngknp_backward(self.base_model.engine_model(), self.train_state(), pos_q["input_ids"],
+                                   pos_q["attention_mask"], codes, tp, tn, prefix_lens)
+        return {n: losses[i] for i, n in enumerate(names)}
+
+    def training_step(self, lr, max_grad_norm=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, **inputs):
+        """One optimisation step as the reference's trainer performs it: backward, gradient all-reduce across the
+        data-parallel ranks (RCCL when torch.distributed is initialised), clip_grad_norm_, AdamW — weights updated in
+        place on the device. Returns the task losses of the batch (before the update)."""
+        from .. import engine as E
+        losses = self.backward(**inputs)
+        st = self.train_state()
+        E.allreduce_grads(st)
+        E.adamw_step(self.base_model.engine_model(), st, lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                     max_grad_norm=max_grad_norm)
+        return losses

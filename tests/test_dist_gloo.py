@@ -173,3 +173,39 @@ def test_bench_launch_command():
     cmd = bench.launch_command(8, {}, ["bench.py", "--gpus", "8", "--steps", "3"])
     assert "--nproc-per-node=8" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+
+
+# ---- data-parallel gradient exchange of the training step (config 5) on two gloo ranks -------------------------------------
+def _grad_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ripor_amd import engine as E
+
+        class _State:   # the flat gradient buffer of a replica (TrainState.grads), on the CPU here
+            pass
+        st = _State()
+        n = 1000
+        st.grads = (torch.arange(n, dtype=torch.float32) + 1.0) * (rank + 1)
+        E.allreduce_grads(st, bucket_elems=256)      # 4 chunks
+        if rank == 0:
+            out.put(st.grads.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = ((torch.arange(1000, dtype=torch.float32) + 1.0) * 1.5).tolist()    # mean of x and 2x
+    assert got == expect
