@@ -164,10 +164,53 @@ def test_training_step_matches_reference_adamw_update():
         off += c
         key = "shared.weight" if n == "encoder.embed_tokens.weight" else n
         d = (after[key] - before[key]).reshape(-1).cpu().numpy()[grad_sample_indices(n, tuple(before[key].shape))]
-        np.testing.assert_allclose(d, ref, atol=3e-2 * lr, rtol=0, err_msg=f"update of {n}")
+        # AdamW's first step moves a weight by lr * g / (|g| + eps): entries whose clipped gradient is of the order of
+        # eps = 1e-8 (a millionth of the tensor's typical entry here) amplify fp32 noise in g to a visible fraction of
+        # lr, so a few sampled entries per tensor may miss the tight bound; none may move by more than lr off.
+        # (an entry whose true gradient is noise-level can even flip sign: up to 2 lr; the arithmetic of the update itself
+        # is checked exactly against the device gradients below)
+        err = np.abs(d - ref)
+        assert (err <= 3e-2 * lr).mean() >= 0.9 and err.max() <= 2.0 * lr * 1.001, f"update of {n}: {err.max() / lr:.3f} lr"
+    # the optimizer arithmetic on the device's own gradients: first AdamW step = -lr * g_c / (|g_c| + eps), g_c = clipped g
+    gn = float(st.grad_norm)
+    clip = min(1.0, 1.0 / (gn + 1e-6))
+    for name, gt in st.named_grads().items():
+        gc = gt.double() * clip
+        expect = (-lr * gc / (gc.abs() + 1e-8)).float()
+        got = (after[name] - before[name]).reshape(expect.shape)
+        # + one ulp of the weight itself (the update of a weight near 1.0 is quantised to 1.2e-7)
+        tol = 2e-3 * lr + 1.3e-7 * before[name].abs().clamp_min(1e-3).reshape(expect.shape)
+        assert ((got - expect).abs() <= tol).all().item(), name
     out = m(**_inputs(g))     # inference forward on the updated weights
     torch.cuda.synchronize()
     for k, v in zip(sorted(g.losses), g.z["losses_after_step"]):
         assert abs(float(out[k]) - v) <= 5e-3 * max(1.0, abs(v)), (k, float(out[k]), v)
     print(f"[train-step] losses {[(k, round(float(losses[k]), 3)) for k in sorted(losses)]} -> "
           f"{[(k, round(float(out[k]), 3)) for k in sorted(out)]} (reference after: {g.z['losses_after_step'].round(3).tolist()})")
+
+
+def test_lngknp_backward_matches_oracle_autograd_at_t5_base_dims():
+    """Full t5-base dims (12 + 12 layers, d_ff 3072, vocab 2048): every gradient tensor of the device backward against
+    autograd through the CPU oracle (itself pinned to the reference's gradients on the mini fixtures,
+    tests/test_oracle_golden.py), whole tensors, max error relative to the tensor's largest entry."""
+    from oracle import t5_ref, train_ref
+    g = TrainGolden("f4_base_bz4_l32")
+    m = _train_model(g)
+    losses = m.backward(**_inputs(g))
+    torch.cuda.synchronize()
+    for k, v in g.losses.items():
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v))
+    hip = {k: v.detach().cpu().double().numpy() for k, v in m.train_state().named_grads().items()}
+    teacher = {k: g.z[k] for k in g.z.files if k.endswith("_scores") and "teacher" in k}
+    torch.set_num_threads(16)
+    _, total, og, gn = train_ref.train_step(t5_ref.T5Ref(g.state_dict, g.dims), g.z["input_ids"], g.z["attention_mask"],
+                                            g.z["pos_doc_encoding"], g.z["neg_doc_encoding"], teacher)
+    worst = (0.0, None)
+    for k, v in hip.items():
+        o = og[k].double().numpy().reshape(v.shape)
+        rel = np.abs(v - o).max() / max(np.abs(o).max(), 1e-30)
+        worst = max(worst, (rel, k))
+        assert rel <= 2e-4, (k, rel)
+    hn = float(np.sqrt(sum((v ** 2).sum() for v in hip.values())))
+    assert abs(hn - gn) <= 1e-4 * gn
+    print(f"[train-bwd] f4_base_bz4_l32 vs oracle autograd: worst tensor error {worst[0]:.2e} ({worst[1]}), global norm {hn:.6g} vs {gn:.6g}")

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Time the ranking fine-tune step (BASELINE config 5 shape on one GPU): t5-base dims, bz examples per step, two
+teacher-forced passes of L = 32 positions over queries of ~16 tokens, backward, AdamW. Prints one JSON line.
+Usage: python tools/train_bench.py [--bz 128] [--steps 5]"""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ripor_amd import engine as E
+from ripor_amd.utils import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bz", type=int, default=128)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--len", type=int, default=32, dest="L")
+args = ap.parse_args()
+L, V, bz = args.L, 256, args.bz
+dims = synth.t5_base_dims(L=L, V=V)
+ctx = E.Context.get(0)
+model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+state = E.TrainState(model)
+ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=5, mean_len=16, std_len=5, min_len=6, max_len=64)
+Lq = (ids.shape[1] + 7) // 8 * 8
+ids = np.pad(ids, ((0, 0), (0, Lq - ids.shape[1]))); mask = np.pad(mask, ((0, 0), (0, Lq - mask.shape[1])))
+codes = synth.make_codes(2 * bz, L, V, seed=5).astype(np.int64).reshape(2, bz, L).transpose(1, 0, 2).copy()
+prefix = [L, 4, 8, 16][: {8: 2, 16: 3, 32: 4}[L]]
+tp = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/p{k}", (bz,), 30.0) for k in prefix]))
+tn = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/n{k}", (bz,), 30.0) for k in prefix]))
+ids_t, mask_t, codes_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(codes).cuda()
+
+
+def step():
+    losses = E.lngknp_backward(model, state, ids_t, mask_t, codes_t, tp, tn, prefix)
+    E.allreduce_grads(state)
+    E.adamw_step(model, state, lr=1e-6)
+    return losses
+
+
+first = step(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    last = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+ctx.profile_reset(); ctx.profile_enable(True)
+E.lngknp_backward(model, state, ids_t, mask_t, codes_t, tp, tn, prefix); torch.cuda.synchronize()
+st = ctx.profile_get(); ctx.profile_enable(False)
+flops_fwd = 2.0 * (bz * float(mask.sum(1).mean()) * (dims.num_layers * (4 * 768 * 768 + 2 * 768 * 3072) + 12 * 2 * 768 * 768)
+                   + bz * 2 * L * 12 * (6 * 768 * 768 + 2 * 768 * 3072))
+print(json.dumps({"task": "lng_knp margin-MSE fine-tune step (forward + backward + AdamW), t5-base dims, fp32 MFMA GEMMs",
+                  "bz": bz, "L": L, "enc_len_padded": int(Lq), "ms_per_step": dt * 1e3, "examples_per_s": bz / dt,
+                  "loss_first": [float(x) for x in first], "loss_last": [float(x) for x in last],
+                  "params": state.total, "approx_tflops": 3 * flops_fwd / dt / 1e12,
+                  "backward_kernel_ms": {k: round(v["total_ms"], 3) for k, v in st.items()}}))
