@@ -22,3 +22,10 @@ rows.sort(reverse=True)
 for r in rows[:12]:
     print("rel %.2e  %-60s max|ref| %.3e  max|err| %.3e" % r)
 print("median rel err %.2e" % np.median([r[0] for r in rows]))
+k = rows[0][1]
+v, o = hip[k], og[k].double().numpy().reshape(hip[k].shape)
+if v.ndim == 2:
+    e = np.abs(v - o)
+    r = e.max(axis=1)
+    top = np.argsort(-r)[:5]
+    print("worst tensor", k, "rows by max error:", [(int(i), float(r[i])) for i in top], " median row error", float(np.median(r)))
