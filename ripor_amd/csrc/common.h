@@ -44,6 +44,19 @@ __device__ __forceinline__ void split_f16(float x, __half& hi, __half& lo, unsig
   lo = __float2half_rn(x - __half2float(hi));
 }
 
+// Per-tensor dynamic plane scale (training GEMMs: activations and gradients of unknown magnitude): the power of two s
+// with amax * s in [2^13, 2^14) — below the f16 maximum with headroom, and far enough above the f16 subnormals that
+// entries down to ~2^-17 of the largest one keep their lo plane normal. amax = 0 / non-finite: 1.
+__host__ __device__ __forceinline__ float dyn_plane_scale(float amax) {
+  union { float f; int i; } u; u.f = amax;
+  const int e = (u.i >> 23) & 0xff;
+  if (e == 0 || e == 255) return 1.0f;
+  int be = 127 + 13 - (e - 127);
+  be = be > 254 ? 254 : (be < 1 ? 1 : be);
+  u.i = be << 23;
+  return u.f;
+}
+
 // Row sum of squares in fixed point (2^-20 units, int64): partial sums from different blocks are combined with
 // integer atomics, so the total does not depend on the order of arrival (bitwise-reproducible RMSNorm scale).
 constexpr float SSQ_FIX = 1048576.0f;
@@ -93,6 +106,9 @@ struct GemmH2Args {
   const unsigned long long* row_ssq; float inv_d_fix, eps;
   const __half* resid_h; size_t r_ps; int ldrh; unsigned long long* ssq_out;
   unsigned int* sat;                       // sticky saturation word of the ctx (split_f16)
+  // dynamic plane scales (training GEMMs): device-side absolute maxima of A and B; when non-null the accumulators are
+  // multiplied by 1 / (dyn_plane_scale(*dyn_a) * dyn_plane_scale(*dyn_b)) instead of acc_scale
+  const float* dyn_a; const float* dyn_b;
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 
@@ -254,6 +270,13 @@ hipError_t launch_margin_mse(const float* scores, const float* teacher_pos, cons
                              int n_prefix, int bz, int L, float* losses, float* margins, hipStream_t s);
 // ---- backward pass + optimizer of the same step (train_kernels.hip) ------------------------------------------------
 hipError_t init_train_kernel_attributes();
+// absolute maximum of a tensor -> *out (two deterministic stages, part: >= 256 floats of scratch)
+hipError_t launch_absmax(const float* x, size_t n, float* part, float* out, hipStream_t s);
+// fp32 [R, C] (row stride ldi) -> f16 hi/lo planes scaled by dyn_plane_scale(*amax):
+//   plain:      out[2][R][C]            (plane stride R*C)
+//   transposed: out[2][C][Rpad]         (plane stride C*Rpad, columns r >= R zero)
+hipError_t launch_split_dyn(const float* x, int R, int C, int ldi, __half* out, const float* amax, hipStream_t s);
+hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out, const float* amax, hipStream_t s);
 hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
 hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,

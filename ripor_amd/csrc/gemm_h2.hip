@@ -50,6 +50,7 @@ constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 template <int BM, int BN, int WM, int WN, bool FULL, int STAGES = 2>
 __global__ __launch_bounds__(64 * WM * WN, STAGES > 2 ? 1 : (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
 void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
   constexpr int NW = WM * WN;                    // waves per block
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA 32x32 tiles per wave
   constexpr int ROWS = 2 * (BM + BN);            // LDS rows of 32 halves (64 B) per buffer
@@ -375,6 +376,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // last reads are retired before the other group starts overwriting it.
 template <bool FULL, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
   constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 // accumulators are added in the fixed order 0..3 through LDS and wave 0 runs the epilogue — deterministic.
 template <bool FULL>
 __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
   constexpr int BM = 32, BN = 32, ST = 4, ROWS = 2 * (BM + BN), PIECES = ROWS / 16;   // 8 KB per stage, 8 pieces
   __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];             // 128 KB
   const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;

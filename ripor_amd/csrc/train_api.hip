@@ -5,10 +5,11 @@
 //   rpr_adamw_step       = clip_grad_norm_ + torch.optim.AdamW as HF Trainer configures them for main.py:131-155,
 //   rpr_param_*          = the layout of the flat buffers (so the host can all-reduce them over RCCL and map them back
 //                          to the checkpoint's tensor names).
-// Arithmetic: fp32 activations and gradients, every matrix product on the exact-fp32 MFMA GEMM kernel
-// (gemm_f32.hip, v_mfma_f32_32x32x2_f32) — gradients span ten orders of magnitude, which the f16 planes of the search
-// path's split-precision GEMM cannot carry without per-tensor scales; the reference trains under bf16 autocast, so fp32
-// is the more precise side. The backward products reuse the forward kernel on explicitly transposed operands
+// Arithmetic: fp32 activations and gradients. Matrix products: the search path's split-precision GEMM (f16 hi/lo planes,
+// 3 f16 MFMAs per product, fp32 accumulation) with PER-TENSOR dynamic plane scales — gradients span ten orders of
+// magnitude, so every operand's absolute maximum is found on the device and a power of two brings it to [2^13, 2^14)
+// before the split; in RPR_PREC_F32 mode the exact-fp32 MFMA kernel (gemm_f32.hip). The reference trains under bf16
+// autocast: both are the more precise side. The backward products reuse the forward kernels on transposed operands
 // (train_kernels.hip); the reductions are deterministic (fixed-order partials, fixed-point integer atomics).
 #include <cmath>
 #include <cstring>
@@ -21,7 +22,7 @@ struct TrainWs {
   // saved forward activations
   DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
   // scratch
-  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, wT, w_part, bias_part, fix, gn_part, gn_out;
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, wT, w_part, bias_part, fix, gn_part, gn_out, amax;
   size_t bytes = 0;
 };
 
@@ -84,9 +85,37 @@ struct Dims {
   size_t enc_stride, dec_stride;   // floats per saved layer
 };
 
-// C[M, N] = act(A[M, K] B[N, K]^T) (+ resid), exact fp32 MFMA
+// Split-precision training GEMM: both operands are fp32 tensors of unknown magnitude (activations, gradients, weights
+// that change every step), so each gets a per-tensor power-of-two scale from its absolute maximum, found on the device
+// (no host round trip) and undone in the epilogue. pa / pb: plane scratch; amax: [2 + 512] floats.
+struct Planes { __half* p; size_t ps; int ld; };
+void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, const float* amax, float* C, int ldc, int M, int N, int K,
+                 const float* resid, int relu) {
+  GemmH2Args g{};
+  g.A = A.p; g.a_ps = A.ps; g.lda = A.ld; g.W = B.p; g.w_ps = B.ps; g.ldw = B.ld;
+  g.resid = resid; g.ldr = ldc;
+  g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
+  g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.sat = Ln.c->status;
+  g.dyn_a = amax; g.dyn_b = amax + 1;
+  Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm_h2(g, Ln.s); },
+         &g.kernel_cls);
+}
+
+// C[M, N] = act(A[M, K] B[N, K]^T) (+ resid): exact fp32 MFMA, or (split-precision mode) f16x2 planes with dynamic scales
 void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
           const float* resid = nullptr, int relu = 0) {
+  if (Ln.c->precision == RPR_PREC_F16X2) {
+    TrainWs& w = *Ln.c->tws;
+    float* am = P<float>(w.amax);
+    __half *pa = P<__half>(w.tA), *pb = P<__half>(w.wT);
+    hipStream_t s = Ln.s;
+    Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax(A, (size_t)M * K, am + 2, am, s); });      // lda == K for every caller
+    Ln.run(RPR_K_OTHER, 0, 4.0 * N * K, [&] { return launch_absmax(B, (size_t)N * K, am + 258, am + 1, s); });
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn(A, M, K, lda, pa, am, s); });
+    Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn(B, N, K, ldb, pb, am + 1, s); });
+    gemm_planes(Ln, {pa, (size_t)M * K, K}, {pb, (size_t)N * K, K}, am, C, ldc, M, N, K, resid, relu);
+    return;
+  }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = B; g.ldw = ldb; g.resid = resid; g.ldr = ldc;
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
@@ -98,12 +127,34 @@ struct Bwd {
   Launcher& Ln; rpr_ctx* c; TrainWs& w; const Dims& D;
   // dX[M, K] = dY[M, N] W[N, K]
   void dx(const float* dY, const float* W, float* dX, int M, int N, int K) {
+    if (c->precision == RPR_PREC_F16X2) {   // transposed planes of W straight from the fp32 weight
+      float* am = P<float>(w.amax);
+      __half *pa = P<__half>(w.tA), *pb = P<__half>(w.wT);
+      hipStream_t s = Ln.s;
+      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N, [&] { return launch_absmax(dY, (size_t)M * N, am + 2, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 4.0 * N * K, [&] { return launch_absmax(W, (size_t)N * K, am + 258, am + 1, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_split_dyn(dY, M, N, N, pa, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pb, am + 1, s); });
+      gemm_planes(Ln, {pa, (size_t)M * N, N}, {pb, (size_t)K * N, N}, am, dX, K, M, K, N, nullptr, 0);
+      return;
+    }
     Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_transpose_pad(W, P<float>(w.wT), N, K, K, N, Ln.s); });
     gemm(Ln, dY, N, P<float>(w.wT), N, dX, K, M, K, N);
   }
   // dW[N, K] (+)= dY[M, N]^T X[M, K]
   void dw(const float* dY, const float* X, float* dW, int M, int N, int K, bool accumulate = false) {
     const int Mp = pad32(M);
+    if (c->precision == RPR_PREC_F16X2) {
+      float* am = P<float>(w.amax);
+      __half *pa = P<__half>(w.tA), *pb = P<__half>(w.tB);
+      hipStream_t s = Ln.s;
+      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N, [&] { return launch_absmax(dY, (size_t)M * N, am + 2, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax(X, (size_t)M * K, am + 258, am + 1, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_split_dyn_T(dY, M, N, N, Mp, pa, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pb, am + 1, s); });
+      gemm_planes(Ln, {pa, (size_t)N * Mp, Mp}, {pb, (size_t)K * Mp, Mp}, am, dW, K, N, K, Mp, accumulate ? dW : nullptr, 0);
+      return;
+    }
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, Ln.s); });
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB), M, K, K, Mp, Ln.s); });
     gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB), Mp, dW, K, N, K, Mp, accumulate ? dW : nullptr);
@@ -139,7 +190,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
-  E(w.gn_part, 1024 * 8); E(w.gn_out, 16);
+  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, 1024 * f);
   return e;
 }
 
@@ -323,7 +374,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c->tws;
   c->tws = nullptr;

@@ -4,6 +4,8 @@
 // projection GEMMs, the block attention kernels (causal variant of enc_attn_kernel; cross-attention with the 2L rows
 // of a query as its "beams") and the fused RMSNorm of the search path. What is specific to training lives here:
 // the teacher-forced input embeddings, the gold-code scores and the margin-MSE losses.
+#include <algorithm>
+
 #include "common.h"
 
 namespace rpr {
@@ -631,6 +633,89 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, clip, lr, b1, b2, eps, wd, bc1,
                      bc2_sqrt);
+  return hipGetLastError();
+}
+
+// ---- per-tensor dynamic f16 planes for the training GEMMs ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      a = fmaxf(fmaxf(a, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    } else {
+      for (size_t j = i; j < n; ++j) a = fmaxf(a, fabsf(x[j]));
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[256];
+  red[threadIdx.x] = threadIdx.x < n ? part[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) *out = red[0];
+}
+hipError_t launch_absmax(const float* x, size_t n, float* part, float* out, hipStream_t s) {
+  const int nb = (int)std::min<size_t>(256, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(absmax_part_kernel, dim3(nb), dim3(256), 0, s, x, n, part);
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, s, part, nb, out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void split_dyn_kernel(const float* __restrict__ x, int R, int C, int ldi, __half* __restrict__ out,
+                                                         const float* __restrict__ amax) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;          // float4 index over R * C / 4
+  const int c4n = C >> 2;
+  if (i4 >= (size_t)R * c4n) return;
+  const int r = (int)(i4 / c4n), c = (int)(i4 - (size_t)r * c4n) * 4;
+  const float sc = dyn_plane_scale(*amax);
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldi + c);
+  __half h[4], l[4];
+  split_f16(v.x * sc, h[0], l[0]); split_f16(v.y * sc, h[1], l[1]); split_f16(v.z * sc, h[2], l[2]); split_f16(v.w * sc, h[3], l[3]);
+  const size_t o = (size_t)r * C + c;
+  *reinterpret_cast<uint2*>(out + o) = *reinterpret_cast<uint2*>(h);
+  *reinterpret_cast<uint2*>(out + (size_t)R * C + o) = *reinterpret_cast<uint2*>(l);
+}
+hipError_t launch_split_dyn(const float* x, int R, int C, int ldi, __half* out, const float* amax, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  if (C & 3) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)R * (C >> 2);
+  hipLaunchKernelGGL(split_dyn_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, R, C, ldi, out, amax);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void split_dyn_T_kernel(const float* __restrict__ x, int R, int C, int ldi, int Rpad,
+                                                           __half* __restrict__ out, const float* __restrict__ amax) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float sc = dyn_plane_scale(*amax);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? x[(size_t)r * ldi + c] * sc : 0.f;
+  }
+  __syncthreads();
+  const size_t ps = (size_t)C * Rpad;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < Rpad) {
+      __half hi, lo;
+      split_f16(tile[tx][ty + 8 * k], hi, lo);
+      out[(size_t)c * Rpad + r] = hi;
+      out[ps + (size_t)c * Rpad + r] = lo;
+    }
+  }
+}
+hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out, const float* amax, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_dyn_T_kernel, dim3((C + 31) / 32, (Rpad + 31) / 32), dim3(256), 0, s, x, R, C, ldi, Rpad, out, amax);
   return hipGetLastError();
 }
 

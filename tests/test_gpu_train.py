@@ -116,14 +116,26 @@ def _train_model(g):
     return m
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
 @pytest.mark.parametrize("name", [n for n in train_golden_names() if "mini" in n])
-def test_lngknp_backward_matches_reference_gradients(name):
+def test_lngknp_backward_matches_reference_gradients(name, precision):
     """rpr_lngknp_backward vs loss.backward() of the imported reference (tests/golden/make_golden.py): Frobenius norm and
-    48 seeded sample entries of every one of the 241 gradient tensors, the global norm, the total loss."""
+    48 seeded sample entries of every one of the 241 gradient tensors, the global norm, the total loss — with the
+    matrix products on the split-precision kernel (per-tensor dynamic plane scales) and on the exact fp32 kernel."""
     from test_oracle_golden import check_grads_against_fixture
     g = TrainGolden(name)
     assert "grad_names" in g.z.files
     m = _train_model(g)
+    from ripor_amd import engine as E
+    ctx = E.Context.get(0)
+    ctx.set_precision(precision)
+    try:
+        _backward_checks(g, m, name, precision, check_grads_against_fixture)
+    finally:
+        ctx.set_precision("f16x2")
+
+
+def _backward_checks(g, m, name, precision, check_grads_against_fixture):
     losses = m.backward(**_inputs(g))
     torch.cuda.synchronize()
     total = sum(float(v) for v in losses.values())
@@ -133,7 +145,7 @@ def test_lngknp_backward_matches_reference_gradients(name):
     worst = check_grads_against_fixture(g, grads, rel=1e-3, label=" (HIP)")
     gnorm = float(torch.sqrt((st.grads.double() ** 2).sum()))
     assert abs(gnorm - float(g.z["grad_global_norm"])) <= 1e-3 * gnorm
-    print(f"[train-bwd] {name}: worst sampled-gradient error {worst[0]:.2e} of scale ({worst[1]}), global norm {gnorm:.6g}")
+    print(f"[train-bwd] {name} {precision}: worst sampled-gradient error {worst[0]:.2e} of scale ({worst[1]}), global norm {gnorm:.6g}")
     # deterministic: a second backward gives the same bits
     first = st.grads.clone()
     m.backward(**_inputs(g))

@@ -12,10 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bz", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--len", type=int, default=32, dest="L")
+ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"])
 args = ap.parse_args()
 L, V, bz = args.L, 256, args.bz
 dims = synth.t5_base_dims(L=L, V=V)
 ctx = E.Context.get(0)
+ctx.set_precision(args.precision)
 model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
 state = E.TrainState(model)
 ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=5, mean_len=16, std_len=5, min_len=6, max_len=64)
@@ -46,7 +48,7 @@ E.lngknp_backward(model, state, ids_t, mask_t, codes_t, tp, tn, prefix); torch.c
 st = ctx.profile_get(); ctx.profile_enable(False)
 flops_fwd = 2.0 * (bz * float(mask.sum(1).mean()) * (dims.num_layers * (4 * 768 * 768 + 2 * 768 * 3072) + 12 * 2 * 768 * 768)
                    + bz * 2 * L * 12 * (6 * 768 * 768 + 2 * 768 * 3072))
-print(json.dumps({"task": "lng_knp margin-MSE fine-tune step (forward + backward + AdamW), t5-base dims, fp32 MFMA GEMMs",
+print(json.dumps({"task": "lng_knp margin-MSE fine-tune step (forward + backward + AdamW), t5-base dims", "gemm_precision": args.precision,
                   "bz": bz, "L": L, "enc_len_padded": int(Lq), "ms_per_step": dt * 1e3, "examples_per_s": bz / dt,
                   "loss_first": [float(x) for x in first], "loss_last": [float(x) for x in last],
                   "params": state.total, "approx_tflops": 3 * flops_fwd / dt / 1e12,
