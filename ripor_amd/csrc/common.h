@@ -270,13 +270,14 @@ hipError_t launch_margin_mse(const float* scores, const float* teacher_pos, cons
                              int n_prefix, int bz, int L, float* losses, float* margins, hipStream_t s);
 // ---- backward pass + optimizer of the same step (train_kernels.hip) ------------------------------------------------
 hipError_t init_train_kernel_attributes();
-// absolute maximum of a tensor -> *out (two deterministic stages, part: >= 256 floats of scratch)
-hipError_t launch_absmax(const float* x, size_t n, float* part, float* out, hipStream_t s);
+// absolute maxima of one or two tensors -> out[0], out[1] by integer atomicMax: the slots must be zero beforehand
+hipError_t launch_absmax2(const float* x0, size_t n0, const float* x1, size_t n1, float* out, hipStream_t s);
 // fp32 [R, C] (row stride ldi) -> f16 hi/lo planes scaled by dyn_plane_scale(*amax):
 //   plain:      out[2][R][C]            (plane stride R*C)
-//   transposed: out[2][C][Rpad]         (plane stride C*Rpad, columns r >= R zero)
+//   transposed: out_t[2][C][Rpad]       (plane stride C*Rpad, columns r >= R zero), optionally the plain planes as well
 hipError_t launch_split_dyn(const float* x, int R, int C, int ldi, __half* out, const float* amax, hipStream_t s);
-hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out, const float* amax, hipStream_t s);
+hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out_t, __half* out_plain, const float* amax,
+                              hipStream_t s);
 hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
 hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,

@@ -22,7 +22,8 @@ struct TrainWs {
   // saved forward activations
   DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
   // scratch
-  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, wT, w_part, bias_part, fix, gn_part, gn_out, amax;
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax;
+  int amax_next = 0;
   size_t bytes = 0;
 };
 
@@ -87,16 +88,28 @@ struct Dims {
 
 // Split-precision training GEMM: both operands are fp32 tensors of unknown magnitude (activations, gradients, weights
 // that change every step), so each gets a per-tensor power-of-two scale from its absolute maximum, found on the device
-// (no host round trip) and undone in the epilogue. pa / pb: plane scratch; amax: [2 + 512] floats.
-struct Planes { __half* p; size_t ps; int ld; };
-void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, const float* amax, float* C, int ldc, int M, int N, int K,
-                 const float* resid, int relu) {
+// (no host round trip; slots of a ring that is zeroed once per pass) and undone in the GEMM epilogue.
+struct Planes { __half* p; size_t ps; int ld; const float* amax; };
+constexpr int AMAX_SLOTS = 8192;
+float* amax_slots(rpr_ctx* c, int n) {          // n fresh (zero) slots
+  TrainWs& w = *c->tws;
+  if (w.amax_next + n > AMAX_SLOTS) return nullptr;
+  float* p = P<float>(w.amax) + w.amax_next;
+  w.amax_next += n;
+  return p;
+}
+void amax_reset(Launcher& Ln) {
+  TrainWs& w = *Ln.c->tws;
+  w.amax_next = 0;
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.amax), AMAX_SLOTS / 2, Ln.s); });
+}
+void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int ldc, int M, int N, int K, const float* resid, int relu) {
   GemmH2Args g{};
   g.A = A.p; g.a_ps = A.ps; g.lda = A.ld; g.W = B.p; g.w_ps = B.ps; g.ldw = B.ld;
   g.resid = resid; g.ldr = ldc;
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.sat = Ln.c->status;
-  g.dyn_a = amax; g.dyn_b = amax + 1;
+  g.dyn_a = A.amax; g.dyn_b = B.amax;
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm_h2(g, Ln.s); },
          &g.kernel_cls);
 }
@@ -106,14 +119,14 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
           const float* resid = nullptr, int relu = 0) {
   if (Ln.c->precision == RPR_PREC_F16X2) {
     TrainWs& w = *Ln.c->tws;
-    float* am = P<float>(w.amax);
+    float* am = amax_slots(Ln.c, 2);
+    if (!am || lda != K || ldb != K) { Ln.err = RPR_ERR_INVALID; return; }
     __half *pa = P<__half>(w.tA), *pb = P<__half>(w.wT);
     hipStream_t s = Ln.s;
-    Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax(A, (size_t)M * K, am + 2, am, s); });      // lda == K for every caller
-    Ln.run(RPR_K_OTHER, 0, 4.0 * N * K, [&] { return launch_absmax(B, (size_t)N * K, am + 258, am + 1, s); });
+    Ln.run(RPR_K_OTHER, 0, 4.0 * (M + N) * K, [&] { return launch_absmax2(A, (size_t)M * K, B, (size_t)N * K, am, s); });
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn(A, M, K, lda, pa, am, s); });
     Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn(B, N, K, ldb, pb, am + 1, s); });
-    gemm_planes(Ln, {pa, (size_t)M * K, K}, {pb, (size_t)N * K, K}, am, C, ldc, M, N, K, resid, relu);
+    gemm_planes(Ln, {pa, (size_t)M * K, K, am}, {pb, (size_t)N * K, K, am + 1}, C, ldc, M, N, K, resid, relu);
     return;
   }
   GemmArgs g{};
@@ -125,39 +138,30 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
 
 struct Bwd {
   Launcher& Ln; rpr_ctx* c; TrainWs& w; const Dims& D;
-  // dX[M, K] = dY[M, N] W[N, K]
-  void dx(const float* dY, const float* W, float* dX, int M, int N, int K) {
-    if (c->precision == RPR_PREC_F16X2) {   // transposed planes of W straight from the fp32 weight
-      float* am = P<float>(w.amax);
-      __half *pa = P<__half>(w.tA), *pb = P<__half>(w.wT);
-      hipStream_t s = Ln.s;
-      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N, [&] { return launch_absmax(dY, (size_t)M * N, am + 2, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 4.0 * N * K, [&] { return launch_absmax(W, (size_t)N * K, am + 258, am + 1, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_split_dyn(dY, M, N, N, pa, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pb, am + 1, s); });
-      gemm_planes(Ln, {pa, (size_t)M * N, N}, {pb, (size_t)K * N, N}, am, dX, K, M, K, N, nullptr, 0);
-      return;
-    }
-    Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_transpose_pad(W, P<float>(w.wT), N, K, K, N, Ln.s); });
-    gemm(Ln, dY, N, P<float>(w.wT), N, dX, K, M, K, N);
-  }
-  // dW[N, K] (+)= dY[M, N]^T X[M, K]
-  void dw(const float* dY, const float* X, float* dW, int M, int N, int K, bool accumulate = false) {
+  // dX[M, K] = dY[M, N] W[N, K]  and  dW[N, K] = dY[M, N]^T X[M, K]  (dX may alias X: X is consumed first)
+  void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K) {
     const int Mp = pad32(M);
+    hipStream_t s = Ln.s;
     if (c->precision == RPR_PREC_F16X2) {
-      float* am = P<float>(w.amax);
-      __half *pa = P<__half>(w.tA), *pb = P<__half>(w.tB);
-      hipStream_t s = Ln.s;
-      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N, [&] { return launch_absmax(dY, (size_t)M * N, am + 2, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax(X, (size_t)M * K, am + 258, am + 1, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_split_dyn_T(dY, M, N, N, Mp, pa, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pb, am + 1, s); });
-      gemm_planes(Ln, {pa, (size_t)N * Mp, Mp}, {pb, (size_t)K * Mp, Mp}, am, dW, K, N, K, Mp, accumulate ? dW : nullptr, 0);
+      // one read of dY gives its plain planes (for dX) and its transposed planes (for dW); W is transposed straight
+      // from the fp32 weight
+      float* am = amax_slots(c, 4);
+      if (!am) { Ln.err = RPR_ERR_INVALID; return; }
+      __half *py = P<__half>(w.tA), *pyt = P<__half>(w.tC), *pxt = P<__half>(w.tB), *pwt = P<__half>(w.wT);
+      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N + 4.0 * N * K, [&] { return launch_absmax2(dY, (size_t)M * N, W, (size_t)N * K, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax2(X, (size_t)M * K, nullptr, 0, am + 2, s); });
+      Ln.run(RPR_K_OTHER, 0, 12.0 * M * N, [&] { return launch_split_dyn_T(dY, M, N, N, Mp, pyt, py, am, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pxt, nullptr, am + 2, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pwt, nullptr, am + 1, s); });
+      gemm_planes(Ln, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am + 2}, dW, K, N, K, Mp, nullptr, 0);
+      gemm_planes(Ln, {py, (size_t)M * N, N, am}, {pwt, (size_t)K * N, N, am + 1}, dX, K, M, K, N, nullptr, 0);
       return;
     }
-    Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, Ln.s); });
-    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB), M, K, K, Mp, Ln.s); });
-    gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB), Mp, dW, K, N, K, Mp, accumulate ? dW : nullptr);
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, s); });
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB), M, K, K, Mp, s); });
+    gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB), Mp, dW, K, N, K, Mp);
+    Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_transpose_pad(W, P<float>(w.wT), N, K, K, N, s); });
+    gemm(Ln, dY, N, P<float>(w.wT), N, dX, K, M, K, N);
   }
   void norm(const float* x, const float* ln, int rows, float post = 1.0f) {   // recompute the normalised input into w.h
     Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * D.dm, [&] { return launch_rmsnorm(x, ln, P<float>(w.h), rows, D.dm, D.eps, Ln.s, post); });
@@ -185,12 +189,12 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.in_idx, R * 4); E(w.out_idx, R * 4); E(w.tok_idx, T * 4);
   E(w.h, rows * dm * f); E(w.dxa, rows * dm * f); E(w.dxb, rows * dm * f); E(w.dbig, rows * wide * f);
   E(w.dattn, rows * inner * f); E(w.dxkv, T * (size_t)D.xld * f); E(w.denc, T * dm * f);
-  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f);
+  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f); E(w.tC, wide * rp * f);
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
-  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, 1024 * f);
+  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f);
   return e;
 }
 
@@ -293,17 +297,14 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   for (int i = D.nd - 1; i >= 0; --i) {
     DecAct a = dec_act(w, D, i);
     // feed-forward: x3 = x2 + relu(norm(x2) Wi^T) Wo^T
-    B.dx(dx, m->dec_wo[i], dbig, R, dm, dff);
-    B.dw(dx, a.ff, g(K_DEC_WO, i), R, dm, dff);
+    B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff);
     Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
     B.norm(a.x2, m->dec_ln2[i], R);
-    B.dw(dbig, h, g(K_DEC_WI, i), R, dff, dm);
-    B.dx(dbig, m->dec_wi[i], h, R, dff, dm);                       // dh into the (now free) h buffer
+    B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm);                       // dh into the (now free) h buffer
     B.norm_bwd(a.x2, m->dec_ln2[i], h, dx, dx2, g(K_DEC_LN2, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x2
     // cross-attention: x2 = x1 + CrossAttn(norm(x1) Wq^T, Kx, Vx) Wo^T
-    B.dx(dx, m->dec_xo[i], dattn, R, dm, inner);
-    B.dw(dx, a.a1, g(K_DEC_XO, i), R, dm, inner);
+    B.dxdw(dx, m->dec_xo[i], a.a1, dattn, g(K_DEC_XO, i), R, dm, inner);
     {
       const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
       float* dxk = P<float>(w.dxkv) + (size_t)i * 2 * inner;
@@ -312,20 +313,17 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
       });
     }
     B.norm(a.x1, m->dec_ln1[i], R);
-    B.dw(dbig, h, g(K_DEC_XQ, i), R, inner, dm);
-    B.dx(dbig, m->dec_xq[i], h, R, inner, dm);
+    B.dxdw(dbig, m->dec_xq[i], h, h, g(K_DEC_XQ, i), R, inner, dm);
     B.norm_bwd(a.x1, m->dec_ln1[i], h, dx, dx2, g(K_DEC_LN1, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x1
     // self-attention: x1 = x0 + SelfAttn(norm(x0) Wqkv^T) Wo^T
-    B.dx(dx, m->dec_o[i], dattn, R, dm, inner);
-    B.dw(dx, a.a0, g(K_DEC_O, i), R, dm, inner);
+    B.dxdw(dx, m->dec_o[i], a.a0, dattn, g(K_DEC_O, i), R, dm, inner);
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
       return launch_self_attn_bwd(a.qkv, dattn, nullptr, d.dec_rel_bias, m->dec_bucket, dbig, P<float>(w.bias_part), g(K_DEC_REL), D.S,
                                   D.L, H, d.rel_buckets, 1, s);
     });
     B.norm(a.x0, m->dec_ln0[i], R);
-    B.dw(dbig, h, g(K_DEC_QKV, i), R, 3 * inner, dm);
-    B.dx(dbig, m->dec_qkv[i], h, R, 3 * inner, dm);
+    B.dxdw(dbig, m->dec_qkv[i], h, h, g(K_DEC_QKV, i), R, 3 * inner, dm);
     B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
   }
@@ -335,30 +333,25 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_sum_selected_rows(dx, P<int32_t>(w.in_idx), g(K_START), R, dm, s); });
   // ---- cross K/V projection and the encoder's final norm
   float* denc = P<float>(w.denc);
-  B.dx(P<float>(w.dxkv), d.dec_xkv, denc, T, D.xld, dm);
-  B.dw(P<float>(w.dxkv), P<float>(w.enc_out), g(K_XKV), T, D.xld, dm);
+  B.dxdw(P<float>(w.dxkv), d.dec_xkv, P<float>(w.enc_out), denc, g(K_XKV), T, D.xld, dm);
   float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
   B.norm_bwd(xe_last, d.enc_final_ln, denc, nullptr, dxa, g(K_ENC_FLN), T);
   dx = dxa; dx2 = dxb;
   for (int i = D.ne - 1; i >= 0; --i) {
     EncAct a = enc_act(w, D, i);
-    B.dx(dx, m->enc_wo[i], dbig, T, dm, dff);
-    B.dw(dx, a.ff, g(K_ENC_WO, i), T, dm, dff);
+    B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff);
     Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
     B.norm(a.xm, m->enc_ln1[i], T);
-    B.dw(dbig, h, g(K_ENC_WI, i), T, dff, dm);
-    B.dx(dbig, m->enc_wi[i], h, T, dff, dm);
+    B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm);
     B.norm_bwd(a.xm, m->enc_ln1[i], h, dx, dx2, g(K_ENC_LN1, i), T);
     std::swap(dx, dx2);
-    B.dx(dx, m->enc_o[i], dattn, T, dm, inner);
-    B.dw(dx, a.attn, g(K_ENC_O, i), T, dm, inner);
+    B.dxdw(dx, m->enc_o[i], a.attn, dattn, g(K_ENC_O, i), T, dm, inner);
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
       return launch_self_attn_bwd(a.qkv, dattn, mask, d.enc_rel_bias, m->enc_bucket, dbig, P<float>(w.bias_part), g(K_ENC_REL), D.bz,
                                   D.Lq, H, d.rel_buckets, 0, s);
     });
     B.norm(a.x, m->enc_ln0[i], T);
-    B.dw(dbig, h, g(K_ENC_QKV, i), T, 3 * inner, dm);
-    B.dx(dbig, m->enc_qkv[i], h, T, 3 * inner, dm);
+    B.dxdw(dbig, m->enc_qkv[i], h, h, g(K_ENC_QKV, i), T, 3 * inner, dm);
     B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
     std::swap(dx, dx2);
   }
@@ -374,7 +367,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c->tws;
   c->tws = nullptr;
@@ -425,6 +418,7 @@ int rpr_lngknp_backward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, cons
   RPR_HIP(hipMemsetAsync(flat_grads, 0, m->params_total * sizeof(float), s));
   RPR_HIP(hipMemsetAsync(w.fix.p, 0, w.fix.cap, s));
   Launcher Ln{c, s};
+  amax_reset(Ln);
   forward(Ln, c, m, D, input_ids, attention_mask, doc_codes, P<int32_t>(c->ws.last));
   if (Ln.err) return Ln.err;
   RPR_HIP(launch_margin_mse(P<float>(w.scores), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, out_losses, P<float>(w.margins), s));

@@ -285,6 +285,91 @@ hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, c
 // Self-attention (encoder: bidirectional buckets + key padding mask; decoder, teacher-forced: causal, unidirectional
 // buckets). qkv: [S*Ls, 3*inner]; dO: [S*Ls, inner]; outputs dqkv [S*Ls, 3*inner] and this block's part of the
 // relative-bias gradient dbias_part[(s * H + h)][buckets]. Recomputes P from q, k (nothing but q, k, v was saved).
+// ---- attention backward: shared pieces ----------------------------------------------------------------------------------
+// LDS rows of Q / K / V / dO are padded to AST = 65 floats: the score phase reads K[j][d] with j across the lanes, and an
+// unpadded 64-float stride would put all of them on one bank.
+constexpr int AST = DKV + 1;
+
+__device__ __forceinline__ void stage_row4(float* dst, const float* src) {
+  const float4 v = *reinterpret_cast<const float4*>(src);
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+
+// Ps[i][j] = score (or -inf where !ok), Gs[i][j] = dP = dO_i . V_j, 2 x 2 outputs per thread (half the LDS reads per FMA)
+template <class OK, class BIAS>
+__device__ __forceinline__ void attn_scores_dp(const float* Qs, const float* Ds, const float* Ks, const float* Vs, int nq, int nk,
+                                               float* Ps, float* Gs, int PL, OK ok, BIAS bias) {
+  const int hq = (nq + 1) >> 1, hk = (nk + 1) >> 1;
+  for (int p = threadIdx.x; p < hq * hk; p += 256) {
+    const int ti = p / hk, tj = p - ti * hk;
+    const int i0 = ti, i1 = ti + hq, j0 = tj, j1 = tj + hk;
+    const bool vi1 = i1 < nq, vj1 = j1 < nk;
+    const float *q0 = Qs + i0 * AST, *q1 = Qs + (vi1 ? i1 : i0) * AST, *o0 = Ds + i0 * AST, *o1 = Ds + (vi1 ? i1 : i0) * AST;
+    const float *k0 = Ks + j0 * AST, *k1 = Ks + (vj1 ? j1 : j0) * AST, *v0 = Vs + j0 * AST, *v1 = Vs + (vj1 ? j1 : j0) * AST;
+    float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f, g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < DKV; ++d) {
+      const float a0 = q0[d], a1 = q1[d], b0 = k0[d], b1 = k1[d], c0 = o0[d], c1 = o1[d], e0 = v0[d], e1 = v1[d];
+      s00 = fmaf(a0, b0, s00); s01 = fmaf(a0, b1, s01); s10 = fmaf(a1, b0, s10); s11 = fmaf(a1, b1, s11);
+      g00 = fmaf(c0, e0, g00); g01 = fmaf(c0, e1, g01); g10 = fmaf(c1, e0, g10); g11 = fmaf(c1, e1, g11);
+    }
+    auto put = [&](int i, int j, float sc, float dp) {
+      const bool k = ok(i, j);
+      Ps[i * PL + j] = k ? sc + bias(i, j) : -INFINITY;
+      Gs[i * PL + j] = k ? dp : 0.f;
+    };
+    put(i0, j0, s00, g00);
+    if (vj1) put(i0, j1, s01, g01);
+    if (vi1) put(i1, j0, s10, g10);
+    if (vi1 && vj1) put(i1, j1, s11, g11);
+  }
+}
+
+// row softmax of Ps in place, then Gs = dS = P * (dP - sum_j dP P); eight lanes per row
+__device__ __forceinline__ void attn_softmax_ds(float* Ps, float* Gs, int nq, int nk, int PL) {
+  const int sub = threadIdx.x & 7;
+  for (int i = threadIdx.x >> 3; i < nq; i += 32) {
+    float* pr = Ps + i * PL; float* gr = Gs + i * PL;
+    float mx = -INFINITY;
+    for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, pr[j]);
+    for (int m = 1; m < 8; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 8));
+    float sum = 0.f;
+    for (int j = sub; j < nk; j += 8) { const float e = (pr[j] == -INFINITY) ? 0.f : expf(pr[j] - mx); pr[j] = e; sum += e; }
+    for (int m = 1; m < 8; m <<= 1) sum += __shfl_xor(sum, m, 8);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float c = 0.f;
+    for (int j = sub; j < nk; j += 8) { const float pj = pr[j] * inv; pr[j] = pj; c = fmaf(gr[j], pj, c); }
+    for (int m = 1; m < 8; m <<= 1) c += __shfl_xor(c, m, 8);
+    for (int j = sub; j < nk; j += 8) gr[j] = pr[j] * (gr[j] - c);
+  }
+}
+
+// out[r][c] = sum_j W[r][j] X[j][c] for two rows r0, r1 = r0 + hr of W (row stride PL) and columns c = lane16 + 16 k
+__device__ __forceinline__ void attn_rows_times(const float* W, int PL, int r0, int r1, const float* X, int nj, int l16,
+                                                float (&a0)[4], float (&a1)[4]) {
+  for (int j = 0; j < nj; ++j) {
+    const float w0 = W[r0 * PL + j], w1 = W[r1 * PL + j];
+    const float* x = X + j * AST + l16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float xv = x[16 * k]; a0[k] = fmaf(w0, xv, a0[k]); a1[k] = fmaf(w1, xv, a1[k]); }
+  }
+}
+// out[r][c] = sum_i W[i][r] X[i][c] (the transposed product) for two columns r0, r1 of W
+__device__ __forceinline__ void attn_cols_times(const float* W, int PL, int r0, int r1, const float* X, int ni, int l16,
+                                                float (&a0)[4], float (&a1)[4]) {
+  for (int i = 0; i < ni; ++i) {
+    const float w0 = W[i * PL + r0], w1 = W[i * PL + r1];
+    const float* x = X + i * AST + l16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float xv = x[16 * k]; a0[k] = fmaf(w0, xv, a0[k]); a1[k] = fmaf(w1, xv, a1[k]); }
+  }
+}
+__device__ __forceinline__ void attn_store16(float* dst, int l16, const float (&a)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[l16 + 16 * k] = a[k];
+}
+
+// One block per (sequence, head). Everything of the head lives in LDS: Q, K, V, dO [Ls][65], P and dS [Ls][Ls + 1].
 __global__ __launch_bounds__(256) void self_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                              const int32_t* __restrict__ mask, const float* __restrict__ rel_bias,
                                                              const int32_t* __restrict__ bucket, float* __restrict__ dqkv,
@@ -292,73 +377,63 @@ __global__ __launch_bounds__(256) void self_attn_bwd_kernel(const float* __restr
                                                              int causal) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int s = blockIdx.x / H, h = blockIdx.x - s * H, inner = H * DKV, ld = 3 * inner, tid = threadIdx.x;
-  const int PL = Ls + 1;
-  float* Qs = sm;                       // [Ls][64]
-  float* Ks = Qs + Ls * DKV;
-  float* Vs = Ks + Ls * DKV;
-  float* Ds = Vs + Ls * DKV;            // dO
-  float* Ps = Ds + Ls * DKV;            // [Ls][PL]  probabilities
+  const int PL = Ls + 1, nd = causal ? Ls : 2 * Ls - 1;
+  float* Qs = sm;                       // [Ls][AST]
+  float* Ks = Qs + Ls * AST;
+  float* Vs = Ks + Ls * AST;
+  float* Ds = Vs + Ls * AST;            // dO
+  float* Ps = Ds + Ls * AST;            // [Ls][PL]  probabilities
   float* Gs = Ps + Ls * PL;             // [Ls][PL]  dP, then dS
-  float* Bs = Gs + Ls * PL;             // [buckets]
+  float* Bs = Gs + Ls * PL;             // [buckets] bias of this head
+  float* diag = Bs + 64;                // [nd] sum of dS along each diagonal j - i
+  int* bk = reinterpret_cast<int*>(diag + 2 * Ls);   // [nd] bucket of each diagonal
+  int* mk = bk + 2 * Ls;                // [Ls] key mask
   const size_t row0 = (size_t)s * Ls;
   for (int i = tid; i < Ls * 16; i += 256) {
     const int r = i >> 4, c = (i & 15) * 4;
     const float* base = qkv + (row0 + r) * ld + h * DKV + c;
-    *reinterpret_cast<float4*>(Qs + r * DKV + c) = *reinterpret_cast<const float4*>(base);
-    *reinterpret_cast<float4*>(Ks + r * DKV + c) = *reinterpret_cast<const float4*>(base + inner);
-    *reinterpret_cast<float4*>(Vs + r * DKV + c) = *reinterpret_cast<const float4*>(base + 2 * inner);
-    *reinterpret_cast<float4*>(Ds + r * DKV + c) = *reinterpret_cast<const float4*>(dO + (row0 + r) * inner + h * DKV + c);
+    stage_row4(Qs + r * AST + c, base); stage_row4(Ks + r * AST + c, base + inner); stage_row4(Vs + r * AST + c, base + 2 * inner);
+    stage_row4(Ds + r * AST + c, dO + (row0 + r) * inner + h * DKV + c);
   }
   if (tid < buckets) Bs[tid] = rel_bias[tid * H + h];
+  // diagonal t: causal i - j = t; bidirectional j - i = t - (Ls - 1)
+  for (int t = tid; t < nd; t += 256) bk[t] = causal ? bucket[t] : bucket[t - (Ls - 1) + (MAX_LQ - 1)];
+  for (int j = tid; j < Ls; j += 256) mk[j] = (causal || mask[row0 + j] != 0) ? 1 : 0;
   __syncthreads();
-  const int32_t* mrow = mask ? mask + (size_t)s * Ls : nullptr;
-  for (int p = tid; p < Ls * Ls; p += 256) {      // scores and dP = dO V^T
-    const int i = p / Ls, j = p - i * Ls;
-    const bool ok = causal ? (j <= i) : (mrow[j] != 0);
-    float sc = 0.f, dp = 0.f;
-    if (ok) {
-      for (int d = 0; d < DKV; ++d) { sc = fmaf(Qs[i * DKV + d], Ks[j * DKV + d], sc); dp = fmaf(Ds[i * DKV + d], Vs[j * DKV + d], dp); }
-      sc += Bs[causal ? bucket[i - j] : bucket[j - i + (MAX_LQ - 1)]];
-    }
-    Ps[i * PL + j] = ok ? sc : -INFINITY;
-    Gs[i * PL + j] = dp;
-  }
+  attn_scores_dp(Qs, Ds, Ks, Vs, Ls, Ls, Ps, Gs, PL,
+                 [&](int i, int j) { return causal ? (j <= i) : (mk[j] != 0); },
+                 [&](int i, int j) { return Bs[bk[causal ? i - j : j - i + Ls - 1]]; });
   __syncthreads();
-  for (int i = tid; i < Ls; i += 256) {            // softmax row i, then dS = P * (dP - sum_j dP P)
-    float mx = -INFINITY;
-    for (int j = 0; j < Ls; ++j) mx = fmaxf(mx, Ps[i * PL + j]);
-    float sum = 0.f;
-    for (int j = 0; j < Ls; ++j) { const float e = (Ps[i * PL + j] == -INFINITY) ? 0.f : expf(Ps[i * PL + j] - mx); Ps[i * PL + j] = e; sum += e; }
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    float c = 0.f;
-    for (int j = 0; j < Ls; ++j) { const float pj = Ps[i * PL + j] * inv; Ps[i * PL + j] = pj; c = fmaf(Gs[i * PL + j], pj, c); }
-    for (int j = 0; j < Ls; ++j) Gs[i * PL + j] = Ps[i * PL + j] * (Gs[i * PL + j] - c);
-  }
+  attn_softmax_ds(Ps, Gs, Ls, Ls, PL);
   __syncthreads();
-  for (int it = tid; it < Ls * 16; it += 256) {    // dQ_i = sum_j dS_ij K_j ; dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i
-    const int r = it >> 4, c = (it & 15) * 4;
-    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dk = dq, dv = dq;
-    for (int j = 0; j < Ls; ++j) {
-      const float g = Gs[r * PL + j];
-      const float4 k4 = *reinterpret_cast<const float4*>(Ks + j * DKV + c);
-      dq.x = fmaf(g, k4.x, dq.x); dq.y = fmaf(g, k4.y, dq.y); dq.z = fmaf(g, k4.z, dq.z); dq.w = fmaf(g, k4.w, dq.w);
-      const float gt = Gs[j * PL + r], pt = Ps[j * PL + r];
-      const float4 q4 = *reinterpret_cast<const float4*>(Qs + j * DKV + c), o4 = *reinterpret_cast<const float4*>(Ds + j * DKV + c);
-      dk.x = fmaf(gt, q4.x, dk.x); dk.y = fmaf(gt, q4.y, dk.y); dk.z = fmaf(gt, q4.z, dk.z); dk.w = fmaf(gt, q4.w, dk.w);
-      dv.x = fmaf(pt, o4.x, dv.x); dv.y = fmaf(pt, o4.y, dv.y); dv.z = fmaf(pt, o4.z, dv.z); dv.w = fmaf(pt, o4.w, dv.w);
-    }
-    float* ob = dqkv + (row0 + r) * ld + h * DKV + c;
-    *reinterpret_cast<float4*>(ob) = dq;
-    *reinterpret_cast<float4*>(ob + inner) = dk;
-    *reinterpret_cast<float4*>(ob + 2 * inner) = dv;
-  }
-  if (tid < buckets) {                               // bias gradient of this block, bucket by bucket (fixed order)
-    float acc = 0.f;
-    for (int i = 0; i < Ls; ++i)
-      for (int j = 0; j < Ls; ++j) {
-        const bool ok = causal ? (j <= i) : (mrow[j] != 0);
-        if (ok && (causal ? bucket[i - j] : bucket[j - i + (MAX_LQ - 1)]) == tid) acc += Gs[i * PL + j];
+  {  // dQ_i = sum_j dS_ij K_j ; dK_j = sum_i dS_ij Q_i ; dV_j = sum_i P_ij dO_i — two rows per thread
+    const int hr = (Ls + 1) >> 1, l16 = tid & 15;
+    for (int t = tid >> 4; t < hr; t += 16) {
+      const int r0 = t, r1 = (t + hr < Ls) ? t + hr : t;
+      float dq0[4] = {}, dq1[4] = {}, dk0[4] = {}, dk1[4] = {}, dv0[4] = {}, dv1[4] = {};
+      attn_rows_times(Gs, PL, r0, r1, Ks, Ls, l16, dq0, dq1);
+      attn_cols_times(Gs, PL, r0, r1, Qs, Ls, l16, dk0, dk1);
+      attn_cols_times(Ps, PL, r0, r1, Ds, Ls, l16, dv0, dv1);
+      float* ob = dqkv + (row0 + r0) * ld + h * DKV;
+      attn_store16(ob, l16, dq0); attn_store16(ob + inner, l16, dk0); attn_store16(ob + 2 * inner, l16, dv0);
+      if (r1 != r0) {
+        ob = dqkv + (row0 + r1) * ld + h * DKV;
+        attn_store16(ob, l16, dq1); attn_store16(ob + inner, l16, dk1); attn_store16(ob + 2 * inner, l16, dv1);
       }
+    }
+  }
+  // bias gradient of this block: dS is zero wherever the score was masked, so each diagonal is summed whole (fixed
+  // order), then the diagonals of one bucket
+  for (int t = tid; t < nd; t += 256) {
+    const int off = causal ? -t : t - (Ls - 1);      // j - i
+    float acc = 0.f;
+    for (int i = 0; i < Ls; ++i) { const int j = i + off; if (j >= 0 && j < Ls) acc += Gs[i * PL + j]; }
+    diag[t] = acc;
+  }
+  __syncthreads();
+  if (tid < buckets) {
+    float acc = 0.f;
+    for (int t = 0; t < nd; ++t) if (bk[t] == tid) acc += diag[t];
     dbias_part[(size_t)blockIdx.x * buckets + tid] = acc;
   }
 }
@@ -373,7 +448,10 @@ __global__ __launch_bounds__(64) void bias_reduce_kernel(const float* __restrict
   dbias[b * H + h] += acc;
 }
 
-size_t self_attn_bwd_smem(int Ls, int buckets) { return ((size_t)4 * Ls * DKV + 2 * (size_t)Ls * (Ls + 1) + buckets) * sizeof(float); }
+size_t self_attn_bwd_smem(int Ls, int buckets) {
+  (void)buckets;   // <= 64, fixed slot
+  return ((size_t)4 * Ls * AST + 2 * (size_t)Ls * (Ls + 1) + 64 + 5 * (size_t)Ls) * sizeof(float);
+}
 
 hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias, const int32_t* bucket,
                                 float* dqkv, float* dbias_part, float* dbias, int S, int Ls, int H, int buckets, int causal,
@@ -397,73 +475,57 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H, inner = H * DKV, tid = threadIdx.x;
   const int PL = Lq + 1;
-  float* Qs = sm;                     // [n][64]
-  float* Ds = Qs + n * DKV;           // dO [n][64]
-  float* Ks = Ds + n * DKV;           // [Lq][64]
-  float* Vs = Ks + Lq * DKV;
-  float* Ps = Vs + Lq * DKV;          // [n][PL]
+  float* Qs = sm;                     // [n][AST]
+  float* Ds = Qs + n * AST;           // dO [n][AST]
+  float* Ks = Ds + n * AST;           // [Lq][AST]
+  float* Vs = Ks + Lq * AST;
+  float* Ps = Vs + Lq * AST;          // [n][PL]
   float* Gs = Ps + n * PL;            // [n][PL]
-  const int32_t* mrow = mask + (size_t)qi * Lq;
+  int* mk = reinterpret_cast<int*>(Gs + n * PL);   // [Lq]
   for (int i = tid; i < n * 16; i += 256) {
     const int r = i >> 4, c = (i & 15) * 4;
     const size_t o = ((size_t)qi * n + r) * inner + h * DKV + c;
-    *reinterpret_cast<float4*>(Qs + r * DKV + c) = *reinterpret_cast<const float4*>(q + o);
-    *reinterpret_cast<float4*>(Ds + r * DKV + c) = *reinterpret_cast<const float4*>(dO + o);
+    stage_row4(Qs + r * AST + c, q + o); stage_row4(Ds + r * AST + c, dO + o);
   }
   for (int i = tid; i < Lq * 16; i += 256) {
     const int j = i >> 4, c = (i & 15) * 4;
     const size_t o = ((size_t)qi * Lq + j) * xld + h * DKV + c;
-    *reinterpret_cast<float4*>(Ks + j * DKV + c) = *reinterpret_cast<const float4*>(xk + o);
-    *reinterpret_cast<float4*>(Vs + j * DKV + c) = *reinterpret_cast<const float4*>(xv + o);
+    stage_row4(Ks + j * AST + c, xk + o); stage_row4(Vs + j * AST + c, xv + o);
   }
+  for (int j = tid; j < Lq; j += 256) mk[j] = mask[(size_t)qi * Lq + j];
   __syncthreads();
-  for (int p = tid; p < n * Lq; p += 256) {
-    const int i = p / Lq, j = p - i * Lq;
-    const bool ok = mrow[j] != 0;
-    float sc = 0.f, dp = 0.f;
-    if (ok)
-      for (int d = 0; d < DKV; ++d) { sc = fmaf(Qs[i * DKV + d], Ks[j * DKV + d], sc); dp = fmaf(Ds[i * DKV + d], Vs[j * DKV + d], dp); }
-    Ps[i * PL + j] = ok ? sc : -INFINITY;
-    Gs[i * PL + j] = dp;
-  }
+  attn_scores_dp(Qs, Ds, Ks, Vs, n, Lq, Ps, Gs, PL, [&](int, int j) { return mk[j] != 0; }, [](int, int) { return 0.f; });
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    float mx = -INFINITY;
-    for (int j = 0; j < Lq; ++j) mx = fmaxf(mx, Ps[i * PL + j]);
-    float sum = 0.f;
-    for (int j = 0; j < Lq; ++j) { const float e = (Ps[i * PL + j] == -INFINITY) ? 0.f : expf(Ps[i * PL + j] - mx); Ps[i * PL + j] = e; sum += e; }
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    float c = 0.f;
-    for (int j = 0; j < Lq; ++j) { const float pj = Ps[i * PL + j] * inv; Ps[i * PL + j] = pj; c = fmaf(Gs[i * PL + j], pj, c); }
-    for (int j = 0; j < Lq; ++j) Gs[i * PL + j] = Ps[i * PL + j] * (Gs[i * PL + j] - c);
-  }
+  attn_softmax_ds(Ps, Gs, n, Lq, PL);
   __syncthreads();
-  for (int it = tid; it < n * 16; it += 256) {      // dq_i = sum_j dS_ij K_j
-    const int r = it >> 4, c = (it & 15) * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < Lq; ++j) {
-      const float g = Gs[r * PL + j];
-      const float4 k4 = *reinterpret_cast<const float4*>(Ks + j * DKV + c);
-      a.x = fmaf(g, k4.x, a.x); a.y = fmaf(g, k4.y, a.y); a.z = fmaf(g, k4.z, a.z); a.w = fmaf(g, k4.w, a.w);
+  const int l16 = tid & 15;
+  {  // dq_i = sum_j dS_ij K_j
+    const int hr = (n + 1) >> 1;
+    for (int t = tid >> 4; t < hr; t += 16) {
+      const int r0 = t, r1 = (t + hr < n) ? t + hr : t;
+      float a0[4] = {}, a1[4] = {};
+      attn_rows_times(Gs, PL, r0, r1, Ks, Lq, l16, a0, a1);
+      attn_store16(dq + ((size_t)qi * n + r0) * inner + h * DKV, l16, a0);
+      if (r1 != r0) attn_store16(dq + ((size_t)qi * n + r1) * inner + h * DKV, l16, a1);
     }
-    *reinterpret_cast<float4*>(dq + ((size_t)qi * n + r) * inner + h * DKV + c) = a;
   }
-  for (int it = tid; it < Lq * 16; it += 256) {     // dK_j = sum_i dS_ij q_i ; dV_j = sum_i P_ij dO_i
-    const int j = it >> 4, c = (it & 15) * 4;
-    float4 dk = make_float4(0.f, 0.f, 0.f, 0.f), dv = dk;
-    for (int i = 0; i < n; ++i) {
-      const float g = Gs[i * PL + j], pp = Ps[i * PL + j];
-      const float4 q4 = *reinterpret_cast<const float4*>(Qs + i * DKV + c), o4 = *reinterpret_cast<const float4*>(Ds + i * DKV + c);
-      dk.x = fmaf(g, q4.x, dk.x); dk.y = fmaf(g, q4.y, dk.y); dk.z = fmaf(g, q4.z, dk.z); dk.w = fmaf(g, q4.w, dk.w);
-      dv.x = fmaf(pp, o4.x, dv.x); dv.y = fmaf(pp, o4.y, dv.y); dv.z = fmaf(pp, o4.z, dv.z); dv.w = fmaf(pp, o4.w, dv.w);
+  {  // dK_j = sum_i dS_ij q_i ; dV_j = sum_i P_ij dO_i
+    const int hr = (Lq + 1) >> 1;
+    for (int t = tid >> 4; t < hr; t += 16) {
+      const int j0 = t, j1 = (t + hr < Lq) ? t + hr : t;
+      float dk0[4] = {}, dk1[4] = {}, dv0[4] = {}, dv1[4] = {};
+      attn_cols_times(Gs, PL, j0, j1, Qs, n, l16, dk0, dk1);
+      attn_cols_times(Ps, PL, j0, j1, Ds, n, l16, dv0, dv1);
+      size_t o = ((size_t)qi * Lq + j0) * xld + h * DKV;
+      attn_store16(dxk + o, l16, dk0); attn_store16(dxv + o, l16, dv0);
+      if (j1 != j0) { o = ((size_t)qi * Lq + j1) * xld + h * DKV; attn_store16(dxk + o, l16, dk1); attn_store16(dxv + o, l16, dv1); }
     }
-    const size_t o = ((size_t)qi * Lq + j) * xld + h * DKV + c;
-    *reinterpret_cast<float4*>(dxk + o) = dk;
-    *reinterpret_cast<float4*>(dxv + o) = dv;
   }
 }
 
-size_t cross_attn_bwd_smem(int n, int Lq) { return ((size_t)2 * n * DKV + 2 * (size_t)Lq * DKV + 2 * (size_t)n * (Lq + 1)) * sizeof(float); }
+size_t cross_attn_bwd_smem(int n, int Lq) {
+  return ((size_t)2 * n * AST + 2 * (size_t)Lq * AST + 2 * (size_t)n * (Lq + 1) + (size_t)Lq) * sizeof(float);
+}
 
 hipError_t launch_cross_attn_bwd(const float* q, const float* xk, const float* xv, int xld, const int32_t* mask, const float* dO,
                                  float* dq, float* dxk, float* dxv, int bz, int n, int Lq, int H, hipStream_t s) {
@@ -637,8 +699,15 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
 }
 
 // ---- per-tensor dynamic f16 planes for the training GEMMs ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
-  __shared__ float red[256];
+// Absolute maxima of up to two tensors in one launch (blockIdx.y picks the tensor). The result is combined with an integer
+// atomicMax on the bit pattern (non-negative floats order like unsigned integers; a maximum does not depend on the order
+// of arrival), so the slots must be zero before the launch — the caller hands out fresh slots of a ring zeroed per step.
+__global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ x0, size_t n0, const float* __restrict__ x1, size_t n1,
+                                                       unsigned int* __restrict__ out) {
+  __shared__ float red[4];
+  const float* x = blockIdx.y ? x1 : x0;
+  const size_t n = blockIdx.y ? n1 : n0;
+  if ((size_t)blockIdx.x * 1024 >= n) return;
   float a = 0.f;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
     if (i + 3 < n) {
@@ -648,22 +717,17 @@ __global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restric
       for (size_t j = i; j < n; ++j) a = fmaxf(a, fabsf(x[j]));
     }
   }
-  red[threadIdx.x] = a;
+  for (int m = 32; m > 0; m >>= 1) a = fmaxf(a, __shfl_xor(a, m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) atomicMax(out + blockIdx.y, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
-__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-  __shared__ float red[256];
-  red[threadIdx.x] = threadIdx.x < n ? part[threadIdx.x] : 0.f;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-  if (threadIdx.x == 0) *out = red[0];
-}
-hipError_t launch_absmax(const float* x, size_t n, float* part, float* out, hipStream_t s) {
-  const int nb = (int)std::min<size_t>(256, (n / 4 + 255) / 256 + 1);
-  hipLaunchKernelGGL(absmax_part_kernel, dim3(nb), dim3(256), 0, s, x, n, part);
-  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, s, part, nb, out);
+hipError_t launch_absmax2(const float* x0, size_t n0, const float* x1, size_t n1, float* out, hipStream_t s) {
+  const size_t n = std::max(n0, x1 ? n1 : 0);
+  if (n == 0) return hipSuccess;
+  const int nb = (int)std::min<size_t>(2048, (n + 4095) / 4096);   // >= 4 float4 per thread before another block pays off
+  hipLaunchKernelGGL(absmax2_kernel, dim3(nb, x1 ? 2 : 1), dim3(256), 0, s, x0, n0, x1, x1 ? n1 : 0,
+                     reinterpret_cast<unsigned int*>(out));
   return hipGetLastError();
 }
 
@@ -689,33 +753,53 @@ hipError_t launch_split_dyn(const float* x, int R, int C, int ldi, __half* out, 
   return hipGetLastError();
 }
 
+// 64 x 64 tile through LDS: transposed planes out_t[2][C][Rpad] (pairs of rows as one half2 store), and, when out_p is
+// given, the plain planes out_p[2][R][C] from the same read of x
 __global__ __launch_bounds__(256) void split_dyn_T_kernel(const float* __restrict__ x, int R, int C, int ldi, int Rpad,
-                                                           __half* __restrict__ out, const float* __restrict__ amax) {
-  __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+                                                           __half* __restrict__ out_t, __half* __restrict__ out_p,
+                                                           const float* __restrict__ amax) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   const float sc = dyn_plane_scale(*amax);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int r = r0 + ty + 8 * k, c = c0 + tx;
-    tile[ty + 8 * k][tx] = (r < R && c < C) ? x[(size_t)r * ldi + c] * sc : 0.f;
+    const int r = (tid >> 4) + 16 * k, c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < R && c0 + c < C) {          // C % 4 == 0: a float4 is inside or outside as a whole
+      v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ldi + c0 + c);
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      if (out_p) {
+        __half h[4], l[4];
+        split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+        const size_t o = (size_t)(r0 + r) * C + c0 + c;
+        *reinterpret_cast<uint2*>(out_p + o) = *reinterpret_cast<uint2*>(h);
+        *reinterpret_cast<uint2*>(out_p + (size_t)R * C + o) = *reinterpret_cast<uint2*>(l);
+      }
+    }
+    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
   }
   __syncthreads();
   const size_t ps = (size_t)C * Rpad;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = c0 + ty + 8 * k, r = r0 + tx;
-    if (c < C && r < Rpad) {
-      __half hi, lo;
-      split_f16(tile[tx][ty + 8 * k], hi, lo);
-      out[(size_t)c * Rpad + r] = hi;
-      out[ps + (size_t)c * Rpad + r] = lo;
+  for (int k = 0; k < 8; ++k) {
+    const int c = (tid >> 5) + 8 * k, r = (tid & 31) * 2;        // Rpad % 2 == 0
+    if (c0 + c < C && r0 + r < Rpad) {
+      __half2 hi, lo;
+      __half h0, l0, h1, l1;
+      split_f16(tile[r][c], h0, l0); split_f16(tile[r + 1][c], h1, l1);
+      hi = __halves2half2(h0, h1); lo = __halves2half2(l0, l1);
+      const size_t o = (size_t)(c0 + c) * Rpad + r0 + r;
+      *reinterpret_cast<__half2*>(out_t + o) = hi;
+      *reinterpret_cast<__half2*>(out_t + ps + o) = lo;
     }
   }
 }
-hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out, const float* amax, hipStream_t s) {
+hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out_t, __half* out_plain, const float* amax,
+                              hipStream_t s) {
   if (R <= 0 || C <= 0) return hipSuccess;
-  hipLaunchKernelGGL(split_dyn_T_kernel, dim3((C + 31) / 32, (Rpad + 31) / 32), dim3(256), 0, s, x, R, C, ldi, Rpad, out, amax);
+  if ((C & 3) || (ldi & 3) || (Rpad & 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(split_dyn_T_kernel, dim3((C + 63) / 64, (Rpad + 63) / 64), dim3(256), 0, s, x, R, C, ldi, Rpad, out_t, out_plain,
+                     amax);
   return hipGetLastError();
 }
 
