@@ -20,6 +20,7 @@
 // >= 112 such tiles) and gemm_h2_dma_kernel (128x128 / 128x64 tiles, 4 waves) for smaller launches; both stage
 // K-tiles with LDS-DMA into unpadded XOR-swizzled rows. Earlier variants (register staging, in-phase software
 // pipelining) are in the history and in DESIGN.md §5 / §8 with their measured numbers.
+#include <algorithm>
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
@@ -74,6 +75,14 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  // split-K (training weight gradients: few output tiles, K = thousands of rows): blockIdx.y walks its own range of
+  // K-tiles and stores a partial result at out + blockIdx.y * part_stride; splitk_reduce_kernel adds them in order
+  int nkt = g.K / HBK, kbeg = 0;
+  if (g.ksplit > 1) {
+    const int per = (nkt + g.ksplit - 1) / g.ksplit;
+    kbeg = blockIdx.y * per;
+    nkt = min(per, nkt - kbeg);
+  }
 
   // per-instruction source pointers (k0 = 0): instruction j of this wave covers LDS rows
   // [16*(wave + NW*j), +16); lane -> row (lane>>2), physical segment (lane&3)
@@ -90,7 +99,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
     else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
     if (!FULL && trow >= limit) trow = limit - 1;                  // ragged tile: duplicate a valid row
-    src[j] = base + (size_t)trow * ld + seg * 8;
+    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * HBK;
   }
   auto stage = [&](int buf, int k0) {
 #pragma unroll
@@ -145,7 +154,6 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     }
   };
 
-  const int nkt = g.K / HBK;
   if (STAGES == 2) {
     stage(0, 0);
     __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
@@ -194,7 +202,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
       const int n = bn + wn * (BN / WN) + j * 32 + ncol;
       const bool nok = FULL || n < g.N;
       const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
-      float* outp = g.out[oi];
+      float* outp = g.out[oi] + (size_t)blockIdx.y * g.part_stride;
       const int ldo = g.ldo[oi];
       float res[16];
       if (g.resid || g.resid_h) {
@@ -669,9 +677,10 @@ template <int BM, int BN, int WM = 2, int WN = 2>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const bool full = (a.M % BM == 0) && (a.N % BN == 0) && !a.m_dev;
-  const dim3 grid(tiles_m * tiles_n), blk(64 * WM * WN);
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  const dim3 grid(tiles_m * tiles_n, ks), blk(64 * WM * WN);
   static const int deep_max = [] { const char* e = getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
-  if ((tiles_m * tiles_n <= deep_max || BM < 128) && !a.m_dev) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
+  if ((tiles_m * tiles_n * ks <= deep_max || BM < 128) && !a.m_dev) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
     if (full)
       hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 4>), grid, blk, 0, s, a, tiles_m, tiles_n);
     else
@@ -700,6 +709,21 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// out[m][n] = (resid ? resid[m][n] : 0) + sum over the splits, in split order (bitwise reproducible); N % 4 == 0
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ks, size_t stride, int M, int N,
+                                                             float* __restrict__ out, int ldo, const float* __restrict__ resid, int ldr) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i4 >= (size_t)M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 - (size_t)m * n4) * 4;
+  float4 a = resid ? *reinterpret_cast<const float4*>(resid + (size_t)m * ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < ks; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + (size_t)m * N + n);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = a;
+}
+
 hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   GemmH2Args a = a_in;
   if (a.acc_scale == 0.f) a.acc_scale = 1.f;      // zero-initialised args mean "no scaling"
@@ -709,7 +733,13 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (force == 256 || (force == 0 && t256 >= 112)) { a_in.kernel_cls = RPR_K_GEMM; return launch_256(a, s); }
+  // 256-tile rounds on the 256 CUs: a launch just over a whole number of rounds (e.g. 288 tiles) leaves most of the
+  // chip idle in its last round; the 128-tile kernels quantise finer (measured M = 8192, N = 2304: 135 vs 151 us)
+  const double round_eff = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+  if (force == 256 || (force == 0 && t256 >= 112 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
+    a_in.kernel_cls = RPR_K_GEMM;
+    return launch_256(a, s);
+  }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
   static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 400; }();   // max rows (measured: 320 rows 53 vs 76 ms per search, 640 rows 86 vs 77)
@@ -721,7 +751,28 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     return hipGetLastError();
   }
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  const bool narrow = force ? (force == 64) : (t128 < 512);
+  // split-K: the caller lent scratch for partial results and the launch is a long reduction into few tiles
+  static const int split_target = [] { const char* e = getenv("RPR_GEMM_SPLITK"); return e ? atoi(e) : 640; }();
+  if (a.part && split_target > 0 && a.K >= 2048 && t128 * 2 < split_target && !a.out_h && !a.ssq_out && !a.row_ssq && !a.relu && !a.resid_h &&
+      !a.m_dev && a.split_n >= a.N && (a.N & 3) == 0 && (a.ldo[0] & 3) == 0 && (!a.resid || (a.ldr & 3) == 0)) {
+    const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    long ks = std::min<long>((split_target + t - 1) / t, a.K / 1024);
+    ks = std::min<long>(ks, (long)(a.part_cap / ((size_t)a.M * a.N)));
+    const int nkt = a.K / HBK;
+    while (ks > 1 && (ks - 1) * ((nkt + ks - 1) / ks) >= nkt) --ks;   // every split owns at least one K-tile
+    if (ks > 1) {
+      GemmH2Args p = a;
+      p.ksplit = (int)ks; p.part_stride = (size_t)a.M * a.N;
+      p.out[0] = p.out[1] = p.out[2] = a.part; p.ldo[0] = p.ldo[1] = p.ldo[2] = a.N; p.split_n = a.N; p.resid = nullptr;
+      hipError_t e = launch_cfg<128, 64>(p, s);
+      if (e != hipSuccess) return e;
+      const size_t n4 = (size_t)a.M * (a.N >> 2);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.part, (int)ks, p.part_stride, a.M,
+                         a.N, a.out[0], a.ldo[0], a.resid, a.ldr);
+      return hipGetLastError();
+    }
+  }
+  const bool narrow = force ? (force == 64) : (t128 < 256);
   return narrow ? launch_cfg<128, 64>(a, s) : launch_cfg<128, 128>(a, s);
 }
 

@@ -13,6 +13,7 @@
 // (train_kernels.hip); the reductions are deterministic (fixed-order partials, fixed-point integer atomics).
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 
 #include "internal.h"
 
@@ -22,8 +23,11 @@ struct TrainWs {
   // saved forward activations
   DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
   // scratch
-  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax;
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax, part;
   int amax_next = 0;
+  // forward GEMM site (keyed by its weight tensor) -> {amax of its input activations, amax of the weight}: the backward
+  // multiplies the same two tensors again (dW = dY^T X, dX = dY W) and reuses both maxima
+  std::unordered_map<const float*, float*> site_amax;
   size_t bytes = 0;
 };
 
@@ -101,6 +105,7 @@ float* amax_slots(rpr_ctx* c, int n) {          // n fresh (zero) slots
 void amax_reset(Launcher& Ln) {
   TrainWs& w = *Ln.c->tws;
   w.amax_next = 0;
+  w.site_amax.clear();
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.amax), AMAX_SLOTS / 2, Ln.s); });
 }
 void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int ldc, int M, int N, int K, const float* resid, int relu) {
@@ -110,6 +115,7 @@ void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int l
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.sat = Ln.c->status;
   g.dyn_a = A.amax; g.dyn_b = B.amax;
+  g.part = P<float>(Ln.c->tws->part); g.part_cap = Ln.c->tws->part.cap / sizeof(float);
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm_h2(g, Ln.s); },
          &g.kernel_cls);
 }
@@ -124,6 +130,7 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
     __half *pa = P<__half>(w.tA), *pb = P<__half>(w.wT);
     hipStream_t s = Ln.s;
     Ln.run(RPR_K_OTHER, 0, 4.0 * (M + N) * K, [&] { return launch_absmax2(A, (size_t)M * K, B, (size_t)N * K, am, s); });
+    w.site_amax[B] = am;
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn(A, M, K, lda, pa, am, s); });
     Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn(B, N, K, ldb, pb, am + 1, s); });
     gemm_planes(Ln, {pa, (size_t)M * K, K, am}, {pb, (size_t)N * K, K, am + 1}, C, ldc, M, N, K, resid, relu);
@@ -145,16 +152,23 @@ struct Bwd {
     if (c->precision == RPR_PREC_F16X2) {
       // one read of dY gives its plain planes (for dX) and its transposed planes (for dW); W is transposed straight
       // from the fp32 weight
-      float* am = amax_slots(c, 4);
+      float* am = amax_slots(c, 3);
       if (!am) { Ln.err = RPR_ERR_INVALID; return; }
       __half *py = P<__half>(w.tA), *pyt = P<__half>(w.tC), *pxt = P<__half>(w.tB), *pwt = P<__half>(w.wT);
-      Ln.run(RPR_K_OTHER, 0, 4.0 * M * N + 4.0 * N * K, [&] { return launch_absmax2(dY, (size_t)M * N, W, (size_t)N * K, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax2(X, (size_t)M * K, nullptr, 0, am + 2, s); });
+      const float *am_x = am + 2, *am_w = am + 1;
+      auto site = w.site_amax.find(W);
+      if (site != w.site_amax.end()) {   // X and W are the forward GEMM's operands: their maxima are known
+        am_x = site->second; am_w = site->second + 1;
+        Ln.run(RPR_K_OTHER, 0, 4.0 * M * N, [&] { return launch_absmax2(dY, (size_t)M * N, nullptr, 0, am, s); });
+      } else {
+        Ln.run(RPR_K_OTHER, 0, 4.0 * M * N + 4.0 * N * K, [&] { return launch_absmax2(dY, (size_t)M * N, W, (size_t)N * K, am, s); });
+        Ln.run(RPR_K_OTHER, 0, 4.0 * M * K, [&] { return launch_absmax2(X, (size_t)M * K, nullptr, 0, am + 2, s); });
+      }
       Ln.run(RPR_K_OTHER, 0, 12.0 * M * N, [&] { return launch_split_dyn_T(dY, M, N, N, Mp, pyt, py, am, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pxt, nullptr, am + 2, s); });
-      Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pwt, nullptr, am + 1, s); });
-      gemm_planes(Ln, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am + 2}, dW, K, N, K, Mp, nullptr, 0);
-      gemm_planes(Ln, {py, (size_t)M * N, N, am}, {pwt, (size_t)K * N, N, am + 1}, dX, K, M, K, N, nullptr, 0);
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pxt, nullptr, am_x, s); });
+      Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pwt, nullptr, am_w, s); });
+      gemm_planes(Ln, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0);
+      gemm_planes(Ln, {py, (size_t)M * N, N, am}, {pwt, (size_t)K * N, N, am_w}, dX, K, M, K, N, nullptr, 0);
       return;
     }
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, s); });
@@ -194,7 +208,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
-  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f);
+  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats
   return e;
 }
 
@@ -367,7 +381,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC, &w.part};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c->tws;
   c->tws = nullptr;

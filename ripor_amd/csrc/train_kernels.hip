@@ -208,18 +208,22 @@ hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s)
 
 // RMSNorm backward. h = post * w * x * rs, rs = rsqrt(mean(x^2) + eps). Given dh:
 //   g = dh * post * w;  dx = rs * g - x * rs^3 * mean(g * x);  dw += dh * post * x * rs (summed over rows)
-// dx_out[row] = dx (+ dres[row]: the gradient arriving through the residual connection). One wave per row; the 4 rows
-// of a block leave one partial dw row (w_part[blk][d]); colsum_kernel adds the partials in block order.
+// dx_out[row] = dx (+ dres[row]: the gradient arriving through the residual connection). One wave per row; the 16 rows
+// of a block (4 per wave, in row order) leave one partial dw row (w_part[blk][d]); colsum_kernel adds the partials in
+// block order.
+constexpr int NB_ROWS = 16;   // rows per block of rmsnorm_bwd_kernel (4 waves x 4 rows)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ dh, const float* __restrict__ dres,
                                                            float* __restrict__ dx_out, float* __restrict__ w_part, int rows,
                                                            int d, float eps, float post) {
-  extern __shared__ float part[];   // [4][d]
+  extern __shared__ float part[];   // [4][d]: each wave's dw contributions of its 4 rows, added in row order
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
   const int n4 = d >> 2;
   float* mypart = part + wave * d;
-  if (row < rows) {
+  for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(mypart)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int rr = 0; rr < NB_ROWS / 4; ++rr) {
+    const int row = blockIdx.x * NB_ROWS + rr * 4 + wave;
+    if (row >= rows) break;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
     const float4* gr = reinterpret_cast<const float4*>(dh + (size_t)row * d);
     const float4* wr = reinterpret_cast<const float4*>(w);
@@ -240,24 +244,24 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                              rs * post * g.z * ww.z - v.z * c, rs * post * g.w * ww.w - v.w * c);
       if (dres) { const float4 r = reinterpret_cast<const float4*>(dres + (size_t)row * d)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
       reinterpret_cast<float4*>(dx_out + (size_t)row * d)[i] = o;
-      reinterpret_cast<float4*>(mypart)[i] = make_float4(g.x * post * v.x * rs, g.y * post * v.y * rs, g.z * post * v.z * rs, g.w * post * v.w * rs);
+      float4 acc = reinterpret_cast<float4*>(mypart)[i];
+      acc.x += g.x * post * v.x * rs; acc.y += g.y * post * v.y * rs; acc.z += g.z * post * v.z * rs; acc.w += g.w * post * v.w * rs;
+      reinterpret_cast<float4*>(mypart)[i] = acc;
     }
-  } else {
-    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(mypart)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < d; k += 256)
     w_part[(size_t)blockIdx.x * d + k] = (part[k] + part[d + k]) + (part[2 * d + k] + part[3 * d + k]);
 }
 
-// out[k] (+)= sum over p of part[p][k]: 8 row groups per column add their contiguous share of the partials in order,
-// then the 8 group sums are added in order (deterministic, 8x shorter dependent chains than one thread per column)
+// out[k] (+)= sum over p of part[p][k]: a block owns 16 columns; 16 row groups add their contiguous share of the partials
+// in order, then the 16 group sums are added in order (deterministic, short dependent chains, d / 16 blocks)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int d,
                                                       int accumulate) {
-  __shared__ float red[8][32];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + col;
-  const int per = (nparts + 7) / 8, p0 = grp * per, p1 = min(nparts, p0 + per);
+  __shared__ float red[16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + col;
+  const int per = (nparts + 15) / 16, p0 = grp * per, p1 = min(nparts, p0 + per);
   float s = 0.f;
   if (k < d)
     for (int p = p0; p < p1; ++p) s += part[(size_t)p * d + k];
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   if (grp == 0 && k < d) {
     float t = 0.f;
 #pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8) t += red[g8][col];
+    for (int g16 = 0; g16 < 16; ++g16) t += red[g16][col];
     out[k] = accumulate ? out[k] + t : t;
   }
 }
@@ -274,10 +278,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
                               float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  const int nblk = (rows + 3) / 4;
+  const int nblk = (rows + NB_ROWS - 1) / NB_ROWS;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), s, x, w, dh, dres, dx_out, w_part, rows, d,
                      eps, post);
-  hipLaunchKernelGGL(colsum_kernel, dim3((d + 31) / 32), dim3(256), 0, s, w_part, dw, nblk, d, accumulate_dw);
+  hipLaunchKernelGGL(colsum_kernel, dim3((d + 15) / 16), dim3(256), 0, s, w_part, dw, nblk, d, accumulate_dw);
   return hipGetLastError();
 }
 
@@ -438,14 +442,22 @@ __global__ __launch_bounds__(256) void self_attn_bwd_kernel(const float* __restr
   }
 }
 
-// dbias[bucket][h] += sum over sequences s of part[(s*H + h)][bucket], in s order
-__global__ __launch_bounds__(64) void bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int S, int H,
-                                                          int buckets) {
-  const int h = blockIdx.x, b = threadIdx.x;
-  if (b >= buckets) return;
+// dbias[bucket][h] += sum over sequences s of part[(s*H + h)][bucket]: eight groups of sequences in parallel, each in s
+// order, then the eight partial sums in group order (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(512) void bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int S, int H,
+                                                           int buckets) {
+  __shared__ float red[8][64];
+  const int h = blockIdx.x, b = threadIdx.x & 63, grp = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += part[((size_t)s * H + h) * buckets + b];
-  dbias[b * H + h] += acc;
+  if (b < buckets)
+    for (int s = grp; s < S; s += 8) acc += part[((size_t)s * H + h) * buckets + b];
+  red[grp][b] = acc;
+  __syncthreads();
+  if (grp == 0 && b < buckets) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += red[k][b];
+    dbias[b * H + h] += t;
+  }
 }
 
 size_t self_attn_bwd_smem(int Ls, int buckets) {
@@ -460,7 +472,7 @@ hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t
   if (smem > 160 * 1024 || buckets > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(self_attn_bwd_kernel, dim3(S * H), dim3(256), smem, s, qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part, S, Ls,
                      H, buckets, causal);
-  hipLaunchKernelGGL(bias_reduce_kernel, dim3(H), dim3(64), 0, s, dbias_part, dbias, S, H, buckets);
+  hipLaunchKernelGGL(bias_reduce_kernel, dim3(H), dim3(512), 0, s, dbias_part, dbias, S, H, buckets);
   return hipGetLastError();
 }
 
@@ -709,13 +721,17 @@ __global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ 
   const size_t n = blockIdx.y ? n1 : n0;
   if ((size_t)blockIdx.x * 1024 >= n) return;
   float a = 0.f;
-  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
-      a = fmaxf(fmaxf(a, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
-    } else {
-      for (size_t j = i; j < n; ++j) a = fmaxf(a, fabsf(x[j]));
-    }
+  const size_t stride = (size_t)gridDim.x * 1024;
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  auto amax4 = [](const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  for (; i + 3 * stride + 3 < n; i += 4 * stride) {      // four independent loads in flight per lane
+    const float4 v0 = *reinterpret_cast<const float4*>(x + i), v1 = *reinterpret_cast<const float4*>(x + i + stride);
+    const float4 v2 = *reinterpret_cast<const float4*>(x + i + 2 * stride), v3 = *reinterpret_cast<const float4*>(x + i + 3 * stride);
+    a = fmaxf(a, fmaxf(fmaxf(amax4(v0), amax4(v1)), fmaxf(amax4(v2), amax4(v3))));
+  }
+  for (; i < n; i += stride) {
+    if (i + 3 < n) a = fmaxf(a, amax4(*reinterpret_cast<const float4*>(x + i)));
+    else for (size_t j = i; j < n; ++j) a = fmaxf(a, fabsf(x[j]));
   }
   for (int m = 32; m > 0; m >>= 1) a = fmaxf(a, __shfl_xor(a, m));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(256) void absmax2_kernel(const float* __restrict__ 
 hipError_t launch_absmax2(const float* x0, size_t n0, const float* x1, size_t n1, float* out, hipStream_t s) {
   const size_t n = std::max(n0, x1 ? n1 : 0);
   if (n == 0) return hipSuccess;
-  const int nb = (int)std::min<size_t>(2048, (n + 4095) / 4096);   // >= 4 float4 per thread before another block pays off
+  const int nb = (int)std::min<size_t>(2048, (n + 8191) / 8192);   // >= 8 float4 per thread before another block pays off
   hipLaunchKernelGGL(absmax2_kernel, dim3(nb, x1 ? 2 : 1), dim3(256), 0, s, x0, n0, x1, x1 ? n1 : 0,
                      reinterpret_cast<unsigned int*>(out));
   return hipGetLastError();
