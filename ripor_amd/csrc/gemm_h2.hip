@@ -51,7 +51,9 @@ constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 template <int BM, int BN, int WM, int WN, bool FULL, int STAGES = 2>
 __global__ __launch_bounds__(64 * WM * WN, STAGES > 2 ? 1 : (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
 void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
+  // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
+  // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
   constexpr int NW = WM * WN;                    // waves per block
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA 32x32 tiles per wave
   constexpr int ROWS = 2 * (BM + BN);            // LDS rows of 32 halves (64 B) per buffer
@@ -219,7 +221,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         const bool ok = nok && (FULL || m < Mlim);
-        float v = acc[i][j][r] * g.acc_scale;
+        float v = acc[i][j][r] * acc_scale;
         if (g.row_ssq) v *= rs[r];
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.resid || g.resid_h) v = res[r] + v;
@@ -253,7 +255,8 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
 template <bool FULL, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
-                                                int lane, int bm, int bn, int wm, int wn, const float* rs_tile) {
+                                                int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
+                                                float acc_scale) {
   constexpr int BM = 256, BN = 256;
   // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
@@ -304,7 +307,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         const bool ok = ncol_ok && (FULL || m < Mlim);
-        const float sc = rs_tile ? g.acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : g.acc_scale;
+        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : acc_scale;
         float v[8];
         *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
         *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
@@ -358,7 +361,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-        const float sc = rs_tile ? g.acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : g.acc_scale;   // fused RMSNorm row scale
+        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : acc_scale;   // fused RMSNorm row scale
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
@@ -384,7 +387,9 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // last reads are retired before the other group starts overwriting it.
 template <bool FULL, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
+  // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
+  // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
   constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 #undef PP_M_END
 #undef PP_STAMP
 
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr);
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
 }
 
 // ---- skinny variant: M <= 400 rows (one to a few dozen queries in flight) ---------------------------------------
@@ -565,7 +570,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 // accumulators are added in the fixed order 0..3 through LDS and wave 0 runs the epilogue — deterministic.
 template <bool FULL>
 __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  if (g.dyn_a) g.acc_scale = 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b));   // per-tensor scales (training)
+  // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
+  // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
   constexpr int BM = 32, BN = 32, ST = 4, ROWS = 2 * (BM + BN), PIECES = ROWS / 16;   // 8 KB per stage, 8 pieces
   __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];             // 128 KB
   const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   for (int r = 0; r < 16; ++r) {
     const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
     const bool mok = FULL || m < g.M, ok = nok && mok;
-    float v = acc[r] * g.acc_scale;
+    float v = acc[r] * acc_scale;
     if (g.row_ssq && mok) v *= ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.resid && ok) v = g.resid[(size_t)m * g.ldr + n] + v;
