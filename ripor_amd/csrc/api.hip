@@ -260,6 +260,15 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   const bool h2 = c->precision == RPR_PREC_F16X2;
   const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
+  // debug: RPR_SELECT_CLOCK=1 prints the phase durations of the selection kernel (eager launches only)
+  unsigned long long* sel_clk = nullptr;
+  {
+    static const bool clk_env = [] { const char* e = getenv("RPR_SELECT_CLOCK"); return e && atoi(e) != 0; }();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (clk_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
+        hipMalloc(&sel_clk, (size_t)L * 8 * sizeof(unsigned long long)) == hipSuccess)
+      hipMemset(sel_clk, 0, (size_t)L * 8 * sizeof(unsigned long long));
+  }
   // index of the last attended key + 1 per query: row packing of the encoder and the cross-attention loop bound
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s, c->status + 1); });
   static const bool packed_env = [] { const char* e = getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
@@ -383,7 +392,19 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
       sa.tap_parent = taps->step_parent ? taps->step_parent + (size_t)t * R : nullptr;
       sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
     }
+    if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
     Ln.run(RPR_K_SELECT, 0, (double)R * V * 4 + (double)R * 40, [&] { return launch_select(sa, s); });
+  }
+  if (sel_clk) {   // debug: phase durations of the selection kernel (block 0), 100 MHz wall clock
+    hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)L * 8);
+    hipMemcpy(h.data(), sel_clk, h.size() * 8, hipMemcpyDeviceToHost);
+    for (int t = 0; t < L; ++t) {
+      fprintf(stderr, "[select t=%2d] us:", t);
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %7.1f", (double)(h[t * 8 + k + 1] - h[t * 8 + k]) * 0.01);
+      fprintf(stderr, "  rounds=%llu\n", h[t * 8 + 7]);
+    }
+    hipFree(sel_clk);
   }
   FinalizeArgs fa{beam_state(w, L & 1, L), Q, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
                   P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};

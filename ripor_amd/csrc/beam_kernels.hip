@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   float* slog = lsum + B;                                                // [B*V] logits of the query (a.lds_logits)
 
   const int r0 = q * B;
+  auto stamp = [&](int k) { if (a.clk && q == 0 && tid == 0) a.clk[k] = wall_clock64(); };
+  stamp(0);
   for (int b = tid; b < B; b += 256) {
     bscore[b] = a.cur.score[r0 + b];
     blo[b] = a.cur.lo[r0 + b];
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       if (lane == 0) valid[it >> 6] = m;
     }
   }
+  stamp(1);
   if (t == 0 && B > 1) {   // replicate beam 0's row (same root range for every beam)
     __syncthreads();
     if (bhi[0] - blo[0] > NARROW) {
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
   }
   __syncthreads();
+  stamp(2);
   if (a.tap_valid)   // debug tap: the child bitmap the selection below works from (tests/test_gpu_parity.py)
     for (int w = tid; w < words; w += 256) a.tap_valid[(size_t)q * words + w] = valid[w];
 
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       }
     }
   }
+  stamp(3);
   int left = own < TK ? own : TK;        // entries of the list not yet consumed
   const bool more = own > TK;            // candidates beyond the list exist
   int* resc = red_i + 4;                 // LDS flag: the winner's wave must rescan for it
@@ -301,6 +306,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       need_rounds = false;
     }
   }
+  stamp(4);
+  if (a.clk && q == 0 && tid == 0) a.clk[7] = need_rounds ? 1 : 0;
   if (need_rounds) {   // block-uniform
   Cand mine; mine.s = ts[0]; mine.item = ti[0];
   for (int j = 0; j < B; ++j) {
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
   }
   __syncthreads();
+  stamp(5);
 
   // ---- phase D: write the next beam state (new slot j <- winner j) ----
   const int ld = a.cur.ld;
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     a.nxt.tokens[(size_t)(r0 + j) * ld + p] = a.cur.tokens[(size_t)(r0 + b) * ld + p];
     a.nxt.anc[(size_t)(r0 + j) * ld + p] = a.cur.anc[(size_t)(r0 + b) * ld + p];
   }
+  stamp(6);
 }
 
 constexpr int SEL_TK_HOST = 16;   // list length of the sorted path

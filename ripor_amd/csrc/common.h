@@ -241,6 +241,7 @@ struct SelectArgs {
   // debug taps for step t (nullable)
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
   unsigned long long* tap_valid;                                   // [Q, B*V/64] phase-A child bitmap (bit = beam*V + token)
+  unsigned long long* clk;   // debug (RPR_SELECT_CLOCK=1, eager mode): 8 wall-clock stamps of block 0 at the phase boundaries
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
