@@ -245,8 +245,10 @@ int rpr_lngknp_forward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids,
  *
  * rpr_lngknp_backward: forward (activations kept in library-owned memory) + backward of the sum of the n_prefix
  *   margin-MSE losses; same batch arguments as rpr_lngknp_forward with n_docs = 2; writes out_losses [dev, n_prefix]
- *   and overwrites flat_grads [dev, rpr_param_total]. fp32 activations and gradients, exact-fp32 MFMA products,
- *   deterministic reductions. Lq <= 128, L <= the model's decoder length.
+ *   and overwrites flat_grads [dev, rpr_param_total]. fp32 activations and gradients; the matrix products follow the
+ *   context's precision (rpr_set_precision): RPR_PREC_F16X2 (default) = split-precision f16 MFMA with per-tensor
+ *   dynamic plane scales found on the device, RPR_PREC_F32 = exact-fp32 MFMA. Deterministic reductions in both.
+ *   Lq <= 128, L <= the model's decoder length.
  * rpr_adamw_step: global L2 norm of flat_grads (-> out_grad_norm [dev, 1], nullable), clip coefficient
  *   min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no clipping), AdamW update of every tensor with the
  *   bias corrections of `step` (1-based), then the f16 weight planes of the search path are refreshed (synchronises
