@@ -293,7 +293,7 @@ def search_batch_size(cfg, batch_size: int, topk: int, max_new_token: int, flag:
     for many queries in flight and its results do not depend on how queries are batched (tests/test_gpu_fullsize.py),
     so by default (``--search_batch_size=-1``) the tasks regroup the query stream into the largest batch whose
     workspace (dominated by the self-attention KV cache, 2*Ndec*L*B*inner*4 bytes per query) fits ~60 % of the free
-    HBM, capped at 2048. ``--search_batch_size=0`` keeps ``--batch_size``; a positive value is used as given."""
+    HBM, capped at 2176 and aligned to whole rounds of GEMM tiles (``align_to_gemm_rounds``). ``--search_batch_size=0`` keeps ``--batch_size``; a positive value is used as given."""
     if flag == 0:
         return batch_size
     if flag > 0:
@@ -306,8 +306,30 @@ def search_batch_size(cfg, batch_size: int, topk: int, max_new_token: int, flag:
         free, _ = torch.cuda.mem_get_info(device)
     except Exception:
         free = 64 << 30
-    auto = int(0.6 * free // per_query)
-    return max(batch_size, min(2048, max(1, auto)))
+    auto = max(1, min(2176, int(0.6 * free // per_query)))
+    return max(batch_size, align_to_gemm_rounds(auto, topk, cfg.d_model))
+
+
+def align_to_gemm_rounds(q_max: int, beams: int, d_model: int) -> int:
+    """Largest Q <= q_max (but not below 0.75 q_max) whose Q*beams decoder rows fill whole rounds of 256x256 GEMM tiles
+    on the 256 CUs for the d_model-wide projections (then also for the 3x / 4x wider ones): a launch just over a whole
+    number of rounds leaves most of the chip idle in its last round. Measured: t5-large, beam 100: 160 queries in
+    flight (63 row tiles x 4 = 252 tiles) 116.8 q/s vs 108.7 q/s at 128 (200 tiles); t5-base, beam 10: 2176 -> 255 tiles.
+    Small batches (less than one round of tiles) are left alone."""
+    cols = max(1, (d_model + 255) // 256)
+    def eff(q):
+        tiles = ((q * beams + 255) // 256) * cols
+        return tiles / float(((tiles + 255) // 256) * 256)
+    if ((q_max * beams + 255) // 256) * cols < 200:
+        return q_max
+    best, best_eff = q_max, eff(q_max)
+    for q in range(q_max, max(1, int(0.75 * q_max)) - 1, -1):
+        e = eff(q)
+        if e > best_eff + 0.02:
+            best, best_eff = q, e
+        if best_eff >= 0.98:
+            break
+    return best
 
 
 def ddp_setup():
