@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048, help="queries in flight per step per GPU")
+    ap.add_argument("--batch", type=int, default=2176, help="queries in flight per step per GPU (2176 x 10 beams = 85 row tiles of 256: 255 / 765 / 1020 GEMM tiles = whole rounds of the 256 CUs)")
     ap.add_argument("--beams", type=int, default=10)
     ap.add_argument("--len", type=int, default=32, dest="L")
     ap.add_argument("--docs", type=int, default=MSMARCO_DOCS)

@@ -10,7 +10,7 @@ timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 -x -s "$@" > $OUT/pyt
 echo "pytest rc=$?" | tee -a $OUT/pytest.log
 grep -E "^\[parity\]|^\[select\]|passed|failed|error" $OUT/pytest.log | tail -40
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
-timeout 300 python tools/gemm_bench.py 20480 > $OUT/gemm_bench.log 2>&1; cat $OUT/gemm_bench.log | tail -8
+timeout 300 python tools/gemm_bench.py 21760 > $OUT/gemm_bench.log 2>&1; cat $OUT/gemm_bench.log | tail -8
 timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.log; echo "bench rc=$?"
 tail -5 $OUT/bench.log; python - <<PY
 import json
