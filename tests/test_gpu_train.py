@@ -237,3 +237,72 @@ def test_lngknp_backward_matches_oracle_autograd_at_t5_base_dims():
     assert abs(hn - gn) <= 1e-3 * gn
     print(f"[train-bwd] f4_base_bz4_l32 vs oracle autograd: worst tensor p99.9 error {worst[0]:.2e} ({worst[1]}), median "
           f"{np.median(rels):.2e}, global norm {hn:.6g} vs {gn:.6g}")
+
+
+@pytest.mark.parametrize("variant", ["shared_codebooks", "scaleup_hidden", "odd_batch_l16"])
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_lngknp_backward_variants_match_oracle_autograd(variant, precision):
+    """Model / batch variants the reference fixtures do not cover: input and output codebooks shared (one gradient tensor
+    receives both scatter paths), scaleup_output_hidden (d_model**-0.5 ... post factor through the final norm), an odd
+    batch of ragged queries whose padded length is not a multiple of 8, L = 16. Reference: autograd through the CPU
+    oracle (pinned to the reference's gradients on the f4 fixtures), whole tensors."""
+    from oracle import t5_ref, train_ref
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    kw = dict(shared_codebooks=dict(shared_output_input_embeds=True), scaleup_hidden=dict(scaleup_output_hidden=True),
+              odd_batch_l16={})[variant]
+    L, bz = (16, 5) if variant == "odd_batch_l16" else (8, 3)
+    dims = synth.mini_dims(L=L, V=256, **kw)
+    # seed 92: no FF pre-activation of this model falls within fp32 noise of 0 for these inputs (seeds 91 and 95 have one:
+    # the ReLU gate then takes different sides in the two implementations and one row of that wi gradient differs
+    # completely — tools/debug_train_variant.py shows the single-row signature). One oracle thread = one summation order.
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    sd = synth.make_state_dict(dims, seed=92)
+    ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=17, mean_len=9, std_len=3, min_len=5, max_len=13)
+    codes = synth.make_codes(2 * bz, L, 256, seed=23).astype(np.int64)
+    pos, neg = codes[:bz], codes[bz:]
+    prefix = train_ref.PREFIX_LENS[L]
+    teacher = {}
+    for k in prefix:
+        key = "" if k == L else train_ref.TEACHER_KEYS[k]
+        teacher[key + "teacher_pos_scores"] = synth.uniform_f32(f"var/{variant}/p{k}", (bz,), 30.0)
+        teacher[key + "teacher_neg_scores"] = synth.uniform_f32(f"var/{variant}/n{k}", (bz,), 30.0)
+    try:
+        ref_losses, _, og, gn = train_ref.train_step(t5_ref.T5Ref(sd, dims), ids, mask, pos, neg, teacher)
+    finally:
+        torch.set_num_threads(prev_threads)
+
+    ctx = E.Context.get(0)
+    ctx.set_precision(precision)
+    try:
+        model = E.DeviceModel(ctx, sd, dims)
+        state = E.TrainState(model)
+        tp = torch.from_numpy(np.stack([teacher[("" if k == L else train_ref.TEACHER_KEYS[k]) + "teacher_pos_scores"] for k in prefix]))
+        tn = torch.from_numpy(np.stack([teacher[("" if k == L else train_ref.TEACHER_KEYS[k]) + "teacher_neg_scores"] for k in prefix]))
+        dc = torch.from_numpy(np.stack([pos, neg], axis=1))
+        losses = E.lngknp_backward(model, state, torch.from_numpy(ids), torch.from_numpy(mask), dc, tp, tn, prefix)
+        torch.cuda.synchronize()
+        for i, name in enumerate(train_ref.LOSS_NAMES[L]):
+            ref = float(ref_losses[name])
+            assert abs(float(losses[i]) - ref) <= 1e-4 * max(1.0, abs(ref)), (variant, name, float(losses[i]), ref)
+        grads = {k: v.detach().cpu().double().numpy() for k, v in state.named_grads().items()}
+        # every tensor within 2e-4 of its largest entry (measured: 5e-6)
+        worst, worst_vec = (0.0, None), (0.0, None)
+        for k, v in grads.items():
+            o = og[k].double().numpy().reshape(v.shape)
+            err = np.abs(v - o).max() / max(np.abs(o).max(), 1e-30)
+            if v.ndim == 1 or "layer_norm" in k:
+                worst_vec = max(worst_vec, (err, k))
+                assert err <= 2e-4, (variant, precision, k, err)
+            else:
+                worst = max(worst, (err, k))
+                assert err <= 2e-4, (variant, precision, k, err)
+        hn = float(np.sqrt(sum((v ** 2).sum() for v in grads.values())))
+        assert abs(hn - gn) <= 1e-3 * gn
+        if variant == "shared_codebooks":
+            assert not any(k.startswith("list_output_embeds") for k in grads)
+        print(f"[train-bwd] {variant} {precision}: worst matrix error {worst[0]:.2e} of its largest entry ({worst[1]}), worst "
+              f"layer-norm vector {worst_vec[0]:.2e} ({worst_vec[1]}), norm {hn:.6g}")
+    finally:
+        ctx.set_precision("f16x2")
