@@ -116,3 +116,31 @@ def test_docid_to_smtid_streaming_reader(lib, tmp_path):
             E.read_docid_to_smtid(str(p))
     with pytest.raises(RiporHipError):
         E.read_docid_to_smtid(str(tmp_path / "missing.json"))
+
+
+def test_hot_gemm_kernels_use_no_scratch():
+    """The ping-pong GEMM instantiations of the search path must not touch scratch memory: a register spill, or a
+    private copy of the by-value argument struct (what writing to one of its fields costs: 320 B/lane, +20 % per launch,
+    3470 -> 3059 queries/s), shows up as ScratchSize > 0 in the compiler's resource remarks long before a GPU run."""
+    import re
+    import subprocess
+    import tempfile
+    import __graft_entry__ as ge
+    src = os.path.join(ge.CSRC, "gemm_h2.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
+                            os.path.join(tmp, "g.o"), "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            usage[name] = int(m.group(1))
+    hot = [k for k in usage if "gemm_h2_pp_kernelILb1E" in k or "gemm_h2_skinny" in k or
+           ("gemm_h2_dma_kernel" in k and "Lb1E" in k)]
+    assert len(hot) >= 5, sorted(usage)
+    assert all(usage[k] == 0 for k in hot), {k: usage[k] for k in hot if usage[k]}
