@@ -587,38 +587,52 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
     *reinterpret_cast<float4*>(Vs + j * DKV + c) = vv;
   }
   __syncthreads();
-  // scores: one thread per (beam, key) pair; four partial sums break the dependent FMA chain
-  for (int pair = tid; pair < B * Lq; pair += 256) {
+  // scores: two threads per (beam, key) pair, 32 dims each (B * Lq is ~120 pairs for 10 beams: one thread per pair
+  // left half of the block idle and made the 16-deep float4 loop the longest serial piece); four partial sums break
+  // the dependent FMA chain, the two halves meet through one shuffle
+  for (int p2 = tid; p2 < 2 * B * Lq; p2 += 256) {     // B * Lq * 2 and 256 are even: both halves of a pair are in range together
+    const int pair = p2 >> 1, hlf = p2 & 1;
     const int b = pair / Lq, j = pair - b * Lq;
-    float sv = -INFINITY;
-    if (mrow[j] != 0) {
-      const float4* qr = reinterpret_cast<const float4*>(Qs + b * QS_LD);
-      const float4* kr = reinterpret_cast<const float4*>(Ks + j * XK_LD);
+    float sv = 0.f;
+    const bool live = mrow[j] != 0;
+    if (live) {
+      const float4* qr = reinterpret_cast<const float4*>(Qs + b * QS_LD) + hlf * (DKV / 8);
+      const float4* kr = reinterpret_cast<const float4*>(Ks + j * XK_LD) + hlf * (DKV / 8);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int d = 0; d < DKV / 4; ++d) {
+      for (int d = 0; d < DKV / 8; ++d) {
         const float4 q4 = qr[d], k4 = kr[d];
         a0 = fmaf(q4.x, k4.x, a0); a1 = fmaf(q4.y, k4.y, a1);
         a2 = fmaf(q4.z, k4.z, a2); a3 = fmaf(q4.w, k4.w, a3);
       }
       sv = (a0 + a1) + (a2 + a3);
     }
-    S[b * SLD + j] = sv;
+    sv += __shfl_xor(sv, 1, 64);
+    if (hlf == 0) S[b * SLD + j] = live ? sv : -INFINITY;
   }
   __syncthreads();
-  // softmax + P.V: one thread per (beam, 4 output dims). Every thread recomputes its beam's max and
-  // exp-sum from the score row (broadcast LDS reads): no cross-lane reductions — the wave-shuffle
-  // softmax was a chain of ~36 dependent ds_bpermute latencies per block and dominated the kernel.
-  for (int item = tid; item < B * 16; item += 256) {
-    const int b = item >> 4, c = (item & 15) * 4;
+  // softmax numerators: the thread that owns a (beam, key) score turns it into exp(s - max of the beam's row) — one exp
+  // per pair instead of one per (pair, 16 output lanes); the row maximum comes from broadcast LDS reads of the row
+  // (a wave-shuffle reduction here was a chain of dependent ds_bpermute latencies and dominated the kernel). The
+  // numerators go to a second array: other threads are still reading the scores of the row.
+  float* P = S + (size_t)(a.bchunk ? a.bchunk : Bq) * SLD;      // [B][Lq+1]
+  for (int pair = tid; pair < B * Lq; pair += 256) {
+    const int b = pair / Lq, j = pair - b * Lq;
     const float* row = S + b * SLD;
     float mx = -INFINITY;
-    for (int j = 0; j < Lq; ++j) mx = fmaxf(mx, row[j]);
+    for (int k = 0; k < Lq; ++k) mx = fmaxf(mx, row[k]);
+    const float sv = row[j];
+    P[b * SLD + j] = (sv == -INFINITY) ? 0.f : expf(sv - mx);
+  }
+  __syncthreads();
+  // P.V: one thread per (beam, 4 output dims)
+  for (int item = tid; item < B * 16; item += 256) {
+    const int b = item >> 4, c = (item & 15) * 4;
+    const float* row = P + b * SLD;
     float sum = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < Lq; ++j) {
-      const float sv = row[j];
-      const float e = (sv == -INFINITY) ? 0.f : expf(sv - mx);
+      const float e = row[j];
       sum += e;
       const float4 v4 = *reinterpret_cast<const float4*>(Vs + j * DKV + c);
       o.x = fmaf(e, v4.x, o.x); o.y = fmaf(e, v4.y, o.y); o.z = fmaf(e, v4.z, o.z); o.w = fmaf(e, v4.w, o.w);
@@ -642,7 +656,7 @@ hipError_t init_t5_kernel_attributes() {
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   DecCrossAttnArgs a = a_in;
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
-  auto smem_for = [&](int nb) { return ((size_t)a.Lq * (XK_LD + DKV) + (size_t)nb * (QS_LD + a.Lq + 1) + 4) * sizeof(float); };
+  auto smem_for = [&](int nb) { return ((size_t)a.Lq * (XK_LD + DKV) + (size_t)nb * (QS_LD + 2 * (a.Lq + 1)) + 4) * sizeof(float); };
   a.bchunk = 0;
   int chunks = 1;
   if (smem_for(a.B) > 64 * 1024) {   // large beams: split the query's beams over blockIdx.y (K/V re-staged per chunk)
