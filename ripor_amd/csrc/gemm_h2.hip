@@ -31,6 +31,8 @@ namespace rpr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 
@@ -308,24 +310,32 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         const bool ok = ncol_ok && (FULL || m < Mlim);
         const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : acc_scale;
-        float v[8];
-        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
-        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
-        __half h[8], l[8];
-        float ss = 0.f, am = 0.f;
+        // pairs of columns as 2-vectors: gfx950 multiplies / adds / fmas two fp32 per instruction (v_pk_*_f32) and
+        // converts two floats to a packed f16 pair in one (v_cvt_pk_f16_f32, round to nearest) — about half the VALU
+        // work of the element-by-element form, which also spent a shift + or per pair on packing
+        f32x2 v[4];
+        *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
+        *reinterpret_cast<float4*>(&v[2]) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
+        f16x2 h[4], l[4];
+        f32x2 ss2 = {0.f, 0.f};
+        float am = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * sc;
-          if (g.relu) x = fmaxf(x, 0.f);
-          if (g.resid_h) x += __half2float(reinterpret_cast<const __half*>(&rh[k])[e]) +
-                              __half2float(reinterpret_cast<const __half*>(&rl_[k])[e]);   // X_PLANE_SCALE == 1
-          ss = fmaf(x, x, ss);
-          float xs = x * ps;
-          am = fmaxf(am, fabsf(xs));
-          xs = __builtin_amdgcn_fmed3f(xs, -65504.f, 65504.f);
-          h[e] = __float2half_rn(xs);
-          l[e] = __float2half_rn(xs - __half2float(h[e]));
+        for (int e = 0; e < 4; ++e) {
+          f32x2 x = v[e] * sc;
+          if (g.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); }
+          if (g.resid_h) {   // X_PLANE_SCALE == 1
+            x += __builtin_convertvector(reinterpret_cast<const f16x2*>(&rh[k])[e], f32x2) +
+                 __builtin_convertvector(reinterpret_cast<const f16x2*>(&rl_[k])[e], f32x2);   // hi + lo is exact in fp32
+          }
+          ss2 += x * x;
+          f32x2 xs = x * ps;
+          am = fmaxf(am, fmaxf(fabsf(xs.x), fabsf(xs.y)));
+          xs.x = __builtin_amdgcn_fmed3f(xs.x, -65504.f, 65504.f);
+          xs.y = __builtin_amdgcn_fmed3f(xs.y, -65504.f, 65504.f);
+          h[e] = __builtin_convertvector(xs, f16x2);
+          l[e] = __builtin_convertvector(xs - __builtin_convertvector(h[e], f32x2), f16x2);
         }
+        float ss = ss2.x + ss2.y;
         if (ok) {
           *reinterpret_cast<uint4*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(h);
           *reinterpret_cast<uint4*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(l);
