@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2176, help="queries in flight per step per GPU (2176 x 10 beams = 85 row tiles of 256: 255 / 765 / 1020 GEMM tiles = whole rounds of the 256 CUs)")
+    ap.add_argument("--batch", type=int, default=None, help="queries in flight per step per GPU; default 2150 = two lanes of 1075 queries (10 750 rows = 42 row tiles of 256: 126 / 378 / 504 GEMM tiles = whole rounds of a lane's 128 CUs), 2176 with --no-lanes (85 row tiles: 255 / 765 / 1020 tiles on 256 CUs)")
     ap.add_argument("--beams", type=int, default=10)
     ap.add_argument("--len", type=int, default=32, dest="L")
     ap.add_argument("--docs", type=int, default=MSMARCO_DOCS)
@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-lanes", action="store_true",
+                    help="one stream for the whole batch instead of two half batches on two CU-masked streams")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"],
                     help="GEMM arithmetic: f16x2 = fp32 operands as two f16 planes, 3 f16 MFMAs per product "
                          "(fp32-equivalent to ~2^-22); f32 = exact fp32 MFMA")
@@ -190,6 +192,13 @@ def main():
     sd = synth.make_state_dict(dims)
     ctx = E.Context.get(local_rank)
     ctx.set_precision(args.precision)
+    if args.no_lanes:
+        ctx.set_lane_split(0)
+    if args.batch is None:
+        args.batch = 2150 if ctx.lane_split() > 0 else 2176
+    Q = args.batch
+    lane_min_q = ctx.lane_split()
+    lanes_on = 0 < lane_min_q <= Q
     model = E.DeviceModel(ctx, sd, dims)
     log(f"[bench r{rank}] weights ({sum(v.size for v in sd.values()) / 1e6:.1f} M params) on device in {time.time() - t0:.1f}s")
     t0 = time.time()
@@ -302,69 +311,96 @@ def main():
                                    f"{Q} queries/step/GPU (MSMARCO-dev-shaped, mean {mean_len:.1f} tokens, padded to {lq_used})",
                        "queries_per_step_per_gpu": Q, "beams": B, "len": L, "docs": trie.N, "enc_len_padded": lq_used,
                        "parallelism": f"query-sharded x{world}, replicated weights+trie, final RCCL all_gather",
-                       "hipgraph": not args.no_graph, "gemm_precision": args.precision},
+                       "hipgraph": not args.no_graph, "gemm_precision": args.precision,
+                       "lanes": ("2 half batches on 2 HIP streams confined to half of the CUs each (rpr_set_lane_split)"
+                                 if lanes_on else "1 (whole batch on one stream)")},
             "algorithmic": {"bytes_per_query": abytes, "flops_per_query": aflops, "tokens_per_query": lq_alg,
                             "hbm_frac_whole_step": abytes * Q / (ms_per_step * 1e-3) / (PEAK_HBM_TBS * 1e12),
                             "mfma_f32_frac_whole_step": aflops * Q / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
         }
         log(f"[bench] timed region done: {value:.1f} queries/s, {ms_per_step:.1f} ms/step")
         if not args.no_roofline:
-            ctx.profile_reset()
-            ctx.profile_enable(True)
-            run_step(W)  # one eager step, hipEvents around every launch on the launch stream
-            torch.cuda.synchronize()
-            stats = ctx.profile_get()
-            ctx.profile_enable(False)
-            log("[bench] roofline leg done")
-            g = stats["gemm"]           # launches of the dominant kernel only (256x256 ping-pong / fp32 MFMA kernel);
-            gs = stats["gemm_small"]    # the few small-tile launches (encoder tail, logits of step 0) are listed apart
-            small_only = g["launches"] == 0      # a handful of rows in flight: every GEMM runs on the small-tile kernels
-            if small_only:
-                g, gs = gs, g
-            ach = g["flops"] / max(1e-9, g["total_ms"] * 1e-3) / 1e12
-            if args.precision == "f32":
-                kname, peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
-            else:
-                kname, peak = "rpr::gemm_h2_pp_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
+            def profiled_step():
+                ctx.profile_reset()
+                ctx.profile_enable(True)
+                run_step(W)  # one eager step, hipEvents around every launch on the stream it is launched on
+                torch.cuda.synchronize()
+                st = ctx.profile_get()
+                ctx.profile_enable(False)
+                return st
+
+            def gemm_roofline(stats, cu_fraction, with_traffic=True):
+                g = stats["gemm"]           # launches of the dominant kernel only (256x256 ping-pong / fp32 MFMA kernel);
+                gs = stats["gemm_small"]    # the few small-tile launches (encoder tail, logits of step 0) are listed apart
+                small_only = g["launches"] == 0      # a handful of rows in flight: every GEMM runs on the small-tile kernels
                 if small_only:
-                    kname = "rpr::gemm_h2_dma_kernel / rpr::gemm_h2_skinny_kernel"
-                note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
-                        "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3 at the nominal 2.4 GHz; the in-kernel "
-                        "s_memtime/s_memrealtime trace (tools/gemm_trace_pp.py) shows the chip sustaining 1.64-1.76 GHz "
-                        "under this kernel (DVFS), i.e. ~0.6 of the peak at the sustained clock")
-            traffic, traffic_src = None, None
-            pmc_path = os.path.join(REPO, "profiles", "latest_hbm_pmc.json")
-            if os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
-                try:
-                    pmc = json.load(open(pmc_path))
-                    key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel<true" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
-                    if key:
-                        # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
-                        traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
-                        traffic_src = ("profiles/latest_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
-                                       "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
-                        # the counters come from an earlier profiled run of tools/profile_round.sh: refuse them when that
-                        # run's launch count per step no longer matches this build's (kernels changed since)
-                        kn = "gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel"
-                        n_pmc = sum(v["launches"] for k, v in pmc["FETCH_SIZE"].items() if isinstance(v, dict) and kn in k)
-                        n_pmc /= float(pmc.get("_meta", {}).get("steps_in_pmc_pass", 1))
-                        if abs(n_pmc - g["launches"]) > 0.5:
-                            traffic_src = (f"stale: profiles/latest_hbm_pmc.json has {n_pmc:g} launches of the kernel per step, "
-                                           f"this build {g['launches']}; re-run tools/profile_round.sh")
-                            traffic = None
-                except Exception:
-                    pass
-            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach,
-                               "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "note": note,
-                               "traffic": traffic, "traffic_source": traffic_src,
-                               "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
-                               "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
-                               "launches_per_step": g["launches"],
-                               "flops_per_launch": g["flops"] / max(1, g["launches"]),
-                               "other_gemm_launches": {"launches_per_step": gs["launches"], "total_ms": gs["total_ms"],
-                                                       "tflops": gs["flops"] / max(1e-9, gs["total_ms"] * 1e-3) / 1e12}}
-            tot = sum(s["total_ms"] for s in stats.values())
-            out["kernel_breakdown_ms"] = {k: round(s["total_ms"], 3) for k, s in stats.items()}
+                    g, gs = gs, g
+                ach = g["flops"] / max(1e-9, g["total_ms"] * 1e-3) / 1e12
+                if args.precision == "f32":
+                    kname, full_peak, note = "rpr::gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+                else:
+                    kname, full_peak = "rpr::gemm_h2_pp_kernel", PEAK_F16_MFMA_TFLOPS / 3.0
+                    if small_only:
+                        kname = "rpr::gemm_h2_dma_kernel / rpr::gemm_h2_skinny_kernel"
+                    note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
+                            "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3 at the nominal 2.4 GHz; the in-kernel "
+                            "s_memtime/s_memrealtime trace (tools/gemm_trace_pp.py) shows the chip sustaining 1.64-1.76 GHz "
+                            "under this kernel (DVFS), i.e. ~0.6 of the peak at the sustained clock")
+                peak = full_peak * cu_fraction
+                if cu_fraction != 1.0:
+                    note += (f"; LANES: every launch of the timed region is one half batch on a HIP stream confined to "
+                             f"{cu_fraction:.2f} of the CUs (hipExtStreamCreateWithCUMask), the other half batch runs beside it "
+                             f"on the other CUs, so the peak of a launch is {cu_fraction:.2f} x the chip's "
+                             f"({full_peak:.1f} TF/s); roofline_unsplit = the same kernel launched on the whole chip "
+                             f"(bench.py --no-lanes)")
+                traffic, traffic_src = None, None
+                pmc_path = os.path.join(REPO, "profiles", "latest_hbm_pmc.json")
+                if with_traffic and os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
+                    try:
+                        pmc = json.load(open(pmc_path))
+                        key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel<true" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                        if key:
+                            # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
+                            traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
+                            traffic_src = ("profiles/latest_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
+                                           "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
+                            # the counters come from an earlier profiled run of tools/profile_round.sh: refuse them when that
+                            # run's launch count per step no longer matches this build's (kernels changed since)
+                            kn = "gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel"
+                            n_pmc = sum(v["launches"] for k, v in pmc["FETCH_SIZE"].items() if isinstance(v, dict) and kn in k)
+                            n_pmc /= float(pmc.get("_meta", {}).get("steps_in_pmc_pass", 1))
+                            if abs(n_pmc - g["launches"]) > 0.5:
+                                traffic_src = (f"stale: profiles/latest_hbm_pmc.json has {n_pmc:g} launches of the kernel per step, "
+                                               f"this run {g['launches']}; re-run tools/profile_round.sh")
+                                traffic = None
+                    except Exception:
+                        pass
+                return {"kernel": kname, "bound": "mfma", "achieved": ach,
+                        "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "cu_fraction": cu_fraction,
+                        "peak_whole_chip": full_peak, "note": note,
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
+                        "avg_launch_us": g["total_ms"] * 1e3 / max(1, g["launches"]),
+                        "launches_per_step": g["launches"],
+                        "flops_per_launch": g["flops"] / max(1, g["launches"]),
+                        "other_gemm_launches": {"launches_per_step": gs["launches"], "total_ms": gs["total_ms"],
+                                                "tflops": gs["flops"] / max(1e-9, gs["total_ms"] * 1e-3) / 1e12}}
+
+            stats = profiled_step()     # the timed configuration (two lanes when the batch is split)
+            log("[bench] roofline leg done")
+            out["roofline"] = gemm_roofline(stats, 0.5 if lanes_on else 1.0)
+            out["lanes"] = 2 if lanes_on else 1
+            if lanes_on:
+                # the same step on one stream with every launch on the whole chip: the kernel's own quality, comparable with
+                # earlier rounds; the per-kernel breakdown and the HBM roofline below come from this step (in lane mode two
+                # kernels run at any time and their durations add up to about twice the wall clock)
+                out["kernel_breakdown_lanes_ms"] = {k: round(v["total_ms"], 3) for k, v in stats.items()}
+                ctx.set_lane_split(0)
+                stats = profiled_step()
+                ctx.set_lane_split(lane_min_q)
+                out["roofline_unsplit"] = gemm_roofline(stats, 1.0, with_traffic=False)
+            tot = sum(v["total_ms"] for v in stats.values())
+            out["kernel_breakdown_ms"] = {k: round(v["total_ms"], 3) for k, v in stats.items()}
             out["kernel_breakdown_ms"]["sum"] = round(tot, 3)
             sa = stats["dec_self_attn"]
             if sa["total_ms"] > 0:

@@ -106,6 +106,8 @@ SIGNATURES = {
     "rpr_profile_reset": (C.c_int, [C.c_void_p]),
     "rpr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(KernelStats)]),
     "rpr_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "rpr_set_lane_split": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rpr_lane_split": (C.c_int32, [C.c_void_p]),
     "rpr_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_void_p]),
     "rpr_op_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,

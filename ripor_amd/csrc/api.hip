@@ -267,7 +267,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (clk_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
         hipMalloc(&sel_clk, (size_t)L * 8 * sizeof(unsigned long long)) == hipSuccess)
-      hipMemset(sel_clk, 0, (size_t)L * 8 * sizeof(unsigned long long));
+      (void)hipMemset(sel_clk, 0, (size_t)L * 8 * sizeof(unsigned long long));
   }
   // index of the last attended key + 1 per query: row packing of the encoder and the cross-attention loop bound
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s, c->status + 1); });
@@ -396,15 +396,15 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
     Ln.run(RPR_K_SELECT, 0, (double)R * V * 4 + (double)R * 40, [&] { return launch_select(sa, s); });
   }
   if (sel_clk) {   // debug: phase durations of the selection kernel (block 0), 100 MHz wall clock
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h((size_t)L * 8);
-    hipMemcpy(h.data(), sel_clk, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data(), sel_clk, h.size() * 8, hipMemcpyDeviceToHost);
     for (int t = 0; t < L; ++t) {
       fprintf(stderr, "[select t=%2d] us:", t);
       for (int k = 0; k < 6; ++k) fprintf(stderr, " %7.1f", (double)(h[t * 8 + k + 1] - h[t * 8 + k]) * 0.01);
       fprintf(stderr, "  rounds=%llu\n", h[t * 8 + 7]);
     }
-    hipFree(sel_clk);
+    (void)hipFree(sel_clk);
   }
   FinalizeArgs fa{beam_state(w, L & 1, L), Q, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
                   P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
@@ -516,6 +516,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   auto* c = new rpr_ctx();
   c->device = device;
   if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
+  if (const char* e = getenv("RPR_LANE_MIN_Q")) c->lane_min_q = atoi(e) > 0 ? atoi(e) : 0;
   if (getenv("RPR_GEMM_TRACE")) {
     void* p = nullptr;
     if (hipMalloc(&p, 1 << 20) == hipSuccess) { (void)hipMemset(p, 0, 1 << 20); c->trace_buf = (unsigned long long*)p; }
@@ -540,13 +541,21 @@ void rpr_free_ctx(rpr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
-  Workspace& w = c->ws;
-  DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.offs, &w.row_src, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
-                   &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
-                   &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
-                   &w.o_scores, &w.o_lo, &w.o_hi, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.attn_h,
-                   &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc};
-  for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  auto free_ws = [](Workspace& w) {
+    DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.offs, &w.row_src, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
+                     &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
+                     &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
+                     &w.o_scores, &w.o_lo, &w.o_hi, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.attn_h,
+                     &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc};
+    for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  };
+  free_ws(c->ws);
+  for (Lane& ln : c->lanes) {
+    free_ws(ln.ws);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+  }
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   free_train_ws(c);
   if (c->status) (void)hipFree(c->status);
   if (c->status_host) (void)hipHostFree(c->status_host);
@@ -845,19 +854,39 @@ int rpr_trie_mask(rpr_ctx* c, const rpr_trie* t, const int32_t* prefix, int32_t 
   return RPR_OK;
 }
 
-int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask,
-               int32_t Q, int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores,
-               int64_t* out_row_lo, int64_t* out_row_hi, const rpr_debug_taps* taps, void* stream) {
-  RPR_REQUIRE(c && m && tr && input_ids && attention_mask && out_tokens && out_scores, "NULL argument");
-  RPR_REQUIRE(m->ctx == c && tr->ctx == c, "model/trie belong to another ctx");
-  RPR_REQUIRE(Q >= 1 && B >= 1 && B <= 65535, "Q or B out of range");
-  RPR_REQUIRE(Lq >= 1 && Lq <= MAX_LQ, "Lq out of range (1..256)");
-  RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
-  RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
-  RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
-  RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
-  RPR_HIP(hipSetDevice(c->device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+namespace {
+
+// the two CU-masked lane streams of a ctx (created on first use)
+bool ensure_lanes(rpr_ctx* c) {
+  if (c->lanes_state) return c->lanes_state > 0;
+  c->lanes_state = -1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+  if (cus < 64 || words > 32) return false;
+  for (int i = 0; i < 2; ++i) {
+    uint32_t mask[32] = {0};
+    for (int k = (i == 0 ? 0 : cus / 2); k < (i == 0 ? cus / 2 : cus); ++k) mask[k >> 5] |= 1u << (k & 31);
+    if (hipExtStreamCreateWithCUMask(&c->lanes[i].stream, (uint32_t)words, mask) != hipSuccess ||
+        hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  c->lanes_state = 1;
+  return true;
+}
+
+// one search on stream s; lane >= 0: in that lane's workspace (swapped into c->ws for the duration of the call)
+int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask, int32_t Q,
+               int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores, int64_t* out_row_lo,
+               int64_t* out_row_hi, const rpr_debug_taps* taps, hipStream_t s, int lane) {
+  struct WsGuard {
+    rpr_ctx* c; int lane;
+    WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) std::swap(c->ws, c->lanes[lane].ws); }
+    ~WsGuard() { if (lane >= 0) std::swap(c->ws, c->lanes[lane].ws); }
+  } ws_guard(c, lane);
   int e = alloc_workspace(c, m, Q, Lq, B, L);
   if (e) return e;
   Workspace& w = c->ws;
@@ -874,7 +903,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps);
     if (Ln.err) return Ln.err;
   } else {
-    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16)};
+    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -897,6 +926,56 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   if (out_row_lo) RPR_HIP(hipMemcpyAsync(out_row_lo, w.o_lo.p, R * 8, hipMemcpyDeviceToDevice, s));
   if (out_row_hi) RPR_HIP(hipMemcpyAsync(out_row_hi, w.o_hi.p, R * 8, hipMemcpyDeviceToDevice, s));
   return RPR_OK;
+}
+
+}  // namespace
+
+int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask,
+               int32_t Q, int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores,
+               int64_t* out_row_lo, int64_t* out_row_hi, const rpr_debug_taps* taps, void* stream) {
+  RPR_REQUIRE(c && m && tr && input_ids && attention_mask && out_tokens && out_scores, "NULL argument");
+  RPR_REQUIRE(m->ctx == c && tr->ctx == c, "model/trie belong to another ctx");
+  RPR_REQUIRE(Q >= 1 && B >= 1 && B <= 65535, "Q or B out of range");
+  RPR_REQUIRE(Lq >= 1 && Lq <= MAX_LQ, "Lq out of range (1..256)");
+  RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
+  RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
+  RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
+  RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // Large batches: two halves on the two CU-masked lanes, side by side (see Lane). Results are those of one call: every
+  // query is processed on its own rows. The caller's stream waits for both lanes.
+  if (c->lane_min_q > 0 && Q >= c->lane_min_q && Q >= 2 && !taps && ensure_lanes(c)) {
+    const int32_t Qh[2] = {(Q + 1) / 2, Q / 2};
+    RPR_HIP(hipEventRecord(c->fork_ev, s));
+    int32_t q0 = 0;
+    for (int i = 0; i < 2; ++i) {
+      Lane& ln = c->lanes[i];
+      RPR_HIP(hipStreamWaitEvent(ln.stream, c->fork_ev, 0));
+      const size_t r0 = (size_t)q0 * B;
+      int e = search_one(c, m, tr, input_ids + (size_t)q0 * Lq, attention_mask + (size_t)q0 * Lq, Qh[i], Lq, B, L, flags,
+                         out_tokens + r0 * L, out_scores + r0, out_row_lo ? out_row_lo + r0 : nullptr,
+                         out_row_hi ? out_row_hi + r0 : nullptr, nullptr, ln.stream, i);
+      if (e) return e;
+      RPR_HIP(hipEventRecord(ln.done, ln.stream));
+      q0 += Qh[i];
+    }
+    for (int i = 0; i < 2; ++i) RPR_HIP(hipStreamWaitEvent(s, c->lanes[i].done, 0));
+    return RPR_OK;
+  }
+  return search_one(c, m, tr, input_ids, attention_mask, Q, Lq, B, L, flags, out_tokens, out_scores, out_row_lo, out_row_hi, taps,
+                    s, -1);
+}
+
+int rpr_set_lane_split(rpr_ctx* c, int32_t min_queries) {
+  RPR_REQUIRE(c && min_queries >= 0, "NULL ctx or negative threshold");
+  c->lane_min_q = min_queries;
+  return RPR_OK;
+}
+int32_t rpr_lane_split(rpr_ctx* c) {
+  if (!c || c->lane_min_q <= 0) return 0;
+  (void)hipSetDevice(c->device);
+  return ensure_lanes(c) ? c->lane_min_q : 0;
 }
 
 int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,

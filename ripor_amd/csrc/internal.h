@@ -72,9 +72,9 @@ struct rpr_d2s {
 };
 
 struct GraphKey {
-  const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags;
+  const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags; int lane;   // lane: -1 = the ctx workspace
   bool operator<(const GraphKey& o) const {
-    return std::tie(m, t, Q, Lq, B, L, flags) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags);
+    return std::tie(m, t, Q, Lq, B, L, flags, lane) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags, o.lane);
   }
 };
 
@@ -93,6 +93,15 @@ struct Workspace {
   DevBuf tr_x, tr_misc;   // rpr_train_forward scratch (teacher-forced decoder)
 };
 
+// Half of a large search batch: its own workspace (KV cache, graphs are keyed by the lane) and a HIP stream confined to
+// half of the CUs (hipExtStreamCreateWithCUMask). The two halves of a batch run side by side: the HBM-bound attention of
+// one under the power-bound GEMMs of the other — on one stream every kernel has all CUs in the same phase.
+struct Lane {
+  Workspace ws;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
+
 struct rpr_ctx {
   int device;
   int precision = RPR_PREC_F16X2;
@@ -101,6 +110,10 @@ struct rpr_ctx {
   struct TrainWs* tws = nullptr;        // activations / scratch of the training step (train_api.hip), freed by free_train_ws
   unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
   Workspace ws;
+  Lane lanes[2];
+  int lanes_state = 0;          // 0 not tried yet, 1 ready, -1 masked streams unavailable on this device
+  int lane_min_q = 1024;        // batches of at least this many queries are split over the two lanes (0 = never)
+  hipEvent_t fork_ev = nullptr;
   size_t ws_bytes = 0;
   int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)
   hipStream_t cap_stream = nullptr;

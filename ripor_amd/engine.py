@@ -58,6 +58,14 @@ class Context:
     def workspace_bytes(self) -> int:
         return int(self.lib.rpr_workspace_bytes(self.handle))
 
+    def set_lane_split(self, min_queries: int):
+        """Batches of at least ``min_queries`` queries run as two halves on two CU-masked streams (0 = never)."""
+        check(self.lib.rpr_set_lane_split(self.handle, int(min_queries)), "rpr_set_lane_split")
+
+    def lane_split(self) -> int:
+        """The threshold in force; 0 when splitting is off or masked streams are unavailable."""
+        return int(self.lib.rpr_lane_split(self.handle))
+
     def status(self, clear: bool = True) -> int:
         """Synchronises the current stream and returns the sticky status flags of the work enqueued so far
         (``_lib.STATUS_SATURATED``: an activation left the f16 plane range in f16x2 mode and was clamped — the results

@@ -358,3 +358,32 @@ def test_query_without_attended_tokens_is_reported():
         generate_for_constrained_prefix_beam_search(model, proc, input_ids=torch.from_numpy(ids).cuda(),
                                                     attention_mask=torch.from_numpy(mask2).cuda(), max_new_tokens=L,
                                                     num_beams=B, num_return_sequences=B)
+
+
+def test_lane_split_gives_the_results_of_one_call(setup):
+    """rpr_set_lane_split: a batch run as two halves on the two CU-masked lane streams (own workspaces, own hipGraphs)
+    returns bit-for-bit what the unsplit call returns, for an odd batch, in graph and eager mode, repeatedly (graph
+    replay), and the caller's stream order holds (results are read right after the call on the same stream)."""
+    E, ctx, dims, synth = setup["E"], setup["ctx"], setup["dims"], setup["synth"]
+    L, V, B, Q = setup["L"], dims.decoder_vocab_sizes[0], 4, 37
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims, seed=31), dims)
+    codes = synth.make_codes(3000, L, V, seed=77)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=78)
+    ids, mask = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    saved = ctx.lane_split()
+    try:
+        ctx.set_lane_split(0)
+        ref = E.search(model, trie, ids, mask, B, L)
+        torch.cuda.synchronize()
+        ctx.set_lane_split(2)
+        if ctx.lane_split() == 0:
+            pytest.skip("CU-masked streams unavailable on this device")
+        for use_graph in (True, True, False):
+            got = E.search(model, trie, ids, mask, B, L, use_graph=use_graph)
+            tok = got.tokens.clone()          # same stream: ordered after both lanes
+            torch.cuda.synchronize()
+            assert torch.equal(tok, ref.tokens) and torch.equal(got.scores, ref.scores)
+            assert torch.equal(got.row_lo, ref.row_lo) and torch.equal(got.row_hi, ref.row_hi)
+    finally:
+        ctx.set_lane_split(saved if saved else 1024)

@@ -227,14 +227,14 @@ def test_constrained_decode_smtid_and_merge(monkeypatch, tmp_path):
 
 
 def test_search_batch_size_policy(monkeypatch):
-    """CLI tasks regroup the query stream: never below --batch_size, capped at 2176 (85 row tiles of 256 at beam 10 =
-    whole rounds of GEMM tiles), sized by the KV cache."""
+    """CLI tasks regroup the query stream: never below --batch_size, capped at 2176 and aligned to whole rounds of GEMM tiles
+    (2150 = two lanes of 1075 queries at beam 10), sized by the KV cache."""
     import torch
     from ripor_amd import evaluate as ev
     from ripor_amd.modeling.t5_generative_retriever import T5forDocIDConfig
     cfg = T5forDocIDConfig(decoder_vocab_sizes=[256] * 32)           # t5-base dims
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (250 << 30, 288 << 30))
-    assert ev.search_batch_size(cfg, 1, 10, 32, -1) == 2176           # beam 10: capped
+    assert ev.search_batch_size(cfg, 1, 10, 32, -1) == 2150           # beam 10: capped at 2176, aligned to two lanes
     b100 = ev.search_batch_size(cfg, 4, 100, 32, -1)
     b1000 = ev.search_batch_size(cfg, 1, 1000, 32, -1)
     assert 200 <= b100 <= 1024 and 30 <= b1000 <= 80, (b100, b1000)   # 2.36 GB of KV cache per query at beam 1000
@@ -474,7 +474,8 @@ def test_auto_batch_aligns_decoder_rows_to_whole_gemm_rounds():
     """evaluate.search_batch_size rounds its memory-based choice down to a batch whose Q*beams rows fill whole rounds of
     256x256 tiles (measured +7.5 % at t5-large / beam 100); small batches and already aligned ones are untouched."""
     from ripor_amd.evaluate import align_to_gemm_rounds as align
-    assert align(2176, 10, 768) == 2176           # 85 row tiles x 3 = 255 tiles
+    assert align(2176, 10, 768) == 2150           # two lanes of 1075 queries: 42 row tiles x 3 = 126 tiles on 128 CUs each
+    assert align(2176, 10, 768, 0) == 2176        # lanes off: 85 row tiles x 3 = 255 tiles on 256 CUs
     assert align(200, 100, 1024) == 163           # 64 row tiles x 4 = 256 tiles
     assert align(128, 100, 1024) == 128           # nothing better within 25 %
     assert align(5, 10, 768) == 5 and align(64, 10, 768) == 64   # under one round of tiles: left alone

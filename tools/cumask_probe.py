@@ -22,36 +22,43 @@ def masked_stream(bits):
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
     assert rc == 0, rc
     return torch.cuda.ExternalStream(st.value)
+NS = int(os.environ.get("NSTREAMS", 2))
 if PAT == "lohi":
-    masks = [[i < 128 for i in range(256)], [i >= 128 for i in range(256)]]
+    masks = [[(i * NS) // 256 == k for i in range(256)] for k in range(NS)]
+elif PAT == "mod":       # bit i -> stream i % NS
+    masks = [[i % NS == k for i in range(256)] for k in range(NS)]
 elif PAT == "evenodd":
     masks = [[i % 2 == 0 for i in range(256)], [i % 2 == 1 for i in range(256)]]
 elif PAT == "xcd":      # if bit i lives on XCD i % 8: XCDs 0-3 vs 4-7
     masks = [[(i % 8) < 4 for i in range(256)], [(i % 8) >= 4 for i in range(256)]]
 else:
     masks = None
-streams = [masked_stream(m) for m in masks] if masks else [torch.cuda.Stream(), torch.cuda.Stream()]
-ctxs = [E.Context(0) for _ in range(2)]
+streams = [masked_stream(m) for m in masks] if masks else [torch.cuda.Stream() for _ in range(NS)]
+ctxs = [E.Context(0) for _ in range(NS)]
 models = [E.DeviceModel(c, sd, dims) for c in ctxs]
 tries = [E.DeviceTrie.from_codes(c, codes, V) for c in ctxs]
 ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=3, mean_len=12, std_len=4, min_len=6, max_len=24)
 ids = torch.from_numpy(ids).cuda(); mask = torch.from_numpy(mask).cuda()
 
+OFFSET = float(os.environ.get("OFFSET_MS", 0)) * 1e-3   # host delay before stream 1's first launch (de-phasing)
+
 def run(n, iters):
     torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(iters):
+    for it in range(iters):
         for i in range(n):
+            if it == 0 and i == 1 and OFFSET > 0:
+                time.sleep(OFFSET)
             with torch.cuda.stream(streams[i]):
                 E.search(models[i], tries[i], ids, mask, B, L, use_graph=GRAPH)
     torch.cuda.synchronize()
     return n * iters * Q / (time.time() - t0)
 
-for i in range(2):
+for i in range(NS):
     with torch.cuda.stream(streams[i]):
         E.search(models[i], tries[i], ids, mask, B, L, use_graph=GRAPH)
 torch.cuda.synchronize()
-run(2, 1)
-print(f"pattern {PAT}, Q={Q} per stream, graph={GRAPH}: 1 masked stream {run(1, 4):8.1f} q/s; 2 streams {run(2, 4):8.1f} q/s", flush=True)
+run(NS, 1)
+print(f"pattern {PAT}, Q={Q} per stream, graph={GRAPH}, offset {OFFSET*1e3:.2f} ms: 1 masked stream {run(1, 4):8.1f} q/s; {NS} streams {run(NS, 6):8.1f} q/s", flush=True)
 if os.environ.get("PLAIN"):   # the same searches on one ordinary stream with one context, bench.py style
     Q2 = int(os.environ["PLAIN"])
     ids2, mask2 = synth.make_queries(Q2, vocab_size=dims.vocab_size, seed=3, mean_len=12, std_len=4, min_len=6, max_len=24)
