@@ -358,7 +358,8 @@ def main():
                 if with_traffic and os.path.exists(pmc_path):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh
                     try:
                         pmc = json.load(open(pmc_path))
-                        key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel<true" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                        key = [k for k in pmc["FETCH_SIZE"] if ("gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel<128, 128") in k]
+                        key.sort(key=lambda k: -pmc["FETCH_SIZE"][k]["launches"])   # the instantiation that ran most
                         if key:
                             # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
                             traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
