@@ -197,8 +197,8 @@ def main():
     if args.batch is None:
         args.batch = 2150 if ctx.lane_split() > 0 else 2176
     Q = args.batch
-    lane_min_q = ctx.lane_split()
-    lanes_on = 0 < lane_min_q <= Q
+    lane_min_rows = ctx.lane_split()
+    lanes_on = 0 < lane_min_rows <= Q * args.beams and Q >= 2
     model = E.DeviceModel(ctx, sd, dims)
     log(f"[bench r{rank}] weights ({sum(v.size for v in sd.values()) / 1e6:.1f} M params) on device in {time.time() - t0:.1f}s")
     t0 = time.time()
@@ -398,7 +398,7 @@ def main():
                 out["kernel_breakdown_lanes_ms"] = {k: round(v["total_ms"], 3) for k, v in stats.items()}
                 ctx.set_lane_split(0)
                 stats = profiled_step()
-                ctx.set_lane_split(lane_min_q)
+                ctx.set_lane_split(lane_min_rows)
                 out["roofline_unsplit"] = gemm_roofline(stats, 1.0, with_traffic=False)
             tot = sum(v["total_ms"] for v in stats.values())
             out["kernel_breakdown_ms"] = {k: round(v["total_ms"], 3) for k, v in stats.items()}

@@ -208,14 +208,14 @@ int rpr_search(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, const int32_t* in
                int32_t* out_tokens, float* out_scores, int64_t* out_row_lo, int64_t* out_row_hi,
                const rpr_debug_taps* taps, void* stream);
 
-/* Lane split of large batches. A call of rpr_search with at least `min_queries` queries (default 1024; 0 = never;
- * env RPR_LANE_MIN_Q) runs as two halves on two internal HIP streams, each confined to half of the CUs
+/* Lane split of large batches. A call of rpr_search with at least `min_rows` decoder rows (queries x beams; default
+ * 10240; 0 = never; env RPR_LANE_MIN_ROWS) runs as two halves on two internal HIP streams, each confined to half of the CUs
  * (hipExtStreamCreateWithCUMask) and each with its own workspace: the HBM-bound attention of one half overlaps the
  * power-bound GEMMs of the other (+3.6 % queries/s at 2150 queries in flight; on one stream all CUs are in the same
  * phase). Results are identical to the unsplit call; the caller's stream waits for both halves. Calls with debug taps
  * are never split. rpr_lane_split returns the threshold in force, 0 when splitting is off or masked streams are
  * unavailable on the device. No counterpart in the reference (its loop is host-bound at batch 1). */
-int rpr_set_lane_split(rpr_ctx* ctx, int32_t min_queries);
+int rpr_set_lane_split(rpr_ctx* ctx, int32_t min_rows);
 int32_t rpr_lane_split(rpr_ctx* ctx);
 
 /* ---- forward of the prefix-oriented ranking fine-tune step (BASELINE config 5) ----------

@@ -516,7 +516,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   auto* c = new rpr_ctx();
   c->device = device;
   if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
-  if (const char* e = getenv("RPR_LANE_MIN_Q")) c->lane_min_q = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("RPR_LANE_MIN_ROWS")) c->lane_min_rows = atoi(e) > 0 ? atoi(e) : 0;
   if (getenv("RPR_GEMM_TRACE")) {
     void* p = nullptr;
     if (hipMalloc(&p, 1 << 20) == hipSuccess) { (void)hipMemset(p, 0, 1 << 20); c->trace_buf = (unsigned long long*)p; }
@@ -945,7 +945,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // Large batches: two halves on the two CU-masked lanes, side by side (see Lane). Results are those of one call: every
   // query is processed on its own rows. The caller's stream waits for both lanes.
-  if (c->lane_min_q > 0 && Q >= c->lane_min_q && Q >= 2 && !taps && ensure_lanes(c)) {
+  if (c->lane_min_rows > 0 && (int64_t)Q * B >= c->lane_min_rows && Q >= 2 && !taps && ensure_lanes(c)) {
     const int32_t Qh[2] = {(Q + 1) / 2, Q / 2};
     RPR_HIP(hipEventRecord(c->fork_ev, s));
     int32_t q0 = 0;
@@ -967,15 +967,15 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
                     s, -1);
 }
 
-int rpr_set_lane_split(rpr_ctx* c, int32_t min_queries) {
-  RPR_REQUIRE(c && min_queries >= 0, "NULL ctx or negative threshold");
-  c->lane_min_q = min_queries;
+int rpr_set_lane_split(rpr_ctx* c, int32_t min_rows) {
+  RPR_REQUIRE(c && min_rows >= 0, "NULL ctx or negative threshold");
+  c->lane_min_rows = min_rows;
   return RPR_OK;
 }
 int32_t rpr_lane_split(rpr_ctx* c) {
-  if (!c || c->lane_min_q <= 0) return 0;
+  if (!c || c->lane_min_rows <= 0) return 0;
   (void)hipSetDevice(c->device);
-  return ensure_lanes(c) ? c->lane_min_q : 0;
+  return ensure_lanes(c) ? c->lane_min_rows : 0;
 }
 
 int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,

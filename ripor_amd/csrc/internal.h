@@ -112,7 +112,7 @@ struct rpr_ctx {
   Workspace ws;
   Lane lanes[2];
   int lanes_state = 0;          // 0 not tried yet, 1 ready, -1 masked streams unavailable on this device
-  int lane_min_q = 1024;        // batches of at least this many queries are split over the two lanes (0 = never)
+  int lane_min_rows = 10240;    // batches of at least this many decoder rows (queries x beams) are split over the two lanes (0 = never)
   hipEvent_t fork_ev = nullptr;
   size_t ws_bytes = 0;
   int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)

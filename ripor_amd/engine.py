@@ -58,9 +58,10 @@ class Context:
     def workspace_bytes(self) -> int:
         return int(self.lib.rpr_workspace_bytes(self.handle))
 
-    def set_lane_split(self, min_queries: int):
-        """Batches of at least ``min_queries`` queries run as two halves on two CU-masked streams (0 = never)."""
-        check(self.lib.rpr_set_lane_split(self.handle, int(min_queries)), "rpr_set_lane_split")
+    def set_lane_split(self, min_rows: int):
+        """Batches of at least ``min_rows`` decoder rows (queries x beams) run as two halves on two CU-masked streams
+        (0 = never)."""
+        check(self.lib.rpr_set_lane_split(self.handle, int(min_rows)), "rpr_set_lane_split")
 
     def lane_split(self) -> int:
         """The threshold in force; 0 when splitting is off or masked streams are unavailable."""

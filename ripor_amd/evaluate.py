@@ -310,17 +310,17 @@ def search_batch_size(cfg, batch_size: int, topk: int, max_new_token: int, flag:
     return max(batch_size, align_to_gemm_rounds(auto, topk, cfg.d_model))
 
 
-def align_to_gemm_rounds(q_max: int, beams: int, d_model: int, lane_min_q: int = 1024) -> int:
+def align_to_gemm_rounds(q_max: int, beams: int, d_model: int, lane_min_rows: int = 10240) -> int:
     """Largest Q <= q_max (but not below 0.75 q_max) whose decoder rows fill whole rounds of 256x256 GEMM tiles for the
     d_model-wide projections (then also for the 3x / 4x wider ones): a launch just over a whole number of rounds leaves
-    most of the chip idle in its last round. A batch of at least ``lane_min_q`` queries runs as two halves on two lanes
+    most of the chip idle in its last round. A batch of at least ``lane_min_rows`` decoder rows runs as two halves on two lanes
     of 128 CUs each (``rpr_set_lane_split``), smaller ones on the 256 CUs. Measured: t5-large, beam 100: 160 queries in
     flight (63 row tiles x 4 = 252 tiles) 116.8 q/s vs 108.7 q/s at 128 (200 tiles); t5-base, beam 10: 2176 -> 255 tiles on
     one stream, 2150 -> 2 x 126 tiles on two lanes. Small batches (less than one round of tiles) are left alone."""
     cols = max(1, (d_model + 255) // 256)
 
     def eff(q):
-        lanes = 2 if lane_min_q and q >= lane_min_q else 1
+        lanes = 2 if lane_min_rows and q >= 2 and q * beams >= lane_min_rows else 1
         tiles = ((((q + lanes - 1) // lanes) * beams + 255) // 256) * cols
         cus = 256 // lanes
         return tiles / float(((tiles + cus - 1) // cus) * cus)

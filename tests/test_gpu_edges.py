@@ -386,4 +386,4 @@ def test_lane_split_gives_the_results_of_one_call(setup):
             assert torch.equal(tok, ref.tokens) and torch.equal(got.scores, ref.scores)
             assert torch.equal(got.row_lo, ref.row_lo) and torch.equal(got.row_hi, ref.row_hi)
     finally:
-        ctx.set_lane_split(saved if saved else 1024)
+        ctx.set_lane_split(saved if saved else 10240)

@@ -476,7 +476,8 @@ def test_auto_batch_aligns_decoder_rows_to_whole_gemm_rounds():
     from ripor_amd.evaluate import align_to_gemm_rounds as align
     assert align(2176, 10, 768) == 2150           # two lanes of 1075 queries: 42 row tiles x 3 = 126 tiles on 128 CUs each
     assert align(2176, 10, 768, 0) == 2176        # lanes off: 85 row tiles x 3 = 255 tiles on 256 CUs
-    assert align(200, 100, 1024) == 163           # 64 row tiles x 4 = 256 tiles
+    assert align(200, 100, 1024) == 162           # two lanes of 81 queries: 32 row tiles x 4 = 128 tiles on 128 CUs each
+    assert align(200, 100, 1024, 0) == 163        # lanes off: 64 row tiles x 4 = 256 tiles
     assert align(128, 100, 1024) == 128           # nothing better within 25 %
     assert align(5, 10, 768) == 5 and align(64, 10, 768) == 64   # under one round of tiles: left alone
     for q_max, beams, d in ((2048, 10, 768), (1000, 10, 768), (48, 1000, 768), (300, 100, 1024)):
