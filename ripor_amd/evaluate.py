@@ -56,6 +56,31 @@ def rankdata_from_ranges(qids, row_lo, row_hi, scores, perm, docids, max_new_tok
     return out
 
 
+class _HostCopier:
+    """Device results -> pinned host memory on a side stream: ``to_host`` returns (event, host tensors); the event
+    completes when the copies have, without waiting for anything enqueued on the main stream afterwards."""
+
+    def __init__(self, device):
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def to_host(self, *tensors):
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        host = []
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+                host.append(h)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return done, tuple(host)
+
+
 def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_to_docids, max_new_token, device,
                            out_dir, local_rank, topk=100, apply_log_softmax_for_scores=False, write=True, gather=False):
     """reference evaluate.py:87-132. ``smtid_to_docids``: the reference's dict
@@ -70,6 +95,16 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
     use_ranges = isinstance(smtid_to_docids, DocidTable)
     gather = bool(gather) and use_ranges and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     kept = []   # per batch (qids, row_lo, row_hi, scores) on the device, for the gather
+    copier = _HostCopier(device) if use_ranges and not gather else None
+    pending = None   # (qids, event, host tensors) of the previous batch: decoded while the GPU runs the current one
+
+    def finish(p):
+        qids, done, (sc, lo, hi) = p
+        done.synchronize()
+        perm = prefix_constrain_processor.trie(device).perm
+        rankdata_from_ranges(qids, lo.tolist(), hi.tolist(), sc.tolist(), perm, smtid_to_docids.docids, max_new_token,
+                             apply_log_softmax_for_scores, into=qid_to_rankdata)
+
     for batch in dataloader:
         with torch.no_grad():
             inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
@@ -83,13 +118,16 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
             kept.append((batch["id"].to(outputs.row_lo.device), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk),
                          outputs.sequences_scores.view(-1, topk)))
             continue
-        relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
         if use_ranges:
-            perm = prefix_constrain_processor.trie(device).perm
-            rankdata_from_ranges(batch_qids, outputs.row_lo.view(-1, topk).cpu().tolist(),
-                                 outputs.row_hi.view(-1, topk).cpu().tolist(), relevant_scores, perm,
-                                 smtid_to_docids.docids, max_new_token, apply_log_softmax_for_scores, into=qid_to_rankdata)
+            # the search is asynchronous: its results travel to pinned host memory on a side stream, and the previous
+            # batch is turned into {docid: score} dicts while this one runs (the reference synchronises Q*B times a step)
+            nxt = (batch_qids,) + copier.to_host(outputs.sequences_scores.view(-1, topk), outputs.row_lo.view(-1, topk),
+                                                  outputs.row_hi.view(-1, topk))
+            if pending is not None:
+                finish(pending)
+            pending = nxt
         else:
+            relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
             str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
             for qid, ranked_smtids, rel_scores in zip(batch_qids, str_smtids, relevant_scores):
                 cur = qid_to_rankdata[qid] = {}
@@ -99,6 +137,8 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                     else:
                         for docid in smtid_to_docids[smtid]:
                             cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
+    if pending is not None:
+        finish(pending)
     if gather:
         gdev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if kept:
