@@ -23,7 +23,13 @@ struct TrainWs {
   // saved forward activations
   DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
   // scratch
-  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax, part;
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax, part, tB2, tC2, part2;
+  // the weight-gradient GEMMs run on a side stream beside the input-gradient GEMMs (each alone leaves CUs idle at
+  // M = 8192): two sets of transposed-plane scratch so that a dW product may still be running two dxdw calls later
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  bool done_pending[2] = {false, false};
+  int flip = 0;
   int amax_next = 0;
   // forward GEMM site (keyed by its weight tensor) -> {amax of its input activations, amax of the weight}: the backward
   // multiplies the same two tensors again (dW = dY^T X, dX = dY W) and reuses both maxima
@@ -108,14 +114,16 @@ void amax_reset(Launcher& Ln) {
   w.site_amax.clear();
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.amax), AMAX_SLOTS / 2, Ln.s); });
 }
-void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int ldc, int M, int N, int K, const float* resid, int relu) {
+void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int ldc, int M, int N, int K, const float* resid, int relu,
+                 DevBuf* part = nullptr) {
   GemmH2Args g{};
   g.A = A.p; g.a_ps = A.ps; g.lda = A.ld; g.W = B.p; g.w_ps = B.ps; g.ldw = B.ld;
   g.resid = resid; g.ldr = ldc;
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.sat = Ln.c->status;
   g.dyn_a = A.amax; g.dyn_b = B.amax;
-  g.part = P<float>(Ln.c->tws->part); g.part_cap = Ln.c->tws->part.cap / sizeof(float);
+  if (!part) part = &Ln.c->tws->part;
+  g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float);
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm_h2(g, Ln.s); },
          &g.kernel_cls);
 }
@@ -154,7 +162,12 @@ struct Bwd {
       // from the fp32 weight
       float* am = amax_slots(c, 3);
       if (!am) { Ln.err = RPR_ERR_INVALID; return; }
-      __half *py = P<__half>(w.tA), *pyt = P<__half>(w.tC), *pxt = P<__half>(w.tB), *pwt = P<__half>(w.wT);
+      const int f = w.flip; w.flip ^= 1;
+      __half *py = P<__half>(w.tA), *pyt = P<__half>(f ? w.tC2 : w.tC), *pxt = P<__half>(f ? w.tB2 : w.tB), *pwt = P<__half>(w.wT);
+      if (w.done_pending[f]) {   // the dW product that last read this scratch set (two calls ago) must be over
+        if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        w.done_pending[f] = false;
+      }
       const float *am_x = am + 2, *am_w = am + 1;
       auto site = w.site_amax.find(W);
       if (site != w.site_amax.end()) {   // X and W are the forward GEMM's operands: their maxima are known
@@ -167,7 +180,18 @@ struct Bwd {
       Ln.run(RPR_K_OTHER, 0, 12.0 * M * N, [&] { return launch_split_dyn_T(dY, M, N, N, Mp, pyt, py, am, s); });
       Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pxt, nullptr, am_x, s); });
       Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pwt, nullptr, am_w, s); });
-      gemm_planes(Ln, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0);
+      // dW on the side stream, dX on the main one
+      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(w.side, w.ev_fork[f], 0) != hipSuccess) {
+        Ln.err = RPR_ERR_HIP; return;
+      }
+      static const bool side_on = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
+      {
+        Launcher L2{c, side_on ? w.side : s};
+        gemm_planes(L2, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0, &w.part2);
+        if (L2.err) { Ln.err = L2.err; return; }
+        if (hipEventRecord(w.ev_done[f], side_on ? w.side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        w.done_pending[f] = true;
+      }
       gemm_planes(Ln, {py, (size_t)M * N, N, am}, {pwt, (size_t)K * N, N, am_w}, dX, K, M, K, N, nullptr, 0);
       return;
     }
@@ -203,12 +227,19 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.in_idx, R * 4); E(w.out_idx, R * 4); E(w.tok_idx, T * 4);
   E(w.h, rows * dm * f); E(w.dxa, rows * dm * f); E(w.dxb, rows * dm * f); E(w.dbig, rows * wide * f);
   E(w.dattn, rows * inner * f); E(w.dxkv, T * (size_t)D.xld * f); E(w.denc, T * dm * f);
-  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f); E(w.tC, wide * rp * f);
+  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f); E(w.tC, wide * rp * f); E(w.tB2, wide * rp * f); E(w.tC2, wide * rp * f);
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
-  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats
+  E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2); E(w.part2, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats per stream
+  if (!e && !w.side) {
+    RPR_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      RPR_HIP(hipEventCreateWithFlags(&w.ev_fork[i], hipEventDisableTiming));
+      RPR_HIP(hipEventCreateWithFlags(&w.ev_done[i], hipEventDisableTiming));
+    }
+  }
   return e;
 }
 
@@ -372,6 +403,12 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   // token embeddings (the encoder's table is the shared one)
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, ids, fix, T, dm, s); });
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_fix_flush(fix, g(K_SHARED), (size_t)d.vocab_size * dm, s); });
+  // the weight gradients still in flight on the side stream belong to this pass: join
+  for (int i = 0; i < 2; ++i)
+    if (w.done_pending[i]) {
+      if (hipStreamWaitEvent(s, w.ev_done[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;
+      w.done_pending[i] = false;
+    }
 }
 
 }  // namespace
@@ -381,8 +418,10 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC, &w.part};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC, &w.part, &w.tB2, &w.tC2, &w.part2};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  for (int i = 0; i < 2; ++i) { if (w.ev_fork[i]) (void)hipEventDestroy(w.ev_fork[i]); if (w.ev_done[i]) (void)hipEventDestroy(w.ev_done[i]); }
+  if (w.side) (void)hipStreamDestroy(w.side);
   delete c->tws;
   c->tws = nullptr;
 }
