@@ -108,6 +108,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     if (dbg & 1) g.ssq_out = nullptr;
     if (dbg & 2) g.row_ssq = nullptr;
     g.sat = L.c->status;
+    g.cus = L.c->cur_cus;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
     GemmArgs g{};
@@ -864,6 +865,7 @@ bool ensure_lanes(rpr_ctx* c) {
   if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
   if (cus < 64 || words > 32) return false;
+  c->lane_cus = cus / 2;
   for (int i = 0; i < 2; ++i) {
     uint32_t mask[32] = {0};
     for (int k = (i == 0 ? 0 : cus / 2); k < (i == 0 ? cus / 2 : cus); ++k) mask[k >> 5] |= 1u << (k & 31);
@@ -884,8 +886,8 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
                int64_t* out_row_hi, const rpr_debug_taps* taps, hipStream_t s, int lane) {
   struct WsGuard {
     rpr_ctx* c; int lane;
-    WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) std::swap(c->ws, c->lanes[lane].ws); }
-    ~WsGuard() { if (lane >= 0) std::swap(c->ws, c->lanes[lane].ws); }
+    WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = c->lane_cus; } }
+    ~WsGuard() { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = 0; } }
   } ws_guard(c, lane);
   int e = alloc_workspace(c, m, Q, Lq, B, L);
   if (e) return e;

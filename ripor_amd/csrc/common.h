@@ -109,6 +109,7 @@ struct GemmH2Args {
   // dynamic plane scales (training GEMMs): device-side absolute maxima of A and B; when non-null the accumulators are
   // multiplied by 1 / (dyn_plane_scale(*dyn_a) * dyn_plane_scale(*dyn_b)) instead of acc_scale
   const float* dyn_a; const float* dyn_b;
+  int cus;                                 // CUs the launch may use (0 = the whole chip): a lane stream's CU mask, for the tile choice
   // split-K (optional): scratch for partial results lent by the caller; launch_gemm_h2 decides whether to use it
   float* part; size_t part_cap;            // floats
   int ksplit; size_t part_stride;          // set by the launcher

@@ -752,8 +752,9 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   // 256-tile rounds on the 256 CUs: a launch just over a whole number of rounds (e.g. 288 tiles) leaves most of the
   // chip idle in its last round; the 128-tile kernels quantise finer (measured M = 8192, N = 2304: 135 vs 151 us)
-  const double round_eff = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-  if (force == 256 || (force == 0 && t256 >= 112 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
+  const int cus = a.cus > 0 ? a.cus : 256;         // a lane stream owns part of the chip: thresholds scale with it
+  const double round_eff = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);
+  if (force == 256 || (force == 0 && t256 >= 112L * cus / 256 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
     a_in.kernel_cls = RPR_K_GEMM;
     return launch_256(a, s);
   }

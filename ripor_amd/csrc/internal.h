@@ -114,6 +114,8 @@ struct rpr_ctx {
   int lanes_state = 0;          // 0 not tried yet, 1 ready, -1 masked streams unavailable on this device
   int lane_min_rows = 10240;    // batches of at least this many decoder rows (queries x beams) are split over the two lanes (0 = never)
   hipEvent_t fork_ev = nullptr;
+  int cur_cus = 0;              // CUs of the lane the current enqueue runs on (0 = the whole chip)
+  int lane_cus = 0;             // CUs per lane
   size_t ws_bytes = 0;
   int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)
   hipStream_t cap_stream = nullptr;
