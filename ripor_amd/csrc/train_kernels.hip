@@ -227,19 +227,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
     const float4* gr = reinterpret_cast<const float4*>(dh + (size_t)row * d);
     const float4* wr = reinterpret_cast<const float4*>(w);
+    // the row (x and dh) is read once and kept in registers for the three passes (d <= 4 * 64 * NV: 1024 for NV = 4);
+    // wider rows fall back to re-reading
+    constexpr int NV = 4;
+    const bool cached = n4 <= 64 * NV;
+    float4 xv[NV], gv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k;
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f); gv[k] = xv[k];
+      if (cached && i < n4) { xv[k] = xr[i]; gv[k] = gr[i]; }
+    }
     float ss = 0.f;
-    for (int i = lane; i < n4; i += 64) { const float4 v = xr[i]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) ss += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
+    } else {
+      for (int i = lane; i < n4; i += 64) { const float4 v = xr[i]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    }
     ss = wave_sum_f(ss);
     const float rs = rsqrtf(ss / (float)d + eps);
     float gx = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-      const float4 v = xr[i], g = gr[i], ww = wr[i];
-      gx += (g.x * ww.x) * v.x + (g.y * ww.y) * v.y + (g.z * ww.z) * v.z + (g.w * ww.w) * v.w;
+    auto gx_term = [&](const float4& v, const float4& g, const float4& ww) {
+      return (g.x * ww.x) * v.x + (g.y * ww.y) * v.y + (g.z * ww.z) * v.z + (g.w * ww.w) * v.w;
+    };
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; if (i < n4) gx += gx_term(xv[k], gv[k], wr[i]); }
+    } else {
+      for (int i = lane; i < n4; i += 64) gx += gx_term(xr[i], gr[i], wr[i]);
     }
     gx = wave_sum_f(gx) * post;
     const float c = gx * rs * rs * rs / (float)d;
-    for (int i = lane; i < n4; i += 64) {
-      const float4 v = xr[i], g = gr[i], ww = wr[i];
+    auto finish = [&](int i, const float4& v, const float4& g) {
+      const float4 ww = wr[i];
       float4 o = make_float4(rs * post * g.x * ww.x - v.x * c, rs * post * g.y * ww.y - v.y * c,
                              rs * post * g.z * ww.z - v.z * c, rs * post * g.w * ww.w - v.w * c);
       if (dres) { const float4 r = reinterpret_cast<const float4*>(dres + (size_t)row * d)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
@@ -247,6 +268,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       float4 acc = reinterpret_cast<float4*>(mypart)[i];
       acc.x += g.x * post * v.x * rs; acc.y += g.y * post * v.y * rs; acc.z += g.z * post * v.z * rs; acc.w += g.w * post * v.w * rs;
       reinterpret_cast<float4*>(mypart)[i] = acc;
+    };
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; if (i < n4) finish(i, xv[k], gv[k]); }
+    } else {
+      for (int i = lane; i < n4; i += 64) finish(i, xr[i], gr[i]);
     }
   }
   __syncthreads();
