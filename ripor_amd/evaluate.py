@@ -56,6 +56,11 @@ def rankdata_from_ranges(qids, row_lo, row_hi, scores, perm, docids, max_new_tok
     return out
 
 
+class _Done:
+    def synchronize(self):
+        pass
+
+
 class _HostCopier:
     """Device results -> pinned host memory on a side stream: ``to_host`` returns (event, host tensors); the event
     completes when the copies have, without waiting for anything enqueued on the main stream afterwards."""
@@ -95,7 +100,8 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
     use_ranges = isinstance(smtid_to_docids, DocidTable)
     gather = bool(gather) and use_ranges and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     kept = []   # per batch (qids, row_lo, row_hi, scores) on the device, for the gather
-    copier = _HostCopier(device) if use_ranges and not gather else None
+    _dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    copier = _HostCopier(_dev) if use_ranges and not gather and _dev.type == "cuda" else None
     pending = None   # (qids, event, host tensors) of the previous batch: decoded while the GPU runs the current one
 
     def finish(p):
@@ -121,8 +127,8 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
         if use_ranges:
             # the search is asynchronous: its results travel to pinned host memory on a side stream, and the previous
             # batch is turned into {docid: score} dicts while this one runs (the reference synchronises Q*B times a step)
-            nxt = (batch_qids,) + copier.to_host(outputs.sequences_scores.view(-1, topk), outputs.row_lo.view(-1, topk),
-                                                  outputs.row_hi.view(-1, topk))
+            res = (outputs.sequences_scores.view(-1, topk), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk))
+            nxt = (batch_qids,) + (copier.to_host(*res) if copier else (_Done(), tuple(t.cpu() for t in res)))
             if pending is not None:
                 finish(pending)
             pending = nxt
