@@ -385,5 +385,16 @@ def test_lane_split_gives_the_results_of_one_call(setup):
             torch.cuda.synchronize()
             assert torch.equal(tok, ref.tokens) and torch.equal(got.scores, ref.scores)
             assert torch.equal(got.row_lo, ref.row_lo) and torch.equal(got.row_hi, ref.row_hi)
+        # the other modes of the call: exact-fp32 GEMMs, log-softmax scores, a prefix shorter than the model's length
+        for prec, kw, Lx in (("f32", {}, L), ("f16x2", {"apply_log_softmax_for_scores": True}, L), ("f16x2", {}, L - 2)):
+            ctx.set_precision(prec)
+            ctx.set_lane_split(0)
+            want = E.search(model, trie, ids, mask, B, Lx, **kw)
+            torch.cuda.synchronize()
+            ctx.set_lane_split(2)
+            got = E.search(model, trie, ids, mask, B, Lx, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got.tokens, want.tokens) and torch.equal(got.scores, want.scores), (prec, kw, Lx)
+        ctx.set_precision("f16x2")
     finally:
         ctx.set_lane_split(saved if saved else 10240)
