@@ -417,6 +417,8 @@ def main():
                     sa_traffic = tot_b / n if n else None
                 except Exception:
                     pass
+                if lanes_on:   # the committed counters are per half-batch launch (lane mode); this object is the unsplit step
+                    sa_traffic = None
                 out["roofline_hbm"] = {"kernel": "rpr::dec_self_attn_fast_kernel<2|4|6|8>", "bound": "hbm", "achieved": ach,
                                        "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": ach / (PEAK_HBM_TBS * 1e3),
                                        "traffic": sa_traffic,
@@ -424,7 +426,9 @@ def main():
                                        "avg_launch_us": sa["total_ms"] * 1e3 / max(1, sa["launches"]),
                                        "launches_per_step": sa["launches"],
                                        "note": "K/V rows of every beam's ancestry, read once per step; ~6.3 TB/s is what "
-                                               "streaming reads reach on this part (MI355X_MICROARCH.md)"}
+                                               "streaming reads reach on this part (MI355X_MICROARCH.md)"
+                                               + ("; measured on the unsplit step (whole-chip launches); PMC traffic of "
+                                                  "whole-chip launches: profiles/r02f_q2176_hbm_pmc.json" if lanes_on else "")}
                 out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
         if world == 1 and args.precision != "f32" and not args.no_exact_fp32:
             # secondary figure: the same step on the exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), 1 warm-up + 2 timed
