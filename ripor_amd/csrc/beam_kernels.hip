@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   int* blo = reinterpret_cast<int*>(taken + words);                      // [B]
   int* bhi = blo + B;                                                    // [B]
   int* widx = bhi + B;                                                   // [B]
-  int* red_i = widx + B;                                                 // [8]
-  float* lmax = reinterpret_cast<float*>(red_i + 8);                     // [B]   (red_i[4] = rescan flag)
+  int* red_i = widx + B;                                                 // [8] (+ 4 floats lmax_w)
+  float* lmax_w = reinterpret_cast<float*>(red_i + 8);                   // [4]   per-wave logit maxima (compact path)
+  float* lmax = lmax_w + 4;                                              // [B]   (red_i[4] = rescan flag)
   float* lsum = lmax + B;                                                // [B] log(sum exp)
   float* slog = lsum + B;                                                // [B*V] logits of the query (a.lds_logits)
 
@@ -94,7 +95,12 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     blo[b] = a.cur.lo[r0 + b];
     bhi[b] = a.cur.hi[r0 + b];
   }
-  for (int w = tid; w < words; w += 256) taken[w] = 0ull;
+  for (int w = tid; w < words; w += 256) { taken[w] = 0ull; valid[w] = 0ull; }
+  int* any_wide = red_i + 6;             // LDS flag: some beam's range is wider than NARROW rows
+  if (tid == 0) *any_wide = 0;
+  __syncthreads();
+  for (int b = tid; b < B; b += 256)
+    if (bhi[b] - blo[b] > 32) *any_wide = 1;   // benign race: every writer stores 1
   __syncthreads();
 
   // ---- phase A: child mask of every beam (64 consecutive tokens of one beam per wave) ----
@@ -107,6 +113,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   constexpr int NARROW = 32;
   // step 0: every beam starts at the root range (init_beams_kernel), so only beam 0 is searched and copied below
   const int search_items = (t == 0) ? V : items;
+  // from depth ~3 on every range is narrow (one doc each): the (beam, token) loop has nothing to search then and, with
+  // the logits left in global memory (large beams), nothing to stage either — at B = 1000 it cost 190 us per step
+  if (*any_wide || a.lds_logits)
   for (int item = tid; item < items; item += 4 * 256) {
     // four (beam, token) pairs per thread advance their binary searches in lockstep: the four probes of a step
     // are independent loads (one search at a time was one dependent L2/HBM latency per probe)
@@ -120,7 +129,6 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       const int lo = blo[b], hi = bhi[b];
       if (in && a.lds_logits) slog[it] = lg_q[a.shared0 ? c : it];
       const bool narrow = hi - lo <= NARROW;           // wave-uniform: a wave covers 64 tokens of one beam
-      if (in && narrow && lane == 0) valid[it >> 6] = 0ull;
       act[u] = in && !narrow && it < search_items;
       lo4[u] = lo; hi4[u] = (act[u] && t < Lc) ? hi : lo; end4[u] = hi; c4[u] = c;
     }
@@ -211,19 +219,27 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   // best untaken candidate among items first, first + stride, ... The logits of four candidates are requested
   // before any of them is looked at: at B = 1000 they live in global memory (L2), and one dependent read per
   // candidate made every arg-max round cost ~16 L2 latencies.
-  auto scan_items = [&](int first, int stride) -> Cand {
+  // Ownership: thread o owns one candidate of every stripe of 256 consecutive items, rotated by the stripe index:
+  // item_k(o) = ((o + k) & 255) + 256 k. With V = 256 a stripe is a beam and the thread meets a different token in every
+  // beam — logits of the beams of a query are strongly correlated, so "thread = token" put most of the top-B on a few
+  // threads (list overflow, rescans), the diagonal spreads them.
+  auto owned = [&](int o, int k) -> int { return ((o + k) & 255) + (k << 8); };
+  auto owner_of = [&](int item) -> int { return ((item & 255) - (item >> 8)) & 255; };
+  const int stripes = (items + 255) >> 8;
+  // best untaken candidate of thread o, its stripes split over the 64 lanes of a wave
+  auto scan_owner = [&](int o) -> Cand {
     Cand best; best.s = -INFINITY; best.item = 0x7fffffff;
-    for (int item = first; item < items; item += 4 * stride) {
+    for (int k0 = lane; k0 < stripes; k0 += 4 * 64) {
       float lg[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int it = item + u * stride;
-        lg[u] = it < items ? raw_logit(it) : 0.f;
+        const int it = owned(o, k0 + u * 64);
+        lg[u] = (k0 + u * 64 < stripes && it < items) ? raw_logit(it) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int it = item + u * stride;
-        if (it >= items) break;
+        const int it = owned(o, k0 + u * 64);
+        if (k0 + u * 64 >= stripes || it >= items) continue;
         if ((taken[it >> 6] >> (it & 63)) & 1ull) continue;
         Cand c; c.s = cand_score(it, lg[u]); c.item = it;
         if (better(c, best)) best = c;
@@ -241,22 +257,94 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   //    the first B entries are the winners in rank order. This is exact unless some thread owns more than TK of
   //    the top B (its last list entry is inside the top B and it has more candidates) — then the rounds run
   //    instead. B = 1000 spent 1000 sequential rounds (2.8 us each) per step before.
+  // ---- large beams, usual case: the valid candidates alone ----
+  // From depth ~3 on every beam has a handful of children: ~B valid candidates among B*V. They are compacted from the
+  // bitmap into the sort buffer and sorted; the result is exact iff the B-th of them beats every INVALID candidate, whose
+  // scores are bounded by ((double)max logit + -1e9) + max beam score (the additions are monotone) — checked, else the
+  // general path below runs. (B = 1000: the scan of all 256 000 candidates was 0.85 of the kernel's 1.3 ms per step.)
+  bool use_compact = false;
+  if (a.sort_lds) {
+    constexpr int NS = 256 * TK;
+    double* cs = reinterpret_cast<double*>(smem_raw + a.sort_off);   // [NS]
+    int* ci = reinterpret_cast<int*>(cs + NS);                       // [NS]
+    int* cnt_s = red_i + 7;
+    int cnt = 0;
+    for (int w = tid; w < words; w += 256) cnt += __popcll(valid[w]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) red_i[wave] = cnt;
+    if (tid == 0) *cnt_s = 0;
+    __syncthreads();
+    const int nv = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+    __syncthreads();                                                 // red_i is reused below
+    if (nv >= B && nv <= NS) {                                       // block-uniform
+      float lm = -INFINITY;
+      if (a.log_softmax) lm = 0.f;                                   // log-probabilities are <= 0
+      else {
+        const int n4 = (a.shared0 ? V : items) >> 2;
+        const float4* l4 = reinterpret_cast<const float4*>(lg_q);
+        for (int i = tid; i < n4; i += 256) { const float4 v = l4[i]; lm = fmaxf(lm, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+      }
+      double bm = -INFINITY;
+      for (int b = tid; b < B; b += 256) bm = fmax(bm, bscore[b]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { lm = fmaxf(lm, __shfl_xor(lm, o, 64)); bm = fmax(bm, __shfl_xor(bm, o, 64)); }
+      if (lane == 0) { red_s[wave] = bm; lmax_w[wave] = lm; }
+      for (int w = tid; w < words; w += 256) {
+        unsigned long long bits = valid[w];
+        while (bits) {
+          const int bit = __ffsll((long long)bits) - 1;
+          bits &= bits - 1;
+          const int item = (w << 6) + bit;
+          const int slot = atomicAdd(cnt_s, 1);
+          cs[slot] = cand_score(item, raw_logit(item));
+          ci[slot] = item;
+        }
+      }
+      int P2 = 256;
+      while (P2 < nv) P2 <<= 1;
+      for (int i = nv + tid; i < P2; i += 256) { cs[i] = -INFINITY; ci[i] = 0x7fffffff; }
+      __syncthreads();
+      for (int k = 2; k <= P2; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          for (int p = tid; p < P2 / 2; p += 256) {
+            const int lo_i = 2 * p - (p & (jj - 1));
+            const int hi_i = lo_i + jj;
+            const bool desc = (lo_i & k) == 0;
+            Cand x; x.s = cs[lo_i]; x.item = ci[lo_i];
+            Cand y; y.s = cs[hi_i]; y.item = ci[hi_i];
+            if (better(y, x) == desc) { cs[lo_i] = y.s; ci[lo_i] = y.item; cs[hi_i] = x.s; ci[hi_i] = x.item; }
+          }
+          __syncthreads();
+        }
+      }
+      const double bmax = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
+      const float lmaxq = fmaxf(fmaxf(lmax_w[0], lmax_w[1]), fmaxf(lmax_w[2], lmax_w[3]));
+      const double bound = ((double)lmaxq + -1e9) + bmax;
+      if (cs[B - 1] > bound) {                                       // block-uniform (LDS values)
+        for (int j = tid; j < B; j += 256) { wscore[j] = cs[j]; widx[j] = ci[j]; }
+        use_compact = true;
+      }
+      __syncthreads();
+    }
+  }
+
   double ts[TK];
   int ti[TK];
 #pragma unroll
   for (int i = 0; i < TK; ++i) { ts[i] = -INFINITY; ti[i] = 0x7fffffff; }
   int own = 0;   // candidates owned by this thread
-  for (int item = tid; item < items; item += 4 * 256) {
+  for (int k0 = 0; k0 < stripes && !use_compact; k0 += 4) {
     float lg[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int it = item + u * 256;
-      lg[u] = it < items ? raw_logit(it) : 0.f;
+      const int it = owned(tid, k0 + u);
+      lg[u] = (k0 + u < stripes && it < items) ? raw_logit(it) : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int it = item + u * 256;
-      if (it >= items) break;
+      const int it = owned(tid, k0 + u);
+      if (k0 + u >= stripes || it >= items) continue;
       ++own;
       Cand c; c.s = cand_score(it, lg[u]); c.item = it;
       Cand last; last.s = ts[TK - 1]; last.item = ti[TK - 1];
@@ -276,8 +364,8 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   int* resc = red_i + 4;                 // LDS flag: the winner's wave must rescan for it
   int* overflow = red_i + 5;             // LDS flag: the sorted union of the lists may miss a top-B candidate
   if (tid == 0) { *resc = 0; *overflow = 0; }
-  bool need_rounds = true;
-  if (a.sort_lds) {
+  bool need_rounds = !use_compact;
+  if (a.sort_lds && !use_compact) {
     constexpr int NS = 256 * TK;
     double* cs = reinterpret_cast<double*>(smem_raw + a.sort_off);   // [NS]
     int* ci = reinterpret_cast<int*>(cs + NS);                       // [NS]
@@ -321,7 +409,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       if (better(c, win)) win = c;
     }
     const bool any = win.item != 0x7fffffff;
-    const int owner_tid = win.item & 255;
+    const int owner_tid = owner_of(win.item);
     const bool owner = any && owner_tid == tid;
     if (tid == 0) { wscore[j] = win.s; widx[j] = win.item; }
     if (owner) {
@@ -337,7 +425,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
     __syncthreads();
     if (any && *resc && wave == (owner_tid >> 6)) {   // list exhausted: the wave rescans that thread's candidates
-      Cand best = scan_items(owner_tid + 256 * lane, 256 * 64);
+      Cand best = scan_owner(owner_tid);
       best = wave_best(best);
       if (owner) mine = best;
     }
@@ -385,7 +473,7 @@ constexpr int SEL_TK_HOST = 16;   // list length of the sorted path
 static size_t select_smem(int B, int V) {
   const size_t words = (size_t)B * V / 64;
   return (2 * (size_t)B + 4) * sizeof(double) + 2 * words * sizeof(unsigned long long) +
-         (3 * (size_t)B + 8) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
+         (3 * (size_t)B + 12) * sizeof(int) + 2 * (size_t)B * sizeof(float) + 16;
 }
 
 bool select_fits(int B, int V) { return V % 64 == 0 && select_smem(B, V) <= 160 * 1024; }
