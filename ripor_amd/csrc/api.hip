@@ -109,6 +109,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     if (dbg & 2) g.row_ssq = nullptr;
     g.sat = L.c->status;
     g.cus = L.c->cur_cus;
+    g.part = P<float>(L.c->ws.part); g.part_cap = L.c->ws.part.cap / sizeof(float); g.mid_split = 1;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
     GemmArgs g{};
@@ -158,6 +159,7 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   E(w.attn_h, R * inner * hb); E(w.ff_h, R * dff * hb);
   E(w.ex_h, T * dm * hb); E(w.x_h, R * dm * hb);
   E(w.ssq_e, (2 * ne + 1) * T * 8); E(w.ssq_d, (3 * nd + 1) * R * 8);
+  E(w.part, (size_t)9 << 20 << 2);   // split-K partials of the mid-size GEMM route: < 256 tiles of 128 x 64, up to 4 splits
   return e;
 }
 
@@ -547,7 +549,7 @@ void rpr_free_ctx(rpr_ctx* c) {
                      &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
                      &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
                      &w.o_scores, &w.o_lo, &w.o_hi, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.attn_h,
-                     &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc};
+                     &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc, &w.part};
     for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   };
   free_ws(c->ws);

@@ -112,6 +112,7 @@ struct GemmH2Args {
   int cus;                                 // CUs the launch may use (0 = the whole chip): a lane stream's CU mask, for the tile choice
   // split-K (optional): scratch for partial results lent by the caller; launch_gemm_h2 decides whether to use it
   float* part; size_t part_cap;            // floats
+  int mid_split;                           // search path: allow the split-K + separate fused-epilogue route (mid-size M)
   int ksplit; size_t part_stride;          // set by the launcher
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };

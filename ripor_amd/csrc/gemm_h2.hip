@@ -741,6 +741,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = a;
 }
 
+// Fused epilogue of a split-K launch whose consumer needs more than a sum (search path, a few hundred to a few thousand
+// rows in flight): out = epilogue(sum over the splits, in split order). One thread per output element, a wave covers 64
+// consecutive columns of one row (N % 64 == 0). Same per-element arithmetic as the tile kernels' epilogues: accumulator
+// scale, fused-RMSNorm row scale, ReLU, residual (fp32 or planes), f16-plane or fp32 output (K/V-cache layout included),
+// fixed-point row sums of squares.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmH2Args g, const float* __restrict__ part, int ks, size_t stride) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)g.M * g.N) return;                  // N % 64 == 0: a wave is inside or outside as a whole
+  const int m = (int)(idx / g.N), n = (int)(idx - (size_t)m * g.N);
+  float acc = 0.f;
+  for (int k = 0; k < ks; ++k) acc += part[(size_t)k * stride + idx];
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
+  float v = acc * acc_scale;
+  if (g.row_ssq) v *= ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps);
+  if (g.relu) v = fmaxf(v, 0.f);
+  if (g.resid) v = g.resid[(size_t)m * g.ldr + n] + v;
+  if (g.resid_h) v = x_from_planes(g.resid_h[(size_t)m * g.ldrh + n], g.resid_h[g.r_ps + (size_t)m * g.ldrh + n]) + v;
+  if (g.out_h) {
+    __half hi, lo;
+    split_f16(v * g.plane_scale, hi, lo, g.sat);
+    g.out_h[(size_t)m * g.ldoh + n] = hi;
+    g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+    v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;   // the value the planes carry (row sums below)
+  } else {
+    const int oi = n / g.split_n, on = n - oi * g.split_n;
+    g.out[oi][out_off(g, oi, m, g.ldo[oi], on)] = v;
+  }
+  if (g.ssq_out) {   // grid-uniform branch: all 64 lanes of the wave hold columns of row m
+    float ss = v * v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+  }
+}
+
 hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   GemmH2Args a = a_in;
   if (a.acc_scale == 0.f) a.acc_scale = 1.f;      // zero-initialised args mean "no scaling"
@@ -760,7 +795,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
-  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 400; }();   // max rows (measured: 320 rows 53 vs 76 ms per search, 640 rows 86 vs 77)
+  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
   if (force == 0 && !a.m_dev && a.M <= skinny) {
     const int tiles_m = (a.M + 31) / 32, tiles_n = (a.N + 31) / 32;
     const bool full = (a.M % 32 == 0) && (a.N % 32 == 0);
@@ -769,6 +804,31 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     return hipGetLastError();
   }
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  // A few hundred to a few thousand rows in flight (beam 1000 with one query, beam 100 with a dozen, beam 10 with
+  // 40-400): the 128x64 launch has fewer blocks than CUs and each walks all of K alone (24-96 K-tiles at ~1 us).
+  // Split K over blockIdx.y into the caller's scratch and run the fused epilogue as its own launch.
+  static const int mid_split = [] { const char* e = getenv("RPR_GEMM_MIDSPLIT"); return e ? atoi(e) : 1; }();
+  if (mid_split && force == 0 && a.part && a.mid_split && !a.m_dev && (a.N & 63) == 0 && a.K >= 512) {
+    const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    const int cus = a.cus > 0 ? a.cus : 256;
+    static const int ks_cap = [] { const char* e = getenv("RPR_GEMM_MIDSPLIT_CAP"); return e ? atoi(e) : 4; }();
+    long ks = std::min<long>(std::min<long>((3L * cus / 2 + t - 1) / t, ks_cap), a.K / 128);
+    ks = std::min<long>(ks, (long)(a.part_cap / ((size_t)a.M * a.N)));
+    const int nkt = a.K / HBK;
+    while (ks > 1 && (ks - 1) * ((nkt + ks - 1) / ks) >= nkt) --ks;
+    if (ks > 1 && t < cus) {
+      GemmH2Args p = a;
+      p.ksplit = (int)ks; p.part_stride = (size_t)a.M * a.N;
+      p.out[0] = p.out[1] = p.out[2] = a.part; p.ldo[0] = p.ldo[1] = p.ldo[2] = a.N; p.split_n = a.N;
+      p.out_h = nullptr; p.resid = nullptr; p.resid_h = nullptr; p.relu = 0; p.row_ssq = nullptr; p.ssq_out = nullptr;
+      p.rm_B = 0; p.acc_scale = 1.0f; p.dyn_a = p.dyn_b = nullptr;
+      hipError_t e = launch_cfg<128, 64>(p, s);
+      if (e != hipSuccess) return e;
+      const size_t n = (size_t)a.M * a.N;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, a.part, (int)ks, p.part_stride);
+      return hipGetLastError();
+    }
+  }
   // split-K: the caller lent scratch for partial results and the launch is a long reduction into few tiles
   static const int split_target = [] { const char* e = getenv("RPR_GEMM_SPLITK"); return e ? atoi(e) : 640; }();
   if (a.part && split_target > 0 && a.K >= 2048 && t128 * 2 < split_target && !a.out_h && !a.ssq_out && !a.row_ssq && !a.relu && !a.resid_h &&

@@ -91,6 +91,7 @@ struct Workspace {
   // encoder states, and the UN-normalised residual streams (fused RMSNorm) with their row sums of squares
   DevBuf eattn_h, eff_h, enc_out_h, attn_h, ff_h, ex_h, x_h, ssq_e, ssq_d;
   DevBuf tr_x, tr_misc;   // rpr_train_forward scratch (teacher-forced decoder)
+  DevBuf part;            // split-K partial sums of the mid-size GEMM route (gemm_h2.hip): 9 M floats
 };
 
 // Half of a large search batch: its own workspace (KV cache, graphs are keyed by the lane) and a HIP stream confined to
