@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
   float* outp = g.out[oi];
   const int ldo = g.ldo[oi];
+  float ssr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
@@ -681,11 +682,20 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
         outp[out_off(g, oi, m, ldo, on)] = v;
       }
     }
-    if (g.ssq_out) {   // wave-uniform branch: all 64 lanes take part in the shuffles
-      float ss = ok ? v * v : 0.f;
+    ssr[r] = ok ? v * v : 0.f;
+  }
+  if (g.ssq_out) {   // wave-uniform branch. The 16 butterflies are independent: issued level by level they overlap
+                     // (one chain after the other cost ~4 us per launch — 12 % of a single-query search)
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      if ((lane & 31) == 0 && mok) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ssr[r] += __shfl_xor(ssr[r], o, 64);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
+        if (FULL || m < g.M) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
+      }
     }
   }
 }
