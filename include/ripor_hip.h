@@ -119,7 +119,10 @@ typedef struct {
 /* RPR_K_GEMM = the dominant projection kernel (256x256 ping-pong tiles in f16x2 mode, the fp32 MFMA kernel in exact
  * mode); RPR_K_GEMM_SMALL = the launches that fall to the 128-row / skinny tile kernels (few rows or few tiles). */
 enum { RPR_K_GEMM = 0, RPR_K_DEC_SELF_ATTN = 1, RPR_K_DEC_CROSS_ATTN = 2, RPR_K_ENC_ATTN = 3,
-       RPR_K_RMSNORM = 4, RPR_K_SELECT = 5, RPR_K_OTHER = 6, RPR_K_GEMM_SMALL = 7, RPR_K_COUNT = 8 };
+       RPR_K_RMSNORM = 4, RPR_K_SELECT = 5, RPR_K_OTHER = 6, RPR_K_GEMM_SMALL = 7,
+       RPR_K_TAIL_SELF_ATTN = 8, /* causal block attention of the forced-tail pass */
+       RPR_K_FORK = 9,           /* fork classification / compaction / rank replay of the forced-tail search */
+       RPR_K_COUNT = 10 };
 
 /* ---- lifecycle (replaces: model.to(local_rank), evaluate.py:470; ddp_setup device binding) ---- */
 int rpr_init(int device, rpr_ctx** out_ctx);
@@ -217,6 +220,36 @@ int rpr_search(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, const int32_t* in
  * unavailable on the device. No counterpart in the reference (its loop is host-bound at batch 1). */
 int rpr_set_lane_split(rpr_ctx* ctx, int32_t min_rows);
 int32_t rpr_lane_split(rpr_ctx* ctx);
+
+/* Forced-tail evaluation (default on; env RPR_FORCED_TAIL=0 / RPR_FORK_DEPTHS="4,6"). Beam search over a docid trie
+ * stops deciding early: once every beam of a query stands on a trie node under which a single distinct smtid remains
+ * (8.8 M docs under 256^4 depth-4 prefixes: after 4 steps for 99 % of the queries), each beam has exactly one valid
+ * child per step, nothing can be pruned any more and the remaining tokens are the rest of the beam's code row — only
+ * the scores are missing. rpr_search therefore walks the first steps sequentially, FORKS at up to two depths chosen from
+ * the trie (queries that are forced there leave; the others are compacted and walk on), and scores the remaining
+ * positions of the forced queries in one teacher-forced decoder pass per fork instead of L - T KV-gathering steps.
+ * Results are those of the step-by-step loop (generation.py:423-540: float64 cumulative scores, the slot order of every
+ * step replayed, sum/(L+1) finalize with ties in reverse slot order); a fork only takes a query whose beams are all
+ * live, single-sequence and close enough in score that no masked (-1e9) candidate could be selected (bound on |logit|
+ * from the output codebooks, computed at rpr_load_model). Calls with debug taps or RPR_FLAG_LOG_SOFTMAX never fork.
+ *   rpr_set_forced_tail(ctx, 0/1)            switch (1 = default);
+ *   rpr_set_fork_depths(ctx, n, depths)      n = -1: depths from the trie statistics (default); n = 0..2: explicit,
+ *                                            ascending, each in [1, L-1] (entries >= L are ignored at search time);
+ *   rpr_fork_depths(...)                     the depths a search of this shape would use -> out_depths[2]; returns
+ *                                            their number (>= 0) or a negative rpr_status. */
+int rpr_set_forced_tail(rpr_ctx* ctx, int32_t enable);
+int rpr_set_fork_depths(rpr_ctx* ctx, int32_t n, const int32_t* depths);
+int rpr_fork_depths(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, int32_t Q, int32_t B, int32_t L, uint32_t flags,
+                    int32_t* out_depths);
+/* HOST ONLY (no ctx, no GPU): the statistic the automatic fork depths come from. codes: [host] [N, Lc] in any order;
+ * out_frac: [host] L + 1 doubles, out_frac[t] = share of the trie nodes at depth t (distinct t-prefixes) under which
+ * exactly one distinct L-token sequence remains. A query whose B beams stand on random depth-t nodes is forced with
+ * probability ~ out_frac[t]^B: the first fork is the first depth where that reaches 1/2, the second the first later
+ * depth where fewer than 0.05 queries of the call are expected to stay unforced. */
+int rpr_trie_single_frac(const uint16_t* codes, int64_t N, int32_t Lc, int32_t L, double* out_frac);
+/* Diagnostic (synchronises the device): for every fork of the last rpr_search its depth, the number of queries that
+ * were forced there and the number that walked on; [host] arrays of 2 entries each; returns the number of forks. */
+int rpr_last_fork_stats(rpr_ctx* ctx, int32_t* out_depths, int32_t* out_forced, int32_t* out_left);
 
 /* ---- forward of the prefix-oriented ranking fine-tune step (BASELINE config 5) ----------
  * Replaces the forward of T5SeqAQEncoderForLngKnpMarginMSE (modeling/t5_generative_retriever.py:902-966; also

@@ -12,10 +12,12 @@ from typing import Optional
 LIB_NAME = "libripor_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_GEMM_SMALL, K_COUNT = range(9)
-KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other", "gemm_small"]
+(K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_GEMM_SMALL, K_TAIL_SELF_ATTN, K_FORK,
+ K_COUNT) = range(11)
+KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other", "gemm_small",
+                      "tail_self_attn", "fork"]
 STATUS_SATURATED, STATUS_EMPTY_QUERY = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PREC_F32, PREC_F16X2 = 0, 1
 FLAG_LOG_SOFTMAX = 1
@@ -108,6 +110,12 @@ SIGNATURES = {
     "rpr_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "rpr_set_lane_split": (C.c_int, [C.c_void_p, C.c_int32]),
     "rpr_lane_split": (C.c_int32, [C.c_void_p]),
+    "rpr_set_forced_tail": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rpr_set_fork_depths": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "rpr_fork_depths": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                  C.POINTER(C.c_int32)]),
+    "rpr_trie_single_frac": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "rpr_last_fork_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rpr_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_void_p]),
     "rpr_op_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,

@@ -135,7 +135,8 @@ int flush_profile(rpr_ctx* c) {
   return 0;
 }
 
-int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L) {
+// forks: depths at which forced queries leave the sequential steps (ascending, each in [1, L-1]; empty = plain search)
+int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L, const std::vector<int>& forks = {}) {
   const auto& d = m->d;
   const size_t T = (size_t)Q * Lq, R = (size_t)Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
   const size_t nd = d.num_decoder_layers, ne = d.num_layers, f = sizeof(float);
@@ -147,7 +148,8 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   E(w.eff, T * dff * f); E(w.enc_out, T * dm * f); E(w.xkv, T * nd * 2 * inner * f);
   E(w.x, R * dm * f); E(w.h, R * dm * f); E(w.q, R * inner * f); E(w.attn, R * inner * f);
   E(w.ff, R * dff * f); E(w.logits, R * (size_t)d.V * f);
-  E(w.kcache, nd * L * R * inner * f); E(w.vcache, nd * L * R * inner * f);
+  const size_t depth0 = forks.empty() ? (size_t)L : (size_t)forks[0];   // stage 0 stops at the first fork
+  E(w.kcache, nd * depth0 * R * inner * f); E(w.vcache, nd * depth0 * R * inner * f);
   E(w.lb, R * (size_t)d.V * 4);
   for (int i = 0; i < 2; ++i) {
     E(w.score[i], R * 8); E(w.lo[i], R * 4); E(w.hi[i], R * 4);
@@ -160,6 +162,31 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L)
   E(w.ex_h, T * dm * hb); E(w.x_h, R * dm * hb);
   E(w.ssq_e, (2 * ne + 1) * T * 8); E(w.ssq_d, (3 * nd + 1) * R * 8);
   E(w.part, (size_t)9 << 20 << 2);   // split-K partials of the mid-size GEMM route: < 256 tiles of 128 x 64, up to 4 splits
+  // forced-tail search: one compacted stage and one tail job per fork, tail activations for the longest tail
+  for (size_t k = 0; k < forks.size(); ++k) {
+    const size_t depth = k + 1 < forks.size() ? (size_t)forks[k + 1] : (size_t)L, Lt = (size_t)(L - forks[k]);
+    StageBufs& sb = w.stage[k];
+    E(sb.qmap, (size_t)Q * 4); E(sb.cnt, 16); E(sb.src, (size_t)Q * 4);
+    E(sb.offs, (size_t)Q * 4); E(sb.last, (size_t)Q * 4); E(sb.mask, T * 4);
+    E(sb.kcache, nd * depth * R * inner * f); E(sb.vcache, nd * depth * R * inner * f);
+    for (int i = 0; i < 2; ++i) {
+      E(sb.score[i], R * 8); E(sb.lo[i], R * 4); E(sb.hi[i], R * 4);
+      E(sb.tokens[i], R * (size_t)L * 2); E(sb.anc[i], R * (size_t)L * 2);
+    }
+    TailBufs& tb = w.tail[k];
+    E(tb.flag, (size_t)Q * 4); E(tb.flist, (size_t)Q * 4); E(tb.cnt, 16);
+    E(tb.qmap, (size_t)Q * 4); E(tb.offs, (size_t)Q * 4); E(tb.last, (size_t)Q * 4); E(tb.mask, T * 4);
+    E(tb.tokens, R * (size_t)L * 2); E(tb.gold, R * Lt * f);
+  }
+  if (!forks.empty()) {
+    const size_t Rt = R * (size_t)(L - forks[0]);
+    E(w.t_qkv, Rt * 3 * inner * f); E(w.t_q, Rt * inner * f);
+    if (c->precision == RPR_PREC_F16X2 && !m->f32_only) {
+      E(w.t_x_h, Rt * dm * hb); E(w.t_attn_h, Rt * inner * hb); E(w.t_ff_h, Rt * dff * hb); E(w.t_ssq, (3 * nd + 1) * Rt * 8);
+    } else {
+      E(w.t_x, Rt * dm * f); E(w.t_h, Rt * dm * f); E(w.t_attn, Rt * inner * f); E(w.t_ff, Rt * dff * f);
+    }
+  }
   return e;
 }
 
@@ -246,22 +273,265 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   c->enc_rows_accounted = Ta;
 }
 
-BeamState beam_state(Workspace& w, int i, int L) {
+BeamState beam_state(DevBuf (&score)[2], DevBuf (&lo)[2], DevBuf (&hi)[2], DevBuf (&tokens)[2], DevBuf (&anc)[2], int i, int L) {
   BeamState st;
-  st.score = P<double>(w.score[i]); st.lo = P<int32_t>(w.lo[i]); st.hi = P<int32_t>(w.hi[i]);
-  st.tokens = P<uint16_t>(w.tokens[i]); st.anc = P<uint16_t>(w.anc[i]); st.ld = L;
+  st.score = P<double>(score[i]); st.lo = P<int32_t>(lo[i]); st.hi = P<int32_t>(hi[i]);
+  st.tokens = P<uint16_t>(tokens[i]); st.anc = P<uint16_t>(anc[i]); st.ld = L;
   return st;
+}
+
+// A batch of queries stepping through the decoder one position at a time: stage 0 = all queries of the call, later
+// stages = the queries left over by a fork, compacted (live counts on the device, static launch geometry).
+struct StageView {
+  int Qcap;                        // query capacity = grid size of every launch
+  const int* nq_dev;               // live queries / live rows (queries x beams) on the device; null = Qcap (stage 0)
+  const int* nrows_dev;
+  StageIO io;                      // qmap (null = identity), first encoder row (null = q * Lq), attended length, mask rows
+  float* kcache; float* vcache;    // [nd][Qcap][H][depth][B][64] fp32: everything one (query, head) can touch is one
+  int depth;                       //   contiguous depth*B*256-B region and the B rows of a position are adjacent
+  BeamState st[2];                 // ping-pong by step parity
+  size_t kv_q(int B, int inner) const { return (size_t)depth * B * inner; }
+  size_t kv_h(int B) const { return (size_t)depth * B * DKV; }
+  size_t kv_layer(int B, int inner) const { return (size_t)Qcap * depth * B * inner; }
+};
+
+// live count of a device counter for the profile accounting of an eager diagnostic pass (synchronises)
+int live_count(Launcher& Ln, const int* dev, int fallback) {
+  if (!dev || !Ln.c->profiling || Ln.err) return fallback;
+  int n = fallback;
+  if (hipMemcpyAsync(&n, dev, sizeof(int), hipMemcpyDeviceToHost, Ln.s) != hipSuccess || hipStreamSynchronize(Ln.s) != hipSuccess) return fallback;
+  return n;
+}
+
+struct SearchDims { int Q, Lq, B, L, xld; bool packed; unsigned flags; };
+
+// Decoder steps [t0, t1) of one stage: embed, nd x {self-attention over the beam's ancestry, cross-attention, FF},
+// logits of position t, fused trie mask / top-B / beam expand (reference generation.py:423-526, one iteration per step).
+void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, const SearchDims& sd, const StageView& sv,
+                   int t0, int t1, bool shared0, const rpr_debug_taps* taps, unsigned long long* sel_clk) {
+  const auto& d = m->d;
+  Workspace& w = c->ws;
+  const int Q = sv.Qcap, B = sd.B, L = sd.L, Lq = sd.Lq, R = Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
+  const int nd = d.num_decoder_layers, V = d.V, xld = sd.xld;
+  const bool h2 = c->precision == RPR_PREC_F16X2;
+  const float eps = d.layer_norm_eps;
+  hipStream_t s = Ln.s;
+  float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
+        *logits = P<float>(w.logits);
+  __half *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
+  const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
+  const size_t layer_stride = sv.kv_layer(B, inner), kv_q = sv.kv_q(B, inner), kv_h = sv.kv_h(B), kv_pos = (size_t)B * DKV, kv_slot = DKV;
+  int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
+  const int Racc = live_count(Ln, sv.nrows_dev, R);   // rows the profile accounts for
+  const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+  auto norm = [&](const float* wgt, float post_scale = 1.0f) {   // exact-fp32 mode only (see XStream)
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Racc * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, Rt, dm, eps, s, post_scale, nullptr, 0, sv.nrows_dev); });
+  };
+  const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
+  const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
+  for (int t = t0; t < t1; ++t) {
+    const BeamState cur = sv.st[t & 1], nxt = sv.st[(t + 1) & 1];
+    Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
+    const int Ma = (Bt == B) ? Racc : Rt;
+    if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_d), (size_t)(3 * nd + 1) * R, s); });
+    Ln.run(RPR_K_OTHER, 0, 2.0 * Ma * dm * 4, [&] {
+      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s,
+                              h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{}, sv.nrows_dev);
+    });
+    for (int i = 0; i < nd; ++i) {
+      float* kc = sv.kcache + i * layer_stride;
+      float* vc = sv.vcache + i * layer_stride;
+      if (!h2) norm(m->dec_ln0[i]);
+      {  // q -> qb, k/v -> cache row block of position t
+        LinOut o{};
+        o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
+        o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
+        o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
+        linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o, sv.nrows_dev, Ma);
+      }
+      {
+        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
+                          h2 ? attn_h : nullptr, ps_i, c->status, sv.nq_dev};
+        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Ma * H * (double)(t + 1) * DKV,
+               4.0 * ((double)Ma * inner * 2 + 2.0 * Ma * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
+      }
+      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
+      if (!h2) norm(m->dec_ln1[i]);
+      linear(Ln, h2 ? xs.in(3 * i + 1) : in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, Rt, out_f32(qb, inner, inner), sv.nrows_dev, Ma);
+      {
+        const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+        DecCrossAttnArgs a{qb, xk, xk + inner, xld, sv.io.mask, attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
+                           sv.io.last, sv.io.offs, 0, c->status, sv.nq_dev};
+        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ma * H * (double)Lq * DKV,
+               4.0 * ((double)Ma * inner * 2 + 2.0 * (Ma / Bt) * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
+      }
+      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
+      if (!h2) norm(m->dec_ln2[i]);
+      LinOut o = out_f32(ff, dff, dff, nullptr, 1);
+      if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
+      linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o, sv.nrows_dev, Ma);
+      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
+    }
+    if (!h2) norm(d.dec_final_ln, post);
+    // logits of position t only (the reference computes every position and keeps [-1])
+    float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
+    {
+      LinW wt{d.out_embeds + (size_t)t * V * dm, nullptr, V, dm};
+      if (h2) {
+        // planes of codebook t (times the final layer-norm weight and the scaleup factor) inside the stacked
+        // [2][L*V][d] buffer: plane stride is L*V*d
+        const LinIn a = xs.in(3 * nd);
+        GemmH2Args g{};
+        g.A = a.h; g.a_ps = a.ps; g.lda = dm;
+        g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
+        g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
+        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
+        g.row_ssq = a.ssq; g.inv_d_fix = a.inv_d_fix; g.eps = a.eps; g.sat = c->status;
+        g.m_dev = sv.nrows_dev; g.cus = c->cur_cus;
+        Ln.run(RPR_K_GEMM, 2.0 * Ma * (double)V * dm, 4.0 * ((double)Ma * dm + (double)V * dm + (double)Ma * V),
+               [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
+      } else {
+        linear(Ln, in_h, wt, Rt, out_f32(lg, V, V), sv.nrows_dev, Ma);
+      }
+    }
+    SelectArgs sa{};
+    sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
+    sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
+    sa.log_softmax = (sd.flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
+    sa.shared0 = (Bt != B) ? 1 : 0;
+    sa.nq_dev = sv.nq_dev;
+    if (taps) {
+      sa.tap_scores = taps->step_scores ? taps->step_scores + (size_t)t * R : nullptr;
+      sa.tap_tokens = taps->step_tokens ? taps->step_tokens + (size_t)t * R : nullptr;
+      sa.tap_parent = taps->step_parent ? taps->step_parent + (size_t)t * R : nullptr;
+      sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
+    }
+    if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
+    Ln.run(RPR_K_SELECT, 0, (double)Ma * V * 4 + (double)Ma * 40, [&] { return launch_select(sa, s); });
+  }
+}
+
+// The fork after step T-1 of stage `sv`: which of its queries are forced (tail job `tb`), the others compacted into
+// the next stage (`nb` / returned view): beam state, the K/V of the T positions walked so far, the cross-attention inputs.
+StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, const SearchDims& sd, const StageView& sv,
+                       int T, int next_depth, TailBufs& tb, StageBufs& nb) {
+  const auto& d = m->d;
+  const int Q = sv.Qcap, B = sd.B, L = sd.L, Lq = sd.Lq, inner = m->inner(), nd = d.num_decoder_layers, H = d.num_heads;
+  hipStream_t s = Ln.s;
+  const BeamState st = sv.st[T & 1];
+  // No masked candidate may overtake a valid one during the remaining n = L - T steps. With |logit| <= bound
+  // (rpr_model::logit_bound) the valid candidates of a step are >= smin - n*bound and the masked ones
+  // <= smax + n*bound - 1e9, so forced requires (smax - smin) + 2*n*bound < 1e9; a tenth of that is demanded.
+  const double spread_max = 1e8 - 2.0 * (double)(L - T) * (double)m->logit_bound;
+  ForkArgs fa{st, tr->codes, tr->L, Q, sv.nq_dev, B, T, L, spread_max, P<int32_t>(tb.flag)};
+  Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_fork_classify(fa, s); });
+  Ln.run(RPR_K_FORK, 0, 0, [&] {
+    return launch_fork_scan(P<int32_t>(tb.flag), Q, sv.nq_dev, B, L - T, P<int32_t>(tb.flist), P<int32_t>(tb.cnt), P<int32_t>(nb.src),
+                            P<int32_t>(nb.cnt), s);
+  });
+  // tail job: per-query inputs and the full token rows of the forced beams
+  Ln.run(RPR_K_FORK, 0, 0, [&] {
+    return launch_gather_stage_io(sv.io, StageOut{P<int32_t>(tb.qmap), P<int32_t>(tb.offs), P<int32_t>(tb.last), P<int32_t>(tb.mask)},
+                                  P<int32_t>(tb.flist), P<int>(tb.cnt), Q, Lq, s);
+  });
+  Ln.run(RPR_K_FORK, 0, 0, [&] {
+    return launch_tail_tokens(st, tr->codes, tr->L, P<int32_t>(tb.flist), P<int>(tb.cnt), Q, B, T, L, P<uint16_t>(tb.tokens), s);
+  });
+  // next stage
+  StageView nv{};
+  nv.Qcap = Q; nv.nq_dev = P<int>(nb.cnt); nv.nrows_dev = P<int>(nb.cnt) + 1;
+  nv.io = StageIO{P<int32_t>(nb.qmap), P<int32_t>(nb.offs), P<int32_t>(nb.last), P<int32_t>(nb.mask)};
+  nv.kcache = P<float>(nb.kcache); nv.vcache = P<float>(nb.vcache); nv.depth = next_depth;
+  for (int i = 0; i < 2; ++i) nv.st[i] = beam_state(nb.score, nb.lo, nb.hi, nb.tokens, nb.anc, i, L);
+  Ln.run(RPR_K_FORK, 0, 0, [&] {
+    return launch_gather_stage_io(sv.io, StageOut{P<int32_t>(nb.qmap), P<int32_t>(nb.offs), P<int32_t>(nb.last), P<int32_t>(nb.mask)},
+                                  P<int32_t>(nb.src), nv.nq_dev, Q, Lq, s);
+  });
+  Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_compact_beams(st, nv.st[T & 1], P<int32_t>(nb.src), nv.nq_dev, Q, B, T, s); });
+  KvCopyArgs kc{sv.kcache, sv.vcache, nv.kcache, nv.vcache, sv.kv_layer(B, inner), sv.kv_q(B, inner), sv.kv_h(B),
+                nv.kv_layer(B, inner), nv.kv_q(B, inner), nv.kv_h(B), P<int32_t>(nb.src), nv.nq_dev, Q, nd, H, T * B * DKV};
+  Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_kv_copy(kc, s); });
+  return nv;
+}
+
+// Tail pass of one fork: the remaining positions T..L-1 of every forced beam in ONE teacher-forced decoder pass
+// (rows = forced queries x beams x (L - T), sequence-major), then the replay of the selection order and finalize.
+// Same layer arithmetic as the sequential steps; self-attention reads the positions < T from the fork stage's KV cache
+// through the beams' ancestry and the positions >= T from this pass's own K/V rows; the B*(L-T) rows of a query share
+// its encoder K/V in cross-attention; instead of V logits per row only the logit of the row's (only valid) token is
+// computed, in exact fp32 (tail_gold_kernel).
+void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims& sd, const StageView& sv, int T, TailBufs& tb) {
+  const auto& d = m->d;
+  Workspace& w = c->ws;
+  const int Q = sv.Qcap, B = sd.B, L = sd.L, Lq = sd.Lq, Lt = L - T, S = Q * B, R = S * Lt;
+  const int inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads, nd = d.num_decoder_layers, V = d.V, xld = sd.xld;
+  const bool h2 = c->precision == RPR_PREC_F16X2;
+  const float eps = d.layer_norm_eps;
+  hipStream_t s = Ln.s;
+  const int* nf_dev = P<int>(tb.cnt);
+  const int* nseq_dev = nf_dev + 1;
+  const int* nrows_dev = nf_dev + 2;
+  const int Ra = live_count(Ln, nrows_dev, R);
+  float *x = P<float>(w.t_x), *h = P<float>(w.t_h), *qkv = P<float>(w.t_qkv), *qb = P<float>(w.t_q), *attn = P<float>(w.t_attn),
+        *ff = P<float>(w.t_ff);
+  __half *attn_h = P<__half>(w.t_attn_h), *ff_h = P<__half>(w.t_ff_h);
+  const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
+  const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+  auto norm = [&](const float* wgt) {   // exact-fp32 mode only (see XStream)
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ra * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, R, dm, eps, s, 1.0f, nullptr, 0, nrows_dev); });
+  };
+  const XStream xs{P<__half>(w.t_x_h), ps_d, P<unsigned long long>(w.t_ssq), (size_t)R, dm, eps};
+  const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
+  if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.t_ssq), (size_t)(3 * nd + 1) * R, s); });
+  Ln.run(RPR_K_OTHER, 0, 2.0 * Ra * dm * 4, [&] {
+    return launch_tail_embed(d.in_embeds, P<uint16_t>(tb.tokens), x, R, nrows_dev, T, L, dm, V, s,
+                             h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
+  });
+  const size_t kv_pos = (size_t)B * DKV;
+  for (int i = 0; i < nd; ++i) {
+    if (!h2) norm(m->dec_ln0[i]);
+    linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, out_f32(qkv, 3 * inner, 3 * inner), nrows_dev, Ra);
+    {
+      const size_t ls = sv.kv_layer(B, inner);
+      TailSelfAttnArgs a{qkv, sv.kcache + i * ls, sv.vcache + i * ls, sv.kv_q(B, inner), sv.kv_h(B), kv_pos, (size_t)DKV,
+                         sv.st[T & 1].anc, L, P<int32_t>(tb.flist), nseq_dev, d.dec_rel_bias, m->dec_bucket, attn,
+                         h2 ? attn_h : nullptr, ps_i, c->status, S, B, H, T, L};
+      Ln.run(RPR_K_TAIL_SELF_ATTN, 2.0 * Ra * H * (double)(L + T + 1) * DKV, 4.0 * ((double)Ra * 4 * inner + 2.0 * (Ra / Lt) * (double)T * inner),
+             [&] { return launch_tail_self_attn(a, s); });
+    }
+    linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, R, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x), nrows_dev, Ra);
+    if (!h2) norm(m->dec_ln1[i]);
+    linear(Ln, h2 ? xs.in(3 * i + 1) : in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, R, out_f32(qb, inner, inner), nrows_dev, Ra);
+    {
+      const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
+      DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(tb.mask), attn, Q, B * Lt, H, Lq, h2 ? attn_h : nullptr, ps_i,
+                         P<int32_t>(tb.last), P<int32_t>(tb.offs), 0, c->status, nf_dev};
+      Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ra * H * (double)Lq * DKV, 4.0 * ((double)Ra * inner * 2 + 2.0 * (Ra / (B * Lt)) * (double)Lq * inner),
+             [&] { return launch_dec_cross_attn(a, s); });
+    }
+    linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), nrows_dev, Ra);
+    if (!h2) norm(m->dec_ln2[i]);
+    LinOut o = out_f32(ff, dff, dff, nullptr, 1);
+    if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
+    linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, R, o, nrows_dev, Ra);
+    linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, R, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x), nrows_dev, Ra);
+  }
+  Ln.run(RPR_K_OTHER, 2.0 * Ra * dm, 4.0 * 2 * Ra * dm, [&] {
+    return launch_tail_gold(x, d.dec_final_ln, d.out_embeds, P<uint16_t>(tb.tokens), P<float>(tb.gold), R, nrows_dev, T, L, dm, V, eps, post,
+                            s, h2 ? xs.x_h : nullptr, ps_d);
+  });
+  TailRankArgs ra{sv.st[T & 1], P<int32_t>(tb.flist), P<int32_t>(tb.qmap), nf_dev, P<uint16_t>(tb.tokens), P<float>(tb.gold), Q, B, T, L,
+                  P<int32_t>(w.o_tokens), P<float>(w.o_scores), P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
+  Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_tail_rank(ra, s); });
 }
 
 // Everything between the staged inputs (ws.ids/ws.mask) and the staged outputs (ws.o_*).
 void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, int Q, int Lq, int B, int L,
-                    unsigned flags, const rpr_debug_taps* taps) {
+                    unsigned flags, const rpr_debug_taps* taps, const std::vector<int>& forks) {
   const auto& d = m->d;
   Workspace& w = c->ws;
-  const int T = Q * Lq, R = Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
-  const int nd = d.num_decoder_layers, V = d.V;
-  const bool h2 = c->precision == RPR_PREC_F16X2;
-  const float eps = d.layer_norm_eps;
+  const int T = Q * Lq, inner = m->inner(), dm = d.d_model;
+  const int nd = d.num_decoder_layers;
   hipStream_t s = Ln.s;
   // debug: RPR_SELECT_CLOCK=1 prints the phase durations of the selection kernel (eager launches only)
   unsigned long long* sel_clk = nullptr;
@@ -287,26 +557,14 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
          out_f32(P<float>(w.xkv), xld, xld), packed ? P<int>(w.offs) + Q : nullptr, c->enc_rows_accounted);
 
-  BeamState st0 = beam_state(w, 0, L);
-  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(st0, Q, B, tr->N, s); });
+  const SearchDims sd{Q, Lq, B, L, xld, packed, flags};
+  StageView sv{};
+  sv.Qcap = Q;
+  sv.io = StageIO{nullptr, packed ? P<int32_t>(w.offs) : nullptr, P<int32_t>(w.last), P<int32_t>(w.mask)};
+  sv.kcache = P<float>(w.kcache); sv.vcache = P<float>(w.vcache); sv.depth = forks.empty() ? L : forks[0];
+  for (int i = 0; i < 2; ++i) sv.st[i] = beam_state(w.score, w.lo, w.hi, w.tokens, w.anc, i, L);
+  Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(sv.st[0], Q, B, tr->N, s); });
 
-  float *x = P<float>(w.x), *h = P<float>(w.h), *qb = P<float>(w.q), *attn = P<float>(w.attn), *ff = P<float>(w.ff),
-        *logits = P<float>(w.logits);
-  __half *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
-  const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
-  const size_t layer_stride = (size_t)L * R * inner;
-  // KV cache of one layer: [q][head][position][slot][64] — the rows one (query, head) group of beams can
-  // touch are one contiguous L*B*256-B region (80 KB for B=10, L=32) and the B candidate rows of a position
-  // are adjacent, so the 256-B row reads of neighbouring waves fall into the same DRAM pages.
-  // RPR_KV_LAYOUT=pos | query selects [position][q][slot][inner] | [q][position][slot][inner] (diagnostic).
-  static const int kv_layout = [] {
-    const char* e = getenv("RPR_KV_LAYOUT");
-    return !e ? 2 : !strcmp(e, "pos") ? 0 : !strcmp(e, "query") ? 1 : 2;
-  }();
-  size_t kv_q, kv_h, kv_pos, kv_slot;
-  if (kv_layout == 0)      { kv_q = (size_t)B * inner;     kv_h = DKV;                 kv_pos = (size_t)R * inner; kv_slot = inner; }
-  else if (kv_layout == 1) { kv_q = (size_t)L * B * inner; kv_h = DKV;                 kv_pos = (size_t)B * inner; kv_slot = inner; }
-  else                     { kv_q = (size_t)L * B * inner; kv_h = (size_t)L * B * DKV; kv_pos = (size_t)B * DKV;   kv_slot = DKV; }
   // Step 0: every beam of a query starts from the same start embedding and the same encoder states, so the
   // decoder pass is computed once per query (Q rows, "one beam") and select reads the shared logits row; the
   // position-0 K/V exist in slot 0 only and every beam's ancestry points there. (The reference recomputes
@@ -314,103 +572,34 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // Off when debug taps are requested (they expect [Q*B, V] logits per step) or RPR_STEP0_SHARED=0.
   static const bool step0_env = [] { const char* e = getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
   const bool shared0 = step0_env && !taps && B > 1;
-  int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
-  const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
-  auto norm = [&](const float* wgt, float post_scale = 1.0f) {   // exact-fp32 mode only (see XStream)
-    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Rt * dm * 4, [&] { return launch_rmsnorm(x, wgt, h, Rt, dm, eps, s, post_scale); });
-  };
-  const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
-  const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
-  for (int t = 0; t < L; ++t) {
-    BeamState cur = beam_state(w, t & 1, L), nxt = beam_state(w, (t + 1) & 1, L);
-    Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
-    if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_d), (size_t)(3 * nd + 1) * R, s); });
-    Ln.run(RPR_K_OTHER, 0, 2.0 * Rt * dm * 4, [&] {
-      return launch_dec_embed(d.start_embed, d.in_embeds, cur.tokens, L, x, Rt, dm, V, t, s,
-                              h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
-    });
-    for (int i = 0; i < nd; ++i) {
-      float* kc = P<float>(w.kcache) + i * layer_stride;
-      float* vc = P<float>(w.vcache) + i * layer_stride;
-      if (!h2) norm(m->dec_ln0[i]);
-      {  // q -> qb, k/v -> cache row block of position t
-        LinOut o{};
-        o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
-        o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
-        o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
-        linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o);
-      }
-      {
-        DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
-                          h2 ? attn_h : nullptr, ps_i, c->status};
-        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Rt * H * (double)(t + 1) * DKV,
-               4.0 * ((double)Rt * inner * 2 + 2.0 * Rt * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
-      }
-      linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x));
-      if (!h2) norm(m->dec_ln1[i]);
-      linear(Ln, h2 ? xs.in(3 * i + 1) : in_h, {m->dec_xq[i], m->h_dec_xq[i], inner, dm}, Rt, out_f32(qb, inner, inner));
-      {
-        const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
-        DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(w.mask), attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
-                           P<int32_t>(w.last), packed ? P<int32_t>(w.offs) : nullptr, 0, c->status};
-        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Rt * H * (double)Lq * DKV,
-               4.0 * ((double)Rt * inner * 2 + 2.0 * Q * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
-      }
-      linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x));
-      if (!h2) norm(m->dec_ln2[i]);
-      LinOut o = out_f32(ff, dff, dff, nullptr, 1);
-      if (h2) { o.h = ff_h; o.ps = ps_f; o.ldh = dff; o.plane_scale = FF_PLANE_SCALE; }
-      linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, Rt, o);
-      linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, Rt, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x));
+  // Stages: stage 0 (all queries) walks steps [0, forks[0]); at every fork the forced queries get their tail pass and
+  // the others are compacted into the next stage, which walks on to the next fork (or to L); finalize ranks whoever is
+  // still stepping at L. Without forks this is the plain loop of the reference.
+  int t0 = 0;
+  for (size_t k = 0; k <= forks.size(); ++k) {
+    const int t1 = k < forks.size() ? forks[k] : L;
+    enqueue_steps(Ln, c, m, tr, sd, sv, t0, t1, shared0, taps, sel_clk);
+    if (k < forks.size()) {
+      const int next_depth = k + 1 < forks.size() ? forks[k + 1] : L;
+      const StageView nv = enqueue_fork(Ln, c, m, tr, sd, sv, t1, next_depth, w.tail[k], w.stage[k]);
+      enqueue_tail(Ln, c, m, sd, sv, t1, w.tail[k]);
+      sv = nv;
     }
-    if (!h2) norm(d.dec_final_ln, post);
-    // logits of position t only (the reference computes every position and keeps [-1])
-    float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
-    {
-      LinW wt{d.out_embeds + (size_t)t * V * dm, nullptr, V, dm};
-      if (h2) {
-        // planes of codebook t (times the final layer-norm weight and the scaleup factor) inside the stacked
-        // [2][L*V][d] buffer: plane stride is L*V*d
-        const LinIn a = xs.in(3 * nd);
-        GemmH2Args g{};
-        g.A = a.h; g.a_ps = a.ps; g.lda = dm;
-        g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
-        g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
-        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
-        g.row_ssq = a.ssq; g.inv_d_fix = a.inv_d_fix; g.eps = a.eps; g.sat = c->status;
-        Ln.run(RPR_K_GEMM, 2.0 * Rt * (double)V * dm, 4.0 * ((double)Rt * dm + (double)V * dm + (double)Rt * V),
-               [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
-      } else {
-        linear(Ln, in_h, wt, Rt, out_f32(lg, V, V));
-      }
-    }
-    SelectArgs sa{};
-    sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
-    sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
-    sa.log_softmax = (flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
-    sa.shared0 = (Bt != B) ? 1 : 0;
-    if (taps) {
-      sa.tap_scores = taps->step_scores ? taps->step_scores + (size_t)t * R : nullptr;
-      sa.tap_tokens = taps->step_tokens ? taps->step_tokens + (size_t)t * R : nullptr;
-      sa.tap_parent = taps->step_parent ? taps->step_parent + (size_t)t * R : nullptr;
-      sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
-    }
-    if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
-    Ln.run(RPR_K_SELECT, 0, (double)R * V * 4 + (double)R * 40, [&] { return launch_select(sa, s); });
+    t0 = t1;
   }
   if (sel_clk) {   // debug: phase durations of the selection kernel (block 0), 100 MHz wall clock
     (void)hipStreamSynchronize(s);
-    std::vector<unsigned long long> h((size_t)L * 8);
-    (void)hipMemcpy(h.data(), sel_clk, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> hb((size_t)L * 8);
+    (void)hipMemcpy(hb.data(), sel_clk, hb.size() * 8, hipMemcpyDeviceToHost);
     for (int t = 0; t < L; ++t) {
       fprintf(stderr, "[select t=%2d] us:", t);
-      for (int k = 0; k < 6; ++k) fprintf(stderr, " %7.1f", (double)(h[t * 8 + k + 1] - h[t * 8 + k]) * 0.01);
-      fprintf(stderr, "  rounds=%llu\n", h[t * 8 + 7]);
+      for (int k = 0; k < 6; ++k) fprintf(stderr, " %7.1f", (double)(hb[t * 8 + k + 1] - hb[t * 8 + k]) * 0.01);
+      fprintf(stderr, "  rounds=%llu\n", hb[t * 8 + 7]);
     }
     (void)hipFree(sel_clk);
   }
-  FinalizeArgs fa{beam_state(w, L & 1, L), Q, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
-                  P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
+  FinalizeArgs fa{sv.st[L & 1], sv.Qcap, B, L, P<int32_t>(w.o_tokens), P<float>(w.o_scores),
+                  P<int64_t>(w.o_lo), P<int64_t>(w.o_hi), sv.nq_dev, sv.io.qmap};
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_finalize(fa, s); });
 }
 
@@ -496,7 +685,7 @@ int alloc_train_workspace(rpr_ctx* c, const rpr_model* m, int bz, int Lq, int nd
 
 extern "C" {
 
-int rpr_abi_version(void) { return 2; }
+int rpr_abi_version(void) { return 3; }
 const char* rpr_last_error(void) { return g_err.c_str(); }
 
 int rpr_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
@@ -516,10 +705,21 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   RPR_HIP(init_t5_kernel_attributes());
   RPR_HIP(init_beam_kernel_attributes());
   RPR_HIP(init_train_kernel_attributes());
+  RPR_HIP(init_tail_kernel_attributes());
   auto* c = new rpr_ctx();
   c->device = device;
   if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
   if (const char* e = getenv("RPR_LANE_MIN_ROWS")) c->lane_min_rows = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("RPR_FORCED_TAIL")) c->forced_tail = atoi(e) != 0;
+  if (const char* e = getenv("RPR_FORK_DEPTHS")) {   // "4,6": explicit fork depths; "" or "0": none
+    c->n_fork_override = 0;
+    for (const char* p = e; *p && c->n_fork_override < MAX_FORKS;) {
+      const int v = atoi(p);
+      if (v > 0) c->fork_override[c->n_fork_override++] = v;
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
   if (getenv("RPR_GEMM_TRACE")) {
     void* p = nullptr;
     if (hipMalloc(&p, 1 << 20) == hipSuccess) { (void)hipMemset(p, 0, 1 << 20); c->trace_buf = (unsigned long long*)p; }
@@ -544,13 +744,9 @@ void rpr_free_ctx(rpr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
-  auto free_ws = [](Workspace& w) {
-    DevBuf* all[] = {&w.ids, &w.mask, &w.last, &w.offs, &w.row_src, &w.ex, &w.eh, &w.eqkv, &w.eattn, &w.eff, &w.enc_out, &w.xkv, &w.x, &w.h, &w.q,
-                     &w.attn, &w.ff, &w.logits, &w.kcache, &w.vcache, &w.lb, &w.score[0], &w.score[1], &w.lo[0],
-                     &w.lo[1], &w.hi[0], &w.hi[1], &w.tokens[0], &w.tokens[1], &w.anc[0], &w.anc[1], &w.o_tokens,
-                     &w.o_scores, &w.o_lo, &w.o_hi, &w.eattn_h, &w.eff_h, &w.enc_out_h, &w.attn_h,
-                     &w.ff_h, &w.ex_h, &w.x_h, &w.ssq_e, &w.ssq_d, &w.tr_x, &w.tr_misc, &w.part};
-    for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  auto free_ws = [](Workspace& w) {   // a Workspace is nothing but DevBufs (static_assert in internal.h)
+    DevBuf* all = reinterpret_cast<DevBuf*>(&w);
+    for (size_t i = 0; i < sizeof(Workspace) / sizeof(DevBuf); ++i) if (all[i].p) (void)hipFree(all[i].p);
   };
   free_ws(c->ws);
   for (Lane& ln : c->lanes) {
@@ -659,6 +855,16 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
     RPR_HIP(hipMemcpy(&sat, c->status, 4, hipMemcpyDeviceToHost));
     if (sat) { m->f32_only = true; RPR_HIP(hipMemset(c->status, 0, 4)); }
   }
+  {  // |logit| <= sqrt(d_model) * max_row |E_out[r] * ln_final| * scaleup factor (forced-tail fork, see internal.h)
+    DevTmp nb;
+    RPR_HIP(nb.alloc(4));
+    RPR_HIP(hipMemset(nb.p, 0, 4));
+    RPR_HIP(launch_max_row_norm(d->out_embeds, d->dec_final_ln, d->L * d->V, d->d_model, nb.as<float>(), nullptr));
+    float mx = 0.f;
+    RPR_HIP(hipMemcpy(&mx, nb.p, 4, hipMemcpyDeviceToHost));
+    const float post = d->scaleup_output_hidden ? (float)pow((double)d->d_model, -0.5) : 1.0f;
+    m->logit_bound = 1.001f * mx * sqrtf((float)d->d_model) * post + 1.0f;   // slack for the split-precision arithmetic
+  }
   *out = m.release();
   return RPR_OK;
 }
@@ -735,6 +941,23 @@ int rpr_trie_build_file(const uint16_t* codes, int64_t N, int32_t L, int32_t V, 
     }
   } catch (const std::exception& ex) {
     set_error(std::string("rpr_trie_build_file: ") + ex.what());
+    return RPR_ERR_OOM;
+  }
+  return RPR_OK;
+}
+
+int rpr_trie_single_frac(const uint16_t* codes, int64_t N, int32_t Lc, int32_t L, double* out_frac) {
+  RPR_REQUIRE(codes && out_frac, "NULL argument");
+  RPR_REQUIRE(N > 0 && N < ((int64_t)1 << 31) - 1 && Lc >= 1 && Lc <= 4096 && L >= 1 && L <= Lc, "N, Lc or L out of range");
+  try {
+    std::vector<uint16_t> sorted;
+    std::vector<int64_t> perm;
+    sort_codes(codes, N, Lc, sorted, perm);
+    std::vector<double> f;
+    trie_single_frac(sorted.data(), N, Lc, L, f);
+    for (int t = 0; t <= L; ++t) out_frac[t] = f[(size_t)t];
+  } catch (const std::exception& ex) {
+    set_error(std::string("rpr_trie_single_frac: ") + ex.what());
     return RPR_ERR_OOM;
   }
   return RPR_OK;
@@ -857,6 +1080,8 @@ int rpr_trie_mask(rpr_ctx* c, const rpr_trie* t, const int32_t* prefix, int32_t 
   return RPR_OK;
 }
 
+}  // extern "C"
+
 namespace {
 
 // the two CU-masked lane streams of a ctx (created on first use)
@@ -882,6 +1107,47 @@ bool ensure_lanes(rpr_ctx* c) {
   return true;
 }
 
+// Fork depths of a search (ascending, at most MAX_FORKS; empty = every query walks all L steps). Explicit depths
+// (rpr_set_fork_depths / RPR_FORK_DEPTHS) win; otherwise they come from the trie: with f_t = the share of depth-t nodes
+// under which one distinct sequence remains (trie_single_frac), a query whose B beams sit on random depth-t nodes is
+// forced with probability ~ f_t^B. First fork: the first depth where that reaches one half; second fork: the first
+// depth after it where fewer than 0.05 queries of the call are expected to stay unforced, so that the last stage is
+// almost always empty (a stage with a handful of live rows still pays ~100 launches per step).
+std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int Q, int B, int L, unsigned flags, bool taps) {
+  std::vector<int> forks;
+  if (!c->forced_tail || taps || (flags & RPR_FLAG_LOG_SOFTMAX) || L < 3 || !std::isfinite(m->logit_bound)) return forks;
+  if (1e8 - 2.0 * L * (double)m->logit_bound <= 1e7) return forks;   // logits too large for the masked-candidate proof
+  if (c->n_fork_override >= 0) {
+    int prev = 0;
+    for (int i = 0; i < c->n_fork_override; ++i) {
+      const int t = c->fork_override[i];
+      if (t > prev && t <= L - 1) { forks.push_back(t); prev = t; }
+    }
+    return forks;
+  }
+  auto it = tr->single_frac.find(L);
+  if (it == tr->single_frac.end()) {
+    std::vector<double> f;
+    trie_single_frac(tr->host_sorted.data(), tr->N, tr->L, L, f);
+    it = tr->single_frac.emplace(L, std::move(f)).first;
+  }
+  const std::vector<double>& f = it->second;
+  auto p_forced = [&](int t) { return std::pow(f[(size_t)t], (double)B); };
+  int t0 = 0;
+  for (int t = 1; t <= L - 2 && !t0; ++t) if (p_forced(t) >= 0.5) t0 = t;
+  if (!t0) return forks;
+  forks.push_back(t0);
+  for (int t = t0 + 1; t <= L - 2 && t <= t0 + 12; ++t)
+    if ((double)Q * (1.0 - p_forced(t)) <= 0.05) { forks.push_back(t); break; }
+  return forks;
+}
+
+int pack_forks(const std::vector<int>& forks) {
+  int v = 0;
+  for (size_t i = 0; i < forks.size(); ++i) v |= forks[i] << (8 * i);
+  return v;
+}
+
 // one search on stream s; lane >= 0: in that lane's workspace (swapped into c->ws for the duration of the call)
 int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask, int32_t Q,
                int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores, int64_t* out_row_lo,
@@ -891,29 +1157,32 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = c->lane_cus; } }
     ~WsGuard() { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = 0; } }
   } ws_guard(c, lane);
-  int e = alloc_workspace(c, m, Q, Lq, B, L);
+  // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
+  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (m->f32_only) c->precision = RPR_PREC_F32;
+  const std::vector<int> forks = choose_forks(c, m, tr, Q, B, L, flags, taps != nullptr);
+  int e = alloc_workspace(c, m, Q, Lq, B, L, forks);
   if (e) return e;
+  c->last_forks = forks;
+  c->last_ws_mask |= lane >= 0 ? (2 << lane) : 1;
   Workspace& w = c->ws;
   const size_t T = (size_t)Q * Lq, R = (size_t)Q * B;
   RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
   RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
 
-  // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
-  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
-  if (m->f32_only) c->precision = RPR_PREC_F32;
   const bool eager = (flags & RPR_FLAG_NO_GRAPH) || taps || c->profiling;
   if (eager) {
     Launcher Ln{c, s};
-    enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps);
+    enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps, forks);
     if (Ln.err) return Ln.err;
   } else {
-    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane};
+    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane, pack_forks(forks)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;
       RPR_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
       Launcher Ln{c, c->cap_stream};
-      enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, nullptr);
+      enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, nullptr, forks);
       hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
       if (Ln.err) { if (graph) (void)hipGraphDestroy(graph); return Ln.err; }
       if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
@@ -934,6 +1203,8 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
 
 }  // namespace
 
+extern "C" {
+
 int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids, const int32_t* attention_mask,
                int32_t Q, int32_t Lq, int32_t B, int32_t L, uint32_t flags, int32_t* out_tokens, float* out_scores,
                int64_t* out_row_lo, int64_t* out_row_hi, const rpr_debug_taps* taps, void* stream) {
@@ -947,6 +1218,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  c->last_ws_mask = 0;
   // Large batches: two halves on the two CU-masked lanes, side by side (see Lane). Results are those of one call: every
   // query is processed on its own rows. The caller's stream waits for both lanes.
   if (c->lane_min_rows > 0 && (int64_t)Q * B >= c->lane_min_rows && Q >= 2 && !taps && ensure_lanes(c)) {
@@ -980,6 +1252,49 @@ int32_t rpr_lane_split(rpr_ctx* c) {
   if (!c || c->lane_min_rows <= 0) return 0;
   (void)hipSetDevice(c->device);
   return ensure_lanes(c) ? c->lane_min_rows : 0;
+}
+
+int rpr_set_forced_tail(rpr_ctx* c, int32_t enable) {
+  RPR_REQUIRE(c, "NULL ctx");
+  c->forced_tail = enable != 0;
+  return RPR_OK;
+}
+
+int rpr_set_fork_depths(rpr_ctx* c, int32_t n, const int32_t* depths) {
+  RPR_REQUIRE(c && n >= -1 && n <= MAX_FORKS && (n <= 0 || depths), "n out of range (-1 = automatic, 0..2 explicit depths)");
+  c->n_fork_override = n;
+  for (int i = 0; i < n; ++i) {
+    RPR_REQUIRE(depths[i] >= 1 && depths[i] < 256 && (i == 0 || depths[i] > depths[i - 1]), "fork depths must be ascending and >= 1");
+    c->fork_override[i] = depths[i];
+  }
+  return RPR_OK;
+}
+
+int rpr_fork_depths(rpr_ctx* c, rpr_model* m, rpr_trie* tr, int32_t Q, int32_t B, int32_t L, uint32_t flags, int32_t* out_depths) {
+  RPR_REQUIRE(c && m && tr && out_depths, "NULL argument");
+  RPR_REQUIRE(Q >= 1 && B >= 1 && L >= 1 && L <= tr->L, "Q, B or L out of range");
+  const std::vector<int> f = choose_forks(c, m, tr, Q, B, L, flags, false);
+  for (size_t i = 0; i < f.size(); ++i) out_depths[i] = f[i];
+  return (int)f.size();
+}
+
+int rpr_last_fork_stats(rpr_ctx* c, int32_t* out_depths, int32_t* out_forced, int32_t* out_left) {
+  RPR_REQUIRE(c && out_depths && out_forced && out_left, "NULL argument");
+  RPR_HIP(hipSetDevice(c->device));
+  RPR_HIP(hipDeviceSynchronize());
+  const int n = (int)c->last_forks.size();
+  for (int k = 0; k < n; ++k) {
+    out_depths[k] = c->last_forks[(size_t)k]; out_forced[k] = 0; out_left[k] = 0;
+    const Workspace* wss[3] = {&c->ws, &c->lanes[0].ws, &c->lanes[1].ws};
+    for (int i = 0; i < 3; ++i) {
+      if (!(c->last_ws_mask & (1 << i)) || !wss[i]->tail[k].cnt.p || !wss[i]->stage[k].cnt.p) continue;
+      int32_t a = 0, b = 0;
+      RPR_HIP(hipMemcpy(&a, wss[i]->tail[k].cnt.p, 4, hipMemcpyDeviceToHost));
+      RPR_HIP(hipMemcpy(&b, wss[i]->stage[k].cnt.p, 4, hipMemcpyDeviceToHost));
+      out_forced[k] += a; out_left[k] += b;
+    }
+  }
+  return n;
 }
 
 int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int B = a.B, V = a.V, t = a.t, Lc = a.Lc;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.nq_dev && q >= *a.nq_dev) return;   // compacted stage: block-uniform
   const int items = B * V, words = items >> 6;
   // LDS carve (all 8-byte aligned)
   double* bscore = reinterpret_cast<double*>(smem_raw);                  // [B]
@@ -511,6 +512,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sc = reinterpret_cast<double*>(smem_raw);  // [B]
   const int B = a.B, L = a.L, q = blockIdx.x, tid = threadIdx.x, r0 = q * B;
+  if (a.nq_dev && q >= *a.nq_dev) return;
+  const size_t o0 = (size_t)(a.qmap ? a.qmap[q] : q) * B;   // output rows of this query
   for (int j = tid; j < B; j += 256) sc[j] = a.st.score[r0 + j] / (double)(L + 1);
   __syncthreads();
   int* rank = reinterpret_cast<int*>(sc + B);  // [B]
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     int rk = 0;
     for (int i = 0; i < B; ++i) rk += (sc[i] > s) || (sc[i] == s && i > j);
     rank[j] = rk;
-    const size_t o = (size_t)r0 + rk;
+    const size_t o = o0 + rk;
     a.out_scores[o] = (float)s;
     a.out_lo[o] = a.st.lo[r0 + j];
     a.out_hi[o] = a.st.hi[r0 + j];
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   __syncthreads();
   for (int i = tid; i < B * L; i += 256) {
     const int j = i / L, p = i - j * L;
-    a.out_tokens[((size_t)r0 + rank[j]) * L + p] = (int32_t)a.st.tokens[(size_t)(r0 + j) * a.st.ld + p];
+    a.out_tokens[(o0 + rank[j]) * L + p] = (int32_t)a.st.tokens[(size_t)(r0 + j) * a.st.ld + p];
   }
 }
 

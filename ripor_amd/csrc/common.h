@@ -167,8 +167,10 @@ hipError_t launch_embed_rows(const float* table, const int32_t* ids, float* out,
 // Packed encoder rows: offs[q] = sum of lens[<q] (offs[Q] = live rows), row_src[offs[q] + j] = q * Lq + j
 hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src, int Q, int Lq, hipStream_t s);
 // x[r] = t==0 ? start : in_embeds[t-1][tokens[r][t-1]]
+// rows_dev (nullable): live row count on the device (a compacted stage of the forced-tail search, api.hip)
 hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
-                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo = XOut{});
+                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo = XOut{},
+                            const int* rows_dev = nullptr);
 
 struct EncAttnArgs {
   const float* qkv;        // [Q*Lq, 3*inner]  (q | k | v)
@@ -199,6 +201,7 @@ struct DecSelfAttnArgs {
   int Q, B, H, t;
   __half* out_h; size_t o_ps;
   unsigned int* sat;
+  const int* nq_dev;       // nullable: live query count on the device (compacted stage); queries past it are skipped
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 
@@ -215,6 +218,7 @@ struct DecCrossAttnArgs {
   const int32_t* offs;     // nullable (packed encoder): K/V row (q, j) is row offs[q] + j instead of q*Lq + j
   int bchunk;              // set by the launcher: beams per block when the beam is split over blockIdx.y (0 = all)
   unsigned int* sat;
+  const int* nq_dev;       // nullable: live query count on the device; queries past it are skipped
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 
@@ -244,6 +248,7 @@ struct SelectArgs {
   double* tap_scores; int32_t* tap_tokens; int32_t* tap_parent;   // [Q, B]
   unsigned long long* tap_valid;                                   // [Q, B*V/64] phase-A child bitmap (bit = beam*V + token)
   unsigned long long* clk;   // debug (RPR_SELECT_CLOCK=1, eager mode): 8 wall-clock stamps of block 0 at the phase boundaries
+  const int* nq_dev;         // nullable: live query count on the device; blocks past it exit
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
@@ -255,6 +260,8 @@ struct FinalizeArgs {
   float* out_scores;         // [Q, B]
   int64_t* out_lo;           // [Q, B]
   int64_t* out_hi;
+  const int* nq_dev;         // nullable: live query count on the device; blocks past it exit
+  const int32_t* qmap;       // nullable: stage query -> query of the call (output row block)
 };
 hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
@@ -265,6 +272,84 @@ hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t s);
 // status (nullable): the ctx's sticky "empty query" word, set to 1 when a query attends to no token
 hipError_t launch_mask_lengths(const int32_t* mask, int32_t* lens, int Q, int Lq, hipStream_t s,
                                unsigned int* status = nullptr);
+
+// ---- forced-tail evaluation (tail_kernels.hip; orchestration in api.hip) -------------------------------------------
+// Once every beam of a query stands on a trie node under which a single distinct sequence remains, beam search can no
+// longer prune for that query: each beam has exactly one valid child per step, the B valid candidates beat every
+// masked one (-1e9) and the remaining tokens are the rest of the beam's code row. Such a query leaves the sequential
+// steps at a FORK: its remaining positions are scored by one teacher-forced decoder pass (the "tail"), the others are
+// compacted into the next stage and go on step by step. Same results as the sequential loop (reference
+// generation.py:423-540); the reference itself has no counterpart — it recomputes the whole prefix every step.
+struct ForkArgs {
+  BeamState st;              // the stage's beams after step T-1 (T tokens each)
+  const uint16_t* codes; int Lc;
+  int Qcap; const int* nq_dev;   // stage capacity / live queries (nullable = Qcap)
+  int B, T, L;
+  double spread_max;         // forced only if max - min of the query's beam scores is below this (see api.hip)
+  int32_t* flag;             // out [Qcap]: 1 = forced
+};
+hipError_t launch_fork_classify(const ForkArgs& a, hipStream_t s);
+// exclusive scans of the flags: forced queries -> flist / tail_cnt {queries, sequences = x B, rows = x B x (L-T), 0},
+// the others -> src (source stage query of every query of the next stage) / next_cnt {queries, rows = x B, 0, 0}
+hipError_t launch_fork_scan(const int32_t* flag, int Qcap, const int* nq_dev, int B, int Lt, int32_t* flist, int32_t* tail_cnt,
+                            int32_t* src, int32_t* next_cnt, hipStream_t s);
+struct StageIO {             // per-query inputs of a stage (all indexed by the stage's query index)
+  const int32_t* qmap;       // nullable = identity: query of the call
+  const int32_t* offs;       // nullable = q * Lq: first encoder row
+  const int32_t* last;       // attended length
+  const int32_t* mask;       // [., Lq]
+};
+struct StageOut { int32_t* qmap; int32_t* offs; int32_t* last; int32_t* mask; };
+// queries list[i] (i < *n_dev) of the source stage -> entry i of dst (qmap / offs / last / mask row)
+hipError_t launch_gather_stage_io(const StageIO& src, const StageOut& dst, const int32_t* list, const int* n_dev, int Qcap, int Lq,
+                                  hipStream_t s);
+// beam state (T tokens per beam) of the source queries src[i] -> next stage's rows i*B ..
+hipError_t launch_compact_beams(const BeamState& from, const BeamState& to, const int32_t* src, const int* n_dev, int Qcap, int B, int T,
+                                hipStream_t s);
+// K/V of positions < T of the source queries: (layer, q, head) regions [depth][B][64] -> the next stage's cache
+struct KvCopyArgs {
+  const float* k_from; const float* v_from; float* k_to; float* v_to;
+  size_t layer_from, q_from, h_from;     // strides (floats) of the source cache
+  size_t layer_to, q_to, h_to;
+  const int32_t* src; const int* n_dev;
+  int Qcap, nd, H, n;        // n = floats per (layer, q, head) to copy = T * B * 64
+};
+hipError_t launch_kv_copy(const KvCopyArgs& a, hipStream_t s);
+// full token row of every forced beam: tokens[(i*B + b)*L + p] = p < T ? beam token : codes[lo_b][p]
+hipError_t launch_tail_tokens(const BeamState& st, const uint16_t* codes, int Lc, const int32_t* flist, const int* nf_dev, int Qcap,
+                              int B, int T, int L, uint16_t* tokens, hipStream_t s);
+// decoder input embedding of the tail rows (sequence-major: row = seq * (L-T) + (p - T)): in_embeds[p-1][token p-1]
+hipError_t launch_tail_embed(const float* in_embeds, const uint16_t* tokens, float* out, int rows, const int* rows_dev, int T, int L,
+                             int d, int V, hipStream_t s, XOut xo = XOut{});
+struct TailSelfAttnArgs {
+  const float* qkv;          // [rows, 3*inner] of the tail rows (q | k | v)
+  const float* kcache;       // the fork stage's cache of this layer (positions < T)
+  const float* vcache;
+  size_t q_stride, h_stride, pos_stride, slot_stride;
+  const uint16_t* anc; int anc_ld;   // the fork stage's ancestry rows
+  const int32_t* flist;      // tail query -> stage query
+  const int* nseq_dev;       // live sequences
+  const float* rel_bias; const int32_t* bucket;
+  float* out; __half* out_h; size_t o_ps; unsigned int* sat;
+  int nseq_cap, B, H, T, L;
+};
+hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s);
+// gold[row] = <final RMSNorm of the row's stream (x post), E_out[p][token p]>, exact fp32 (as launch_gold_scores)
+hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_embeds, const uint16_t* tokens, float* gold, int rows,
+                            const int* rows_dev, int T, int L, int d, int V, float eps, float post, hipStream_t s,
+                            const __half* x_h = nullptr, size_t x_ps = 0);
+struct TailRankArgs {
+  BeamState st;              // the fork stage's beams (scores, ranges)
+  const int32_t* flist; const int32_t* qmap; const int* nf_dev;   // qmap: tail query -> query of the call
+  const uint16_t* tokens;    // [., B, L]
+  const float* gold;         // [., B, L-T]
+  int Qcap, B, T, L;
+  int32_t* out_tokens; float* out_scores; int64_t* out_lo; int64_t* out_hi;
+};
+hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s);
+// max over the rows of |E[r] (*) w|_2 (w nullable): bound of the logits after the final RMSNorm (model load)
+hipError_t launch_max_row_norm(const float* E, const float* w, int rows, int d, float* out /*zeroed*/, hipStream_t s);
+hipError_t init_tail_kernel_attributes();
 
 // ---- teacher-forced forward of the ranking fine-tune step (train_kernels.hip) -------------------
 hipError_t launch_train_dec_embed(const float* start, const float* in_embeds, const int32_t* codes, float* out, int S,

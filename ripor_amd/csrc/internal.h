@@ -5,6 +5,7 @@
 #include <memory>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -45,6 +46,10 @@ struct rpr_model {
   struct ParamRef { int kind; int layer; float* ptr; size_t numel; size_t offset; };
   std::vector<ParamRef> params;
   size_t params_total = 0;
+  // bound of |logit| for any decoder state: sqrt(d_model) * max row norm of the output codebooks times the final
+  // layer-norm weight (Cauchy-Schwarz on the RMS-normalised hidden state), times the scaleup factor; computed at load.
+  // The forced-tail fork uses it to prove that no masked (-1e9) candidate can overtake a valid one (api.hip).
+  float logit_bound = INFINITY;
   int inner() const { return d.num_heads * d.d_kv; }
   ~rpr_model() {   // device memory goes with the object, also on the error paths of rpr_load_model
     if (enc_bucket) (void)hipFree(enc_bucket);
@@ -61,6 +66,7 @@ struct rpr_trie {
   std::vector<int64_t> perm;
   std::vector<uint16_t> host_sorted;
   std::string keys;           // docid strings in original row order, '\n'-joined (only when loaded from a file that has them)
+  std::map<int, std::vector<double>> single_frac;   // per search length L: trie_single_frac (lazily, first search of that length)
   ~rpr_trie() { if (codes) (void)hipFree(codes); }
 };
 
@@ -73,10 +79,30 @@ struct rpr_d2s {
 
 struct GraphKey {
   const rpr_model* m; const rpr_trie* t; int Q, Lq, B, L; unsigned flags; int lane;   // lane: -1 = the ctx workspace
+  int forks;                                                                           // fork depths, 8 bits each (0 = none)
   bool operator<(const GraphKey& o) const {
-    return std::tie(m, t, Q, Lq, B, L, flags, lane) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags, o.lane);
+    return std::tie(m, t, Q, Lq, B, L, flags, lane, forks) < std::tie(o.m, o.t, o.Q, o.Lq, o.B, o.L, o.flags, o.lane, o.forks);
   }
 };
+
+// Forced-tail search (api.hip::enqueue_search): a compacted batch of queries that goes on step by step after a fork
+struct StageBufs {
+  DevBuf qmap;              // int32 [cap]: stage query -> query of the call
+  DevBuf cnt;               // int32 [4]: live queries, live rows (queries x beams)
+  DevBuf src;               // int32 [cap]: source query (in the previous stage) of every query
+  DevBuf offs, last, mask;  // first encoder row / attended length / mask row of every stage query
+  DevBuf kcache, vcache;    // [nd][cap][H][depth][B][64]
+  DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
+};
+// ... and the queries that leave at that fork: their remaining positions are scored in one teacher-forced pass
+struct TailBufs {
+  DevBuf flag, flist;       // int32 [cap]: forced?, tail query -> stage query
+  DevBuf cnt;               // int32 [4]: forced queries, sequences (x B), rows (x B x (L - T))
+  DevBuf qmap, offs, last, mask;
+  DevBuf tokens;            // uint16 [cap * B][L]
+  DevBuf gold;              // float [cap * B][L - T]
+};
+constexpr int MAX_FORKS = 2;
 
 struct Workspace {
   // encoder
@@ -92,7 +118,15 @@ struct Workspace {
   DevBuf eattn_h, eff_h, enc_out_h, attn_h, ff_h, ex_h, x_h, ssq_e, ssq_d;
   DevBuf tr_x, tr_misc;   // rpr_train_forward scratch (teacher-forced decoder)
   DevBuf part;            // split-K partial sums of the mid-size GEMM route (gemm_h2.hip): 9 M floats
+  // forced-tail search: stages 1.. (stage 0 = the buffers above), one tail job per fork, and the activations of a tail
+  // pass (rows = queries x beams x remaining positions), shared by the forks
+  StageBufs stage[MAX_FORKS];
+  TailBufs tail[MAX_FORKS];
+  DevBuf t_x, t_h, t_qkv, t_q, t_attn, t_ff, t_x_h, t_attn_h, t_ff_h, t_ssq;
 };
+
+static_assert(sizeof(Workspace) % sizeof(DevBuf) == 0 && std::is_standard_layout<Workspace>::value,
+              "Workspace must consist of DevBuf members only (rpr_free_ctx walks it as an array)");
 
 // Half of a large search batch: its own workspace (KV cache, graphs are keyed by the lane) and a HIP stream confined to
 // half of the CUs (hipExtStreamCreateWithCUMask). The two halves of a batch run side by side: the HBM-bound attention of
@@ -117,6 +151,11 @@ struct rpr_ctx {
   hipEvent_t fork_ev = nullptr;
   int cur_cus = 0;              // CUs of the lane the current enqueue runs on (0 = the whole chip)
   int lane_cus = 0;             // CUs per lane
+  int forced_tail = 1;          // 0 = every query runs all L steps sequentially
+  int fork_override[MAX_FORKS] = {0, 0};   // explicit fork depths (rpr_set_fork_depths / RPR_FORK_DEPTHS); 0 = from the trie statistics
+  int n_fork_override = -1;     // -1 = automatic
+  std::vector<int> last_forks;  // fork depths of the last rpr_search and the workspaces it ran in (bit 0: ctx, 1 / 2: lanes)
+  int last_ws_mask = 0;         //   -> rpr_last_fork_stats
   size_t ws_bytes = 0;
   int enc_rows_accounted = 0;   // live encoder rows of the last enqueue (profile accounting)
   hipStream_t cap_stream = nullptr;

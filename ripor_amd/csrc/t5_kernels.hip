@@ -11,33 +11,9 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include "kernel_utils.h"
 
 namespace rpr {
-
-__device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t idx, float4 v, unsigned int* sat,
-                                              float scale = A_PLANE_SCALE) {
-  __half h[4], l[4];   // activation planes hold x * A_PLANE_SCALE (common.h)
-  split_f16(v.x * scale, h[0], l[0], sat); split_f16(v.y * scale, h[1], l[1], sat);
-  split_f16(v.z * scale, h[2], l[2], sat); split_f16(v.w * scale, h[3], l[3], sat);
-  *reinterpret_cast<uint2*>(out_h + idx) = *reinterpret_cast<uint2*>(h);
-  *reinterpret_cast<uint2*>(out_h + o_ps + idx) = *reinterpret_cast<uint2*>(l);
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // ------------------------------------------------------------------------------------ RMSNorm
 // one wave per row; d % 4 == 0
@@ -85,33 +61,6 @@ hipError_t launch_rmsnorm(const float* x, const float* w, float* out, int rows, 
 }
 
 // ------------------------------------------------------------------------------------ embeddings
-// One wave copies an embedding row into the residual stream; with the fused RMSNorm (XOut) it also emits the row's
-// f16 planes and its fixed-point sum of squares (the wave owns the whole row: plain store, no atomic).
-__device__ __forceinline__ void copy_row_x(const float4* __restrict__ src, float* __restrict__ out, int row, int d,
-                                           int lane, const XOut& xo) {
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)row * d);   // only written when x_h == nullptr (fp32 mode)
-  float ss = 0.f;
-  for (int i = lane; i < (d >> 2); i += 64) {
-    float4 v = src[i];
-    if (xo.x_h) {
-      const size_t idx = (size_t)row * d + 4 * (size_t)i;
-      __half h[4], l[4];
-      split_f16(v.x * X_PLANE_SCALE, h[0], l[0], xo.sat); split_f16(v.y * X_PLANE_SCALE, h[1], l[1], xo.sat);
-      split_f16(v.z * X_PLANE_SCALE, h[2], l[2], xo.sat); split_f16(v.w * X_PLANE_SCALE, h[3], l[3], xo.sat);
-      *reinterpret_cast<uint2*>(xo.x_h + idx) = *reinterpret_cast<uint2*>(h);
-      *reinterpret_cast<uint2*>(xo.x_h + xo.x_ps + idx) = *reinterpret_cast<uint2*>(l);
-      v = make_float4(x_from_planes(h[0], l[0]), x_from_planes(h[1], l[1]), x_from_planes(h[2], l[2]), x_from_planes(h[3], l[3]));
-    } else {
-      dst[i] = v;
-    }
-    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-  }
-  if (xo.ssq) {
-    ss = wave_sum(ss);
-    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss);
-  }
-}
-
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                                           float* __restrict__ out, int rows, int d, int vocab,
                                                           const int32_t* __restrict__ row_src,
@@ -176,9 +125,10 @@ hipError_t launch_pack_rows(const int32_t* lens, int32_t* offs, int32_t* row_src
 // position 0 is the constant start_token_embed, position t>=1 is list_decoder_embeds[t-1][token_t].
 __global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict__ start, const float* __restrict__ in_embeds,
                                                          const uint16_t* __restrict__ tokens, int tok_ld,
-                                                         float* __restrict__ out, int R, int d, int V, int t, XOut xo) {
+                                                         float* __restrict__ out, int R, int d, int V, int t, XOut xo,
+                                                         const int* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
+  if (row >= R || (rows_dev && row >= *rows_dev)) return;
   const float* src = start;
   if (t > 0) {
     const int tok = tokens[(size_t)row * tok_ld + (t - 1)];
@@ -188,9 +138,9 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const float* __restrict_
 }
 
 hipError_t launch_dec_embed(const float* start, const float* in_embeds, const uint16_t* tokens, int tok_ld,
-                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo) {
+                            float* out, int R, int d, int V, int t, hipStream_t s, XOut xo, const int* rows_dev) {
   hipLaunchKernelGGL(dec_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, s, start, in_embeds, tokens, tok_ld, out,
-                     R, d, V, t, xo);
+                     R, d, V, t, xo, rows_dev);
   return hipGetLastError();
 }
 
@@ -303,7 +253,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
                                                         float* __restrict__ out, int Q, int B, int H, int t, int Lq,
                                                         int xld, __half* __restrict__ out_h, size_t o_ps,
                                                         size_t q_stride, size_t h_stride, size_t pos_stride,
-                                                        size_t slot_stride, unsigned int* sat) {
+                                                        size_t slot_stride, unsigned int* sat, const int* __restrict__ nq_dev) {
   __shared__ float Ss[4][MAX_LQ];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -316,6 +266,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   const int R = Q * B, inner = H * DKV;
   if (w >= R * H) return;
   const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
+  if (nq_dev && qi >= *nq_dev) return;
   const int r = qi * B + b;
   const int g = lane >> 4, li = lane & 15;
   float* S = Ss[wave];
@@ -423,6 +374,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   const int R = a.Q * B, inner = H * DKV;
   if (w >= R * H) return;
   const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
+  if (a.nq_dev && qi >= *a.nq_dev) return;
   const int r = qi * B + b;
   const int g = lane >> 4, li = lane & 15;
   const int nkeys = t + 1;
@@ -509,7 +461,7 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(dec_attn_kernel<true>, dim3((items + 3) / 4), dim3(256), 0, s, a.q, a.kcache, a.vcache, a.anc,
                      a.anc_ld, a.rel_bias, a.bucket, (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps,
-                     a.q_stride, a.h_stride, a.pos_stride, a.slot_stride, a.sat);
+                     a.q_stride, a.h_stride, a.pos_stride, a.slot_stride, a.sat, a.nq_dev);
   return hipGetLastError();
 }
 
@@ -527,6 +479,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   const int b_first = a.bchunk ? (int)blockIdx.y * a.bchunk : 0;
   const int B = a.bchunk ? min(a.bchunk, Bq - b_first) : Bq;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
+  if (a.nq_dev && qi >= *a.nq_dev) return;
   const int SLD = a.Lq + 1;
   float* Ks = smem;                        // [Lq][68]
   float* Vs = Ks + (size_t)a.Lq * XK_LD;   // [Lq][64]

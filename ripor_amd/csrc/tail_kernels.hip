@@ -1,0 +1,416 @@
+// Forced-tail evaluation of the trie-constrained beam search (gfx950, wave64): the fork (which queries can no longer
+// be pruned, compaction of the others into the next stage) and the kernels of the teacher-forced tail pass that are
+// not shared with the sequential steps. Orchestration: api.hip::enqueue_search.
+//
+// Semantics preserved (reference t5_pretrainer/tasks/generation.py): per step, candidate = ((double)logit_f32 +
+// (valid ? 0 : -1e9)) + beam_score in float64 (:453-463); the first B of the sorted candidates become the new beams in
+// that order, ties by ascending flat index beam*V + token (:484-503); finalize ranks by float64 sum/(L+1) descending
+// with exact ties in reverse slot order and stores float32 (:532-540). For a forced query every beam has exactly one
+// valid child per step, so the B winners of a step are those B candidates (fork_classify_kernel proves that no masked
+// candidate can reach them) and only their ORDER has to be replayed: tail_rank_kernel.
+#include "common.h"
+#include "kernel_utils.h"
+
+namespace rpr {
+
+// ------------------------------------------------------------------------------------ fork
+// One wave per stage query. forced <=> every beam is live (non-empty trie range), its range holds one distinct
+// sequence over the columns T..L-1 (first row == last row there: the rows are sorted), and the spread of the beam
+// scores is small enough that B valid continuations stay above every masked candidate for all remaining steps.
+__global__ __launch_bounds__(256) void fork_classify_kernel(ForkArgs a) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= a.Qcap || (a.nq_dev && q >= *a.nq_dev)) return;
+  const int r0 = q * a.B;
+  bool ok = true;
+  double smin = INFINITY, smax = -INFINITY;
+  for (int b = lane; b < a.B; b += 64) {
+    const int lo = a.st.lo[r0 + b], hi = a.st.hi[r0 + b];
+    const double s = a.st.score[r0 + b];
+    smin = fmin(smin, s); smax = fmax(smax, s);
+    if (lo >= hi) { ok = false; continue; }
+    if (hi - lo > 1) {
+      const uint16_t* first = a.codes + (size_t)lo * a.Lc;
+      const uint16_t* last = a.codes + (size_t)(hi - 1) * a.Lc;
+      for (int p = a.T; p < a.L; ++p)
+        if (first[p] != last[p]) { ok = false; break; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    smin = fmin(smin, __shfl_xor(smin, o, 64));
+    smax = fmax(smax, __shfl_xor(smax, o, 64));
+  }
+  const bool all_ok = __all(ok);
+  if (lane == 0) a.flag[q] = (all_ok && (smax - smin) < a.spread_max) ? 1 : 0;   // NaN scores compare false: not forced
+}
+
+hipError_t launch_fork_classify(const ForkArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(fork_classify_kernel, dim3((a.Qcap + 3) / 4), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// One block: the two lists in query order (forced -> flist, the others -> src) and the live counts of the tail pass
+// and of the next stage.
+__global__ __launch_bounds__(1024) void fork_scan_kernel(const int32_t* __restrict__ flag, int Qcap, const int* __restrict__ nq_dev,
+                                                          int B, int Lt, int32_t* __restrict__ flist, int32_t* __restrict__ tail_cnt,
+                                                          int32_t* __restrict__ src, int32_t* __restrict__ next_cnt) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int n = nq_dev ? min(*nq_dev, Qcap) : Qcap;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < n; q0 += 1024) {
+    const int q = q0 + tid;
+    const int v = (q < n && flag[q] != 0) ? 1 : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan
+      const int add = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    if (q < n) {
+      const int nf_before = carry + part[tid] - v;   // forced queries before q
+      if (v) flist[nf_before] = q; else src[q - nf_before] = q;
+    }
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int nf = carry, nu = n - carry;
+    tail_cnt[0] = nf; tail_cnt[1] = nf * B; tail_cnt[2] = nf * B * Lt; tail_cnt[3] = 0;
+    next_cnt[0] = nu; next_cnt[1] = nu * B; next_cnt[2] = 0; next_cnt[3] = 0;
+  }
+}
+
+hipError_t launch_fork_scan(const int32_t* flag, int Qcap, const int* nq_dev, int B, int Lt, int32_t* flist, int32_t* tail_cnt,
+                            int32_t* src, int32_t* next_cnt, hipStream_t s) {
+  hipLaunchKernelGGL(fork_scan_kernel, dim3(1), dim3(1024), 0, s, flag, Qcap, nq_dev, B, Lt, flist, tail_cnt, src, next_cnt);
+  return hipGetLastError();
+}
+
+// one wave per destination query
+__global__ __launch_bounds__(256) void gather_stage_io_kernel(StageIO src, StageOut dst, const int32_t* __restrict__ list,
+                                                               const int* __restrict__ n_dev, int Qcap, int Lq) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= Qcap || i >= *n_dev) return;
+  const int q = list[i];
+  if (lane == 0) {
+    dst.qmap[i] = src.qmap ? src.qmap[q] : q;
+    dst.offs[i] = src.offs ? src.offs[q] : q * Lq;
+    dst.last[i] = src.last[q];
+  }
+  for (int j = lane; j < Lq; j += 64) dst.mask[(size_t)i * Lq + j] = src.mask[(size_t)q * Lq + j];
+}
+
+hipError_t launch_gather_stage_io(const StageIO& src, const StageOut& dst, const int32_t* list, const int* n_dev, int Qcap, int Lq,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(gather_stage_io_kernel, dim3((Qcap + 3) / 4), dim3(256), 0, s, src, dst, list, n_dev, Qcap, Lq);
+  return hipGetLastError();
+}
+
+// one block per destination query
+__global__ __launch_bounds__(256) void compact_beams_kernel(BeamState from, BeamState to, const int32_t* __restrict__ src,
+                                                             const int* __restrict__ n_dev, int B, int T) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (i >= *n_dev) return;
+  const int q = src[i];
+  const size_t rf = (size_t)q * B, rt = (size_t)i * B;
+  for (int b = tid; b < B; b += 256) {
+    to.score[rt + b] = from.score[rf + b];
+    to.lo[rt + b] = from.lo[rf + b];
+    to.hi[rt + b] = from.hi[rf + b];
+  }
+  for (int k = tid; k < B * T; k += 256) {
+    const int b = k / T, p = k - b * T;
+    to.tokens[(rt + b) * to.ld + p] = from.tokens[(rf + b) * from.ld + p];
+    to.anc[(rt + b) * to.ld + p] = from.anc[(rf + b) * from.ld + p];
+  }
+}
+
+hipError_t launch_compact_beams(const BeamState& from, const BeamState& to, const int32_t* src, const int* n_dev, int Qcap, int B, int T,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(compact_beams_kernel, dim3(Qcap), dim3(256), 0, s, from, to, src, n_dev, B, T);
+  return hipGetLastError();
+}
+
+// block (i, layer * H + head): the first n floats of the (layer, query, head) region [depth][B][64] — positions < T
+__global__ __launch_bounds__(256) void kv_copy_kernel(KvCopyArgs a) {
+  const int i = blockIdx.x;
+  if (i >= *a.n_dev) return;
+  const int lh = blockIdx.y, layer = lh / a.H, h = lh - layer * a.H;
+  const size_t of = (size_t)layer * a.layer_from + (size_t)a.src[i] * a.q_from + (size_t)h * a.h_from;
+  const size_t ot = (size_t)layer * a.layer_to + (size_t)i * a.q_to + (size_t)h * a.h_to;
+  const float4* kf = reinterpret_cast<const float4*>(a.k_from + of);
+  const float4* vf = reinterpret_cast<const float4*>(a.v_from + of);
+  float4* kt = reinterpret_cast<float4*>(a.k_to + ot);
+  float4* vt = reinterpret_cast<float4*>(a.v_to + ot);
+  for (int k = threadIdx.x; k < (a.n >> 2); k += 256) { kt[k] = kf[k]; vt[k] = vf[k]; }
+}
+
+hipError_t launch_kv_copy(const KvCopyArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kv_copy_kernel, dim3(a.Qcap, a.nd * a.H), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ tail pass
+// one block per forced query: the whole token row of each of its beams
+__global__ __launch_bounds__(256) void tail_tokens_kernel(BeamState st, const uint16_t* __restrict__ codes, int Lc,
+                                                           const int32_t* __restrict__ flist, const int* __restrict__ nf_dev,
+                                                           int B, int T, int L, uint16_t* __restrict__ tokens) {
+  const int i = blockIdx.x;
+  if (i >= *nf_dev) return;
+  const int q = flist[i];
+  for (int k = threadIdx.x; k < B * L; k += 256) {
+    const int b = k / L, p = k - b * L;
+    const size_t r = (size_t)q * B + b;
+    tokens[((size_t)i * B + b) * L + p] = p < T ? st.tokens[r * st.ld + p] : codes[(size_t)st.lo[r] * Lc + p];
+  }
+}
+
+hipError_t launch_tail_tokens(const BeamState& st, const uint16_t* codes, int Lc, const int32_t* flist, const int* nf_dev, int Qcap,
+                              int B, int T, int L, uint16_t* tokens, hipStream_t s) {
+  hipLaunchKernelGGL(tail_tokens_kernel, dim3(Qcap), dim3(256), 0, s, st, codes, Lc, flist, nf_dev, B, T, L, tokens);
+  return hipGetLastError();
+}
+
+// decoder input embeddings of the tail rows (reference t5_generative_retriever.py:194-214: position p >= 1 takes
+// list_decoder_embeds[p-1][token p-1]); one wave per row
+__global__ __launch_bounds__(256) void tail_embed_kernel(const float* __restrict__ in_embeds, const uint16_t* __restrict__ tokens,
+                                                          float* __restrict__ out, int rows, const int* __restrict__ rows_dev,
+                                                          int T, int L, int d, int V, XOut xo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows || row >= *rows_dev) return;
+  const int Lt = L - T, seq = row / Lt, p = T + (row - seq * Lt);
+  const int tok = tokens[(size_t)seq * L + (p - 1)];
+  copy_row_x(reinterpret_cast<const float4*>(in_embeds + ((size_t)(p - 1) * V + tok) * d), out, row, d, lane, xo);
+}
+
+hipError_t launch_tail_embed(const float* in_embeds, const uint16_t* tokens, float* out, int rows, const int* rows_dev, int T, int L,
+                             int d, int V, hipStream_t s, XOut xo) {
+  if (rows <= 0 || T < 1) return rows <= 0 ? hipSuccess : hipErrorInvalidValue;
+  hipLaunchKernelGGL(tail_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in_embeds, tokens, out, rows, rows_dev, T, L, d, V, xo);
+  return hipGetLastError();
+}
+
+// Causal self-attention of the tail positions of one beam: one block per (sequence, head). K and V of all L positions
+// are staged once in LDS — positions < T from the fork stage's KV cache through the beam's ancestry (written by the
+// sequential steps, never moved), positions >= T from this pass's own q|k|v rows — then every wave handles query
+// positions T + wave, T + wave + 4, ...: lane j scores key j (L <= 64), the q row is broadcast with v_readlane,
+// softmax across the wave, P.V with lane = output dim. Arithmetic of dec_self_attn_fast_kernel / enc_attn_kernel
+// (unscaled scores + unidirectional relative bias, fp32 softmax normalised before P.V).
+__global__ __launch_bounds__(256) void tail_self_attn_kernel(TailSelfAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
+  const int seq = blockIdx.x / H, h = blockIdx.x - seq * H;
+  if (seq >= *a.nseq_dev) return;
+  float* Ks = smem;                    // [L][65]
+  float* Vs = smem + (size_t)L * 65;   // [L][64]
+  float* Ps = Vs + (size_t)L * 64;     // [4][64]
+  float* Bs = Ps + 4 * 64;             // [buckets <= 64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = seq / a.B, b = seq - fi * a.B;
+  const int qi = a.flist[fi];
+  const uint16_t* ancr = a.anc + ((size_t)qi * a.B + b) * a.anc_ld;
+  const size_t cbase = (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
+  const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * DKV;
+  for (int i = tid; i < L * 16; i += 256) {
+    const int j = i >> 4, c = (i & 15) * 4;
+    float4 kv, vv;
+    if (j < T) {
+      const size_t off = cbase + (size_t)j * a.pos_stride + (size_t)ancr[j] * a.slot_stride + c;
+      kv = *reinterpret_cast<const float4*>(a.kcache + off);
+      vv = *reinterpret_cast<const float4*>(a.vcache + off);
+    } else {
+      const float* r = tbase + (size_t)(j - T) * ld + c;
+      kv = *reinterpret_cast<const float4*>(r + inner);
+      vv = *reinterpret_cast<const float4*>(r + 2 * inner);
+    }
+    float* kd = Ks + j * 65 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+  }
+  if (tid < 64) Bs[tid] = a.rel_bias[a.bucket[tid] * H + h];   // bias of distance n = i - j (bucket table: MAX_DEC_LEN = 64 entries)
+  __syncthreads();
+  float* P = Ps + wave * 64;
+  for (int i = T + wave; i < L; i += 4) {
+    const float qv = tbase[(size_t)(i - T) * ld + lane];  // lane d holds q_i[d]
+    const int jc = lane <= i ? lane : i;
+    const float* kr = Ks + jc * 65;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKV; ++d) {
+      const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
+      acc = fmaf(qd, kr[d], acc);
+    }
+    const float sc = lane <= i ? acc + Bs[i - lane] : -INFINITY;
+    const float mx = wave_max(sc);
+    const float e = (sc == -INFINITY) ? 0.f : expf(sc - mx);
+    const float sum = wave_sum(e);
+    P[lane] = e / sum;
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int j = 0; j <= i; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
+    const size_t oidx = ((size_t)seq * Lt + (i - T)) * inner + h * DKV + lane;
+    if (a.out_h) {
+      __half hi, lo;
+      split_f16(o * A_PLANE_SCALE, hi, lo, a.sat);
+      a.out_h[oidx] = hi;
+      a.out_h[a.o_ps + oidx] = lo;
+    } else {
+      a.out[oidx] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static size_t tail_self_attn_smem(int L) { return ((size_t)L * 65 + (size_t)L * 64 + 4 * 64 + 64) * sizeof(float); }
+
+hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
+  if (a.L > MAX_DEC_LEN || a.T < 1 || a.T >= a.L) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(tail_self_attn_kernel, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L), s, a);
+  return hipGetLastError();
+}
+
+// Gold-code score of a tail row: final RMSNorm of the row's stream (times d_model^-0.5 under scaleup_output_hidden)
+// dotted with the OUTPUT codebook row of the token at that position = the logit the sequential step's GEMM would give
+// the beam's only valid child (reference get_lm_logits, t5_generative_retriever.py:250-262), in exact fp32.
+__global__ __launch_bounds__(256) void tail_gold_kernel(const float* __restrict__ x, const float* __restrict__ ln,
+                                                         const float* __restrict__ out_embeds, const uint16_t* __restrict__ tokens,
+                                                         float* __restrict__ gold, int rows, const int* __restrict__ rows_dev, int T,
+                                                         int L, int d, int V, float eps, float post, const __half* __restrict__ x_h,
+                                                         size_t x_ps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows || row >= *rows_dev) return;
+  const int Lt = L - T, seq = row / Lt, p = T + (row - seq * Lt);
+  const int tok = tokens[(size_t)seq * L + p];
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);   // only dereferenced when x_h == nullptr
+  const float4* wr = reinterpret_cast<const float4*>(ln);
+  const float4* er = reinterpret_cast<const float4*>(out_embeds + ((size_t)p * V + tok) * d);
+  const int n4 = d >> 2;
+  auto load4 = [&](int k) -> float4 {
+    if (!x_h) return xr[k];
+    const size_t idx = (size_t)row * d + 4 * (size_t)k;
+    const uint2 hh = *reinterpret_cast<const uint2*>(x_h + idx), ll = *reinterpret_cast<const uint2*>(x_h + x_ps + idx);
+    const __half* h = reinterpret_cast<const __half*>(&hh); const __half* l = reinterpret_cast<const __half*>(&ll);
+    return make_float4(x_from_planes(h[0], l[0]), x_from_planes(h[1], l[1]), x_from_planes(h[2], l[2]), x_from_planes(h[3], l[3]));
+  };
+  float ss = 0.f;
+  for (int k = lane; k < n4; k += 64) {
+    const float4 v = load4(k);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)d + eps);
+  float acc = 0.f;
+  for (int k = lane; k < n4; k += 64) {
+    const float4 v = load4(k), g = wr[k], e = er[k];
+    float4 hd = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
+    if (post != 1.0f) { hd.x *= post; hd.y *= post; hd.z *= post; hd.w *= post; }
+    acc += (hd.x * e.x + hd.y * e.y) + (hd.z * e.z + hd.w * e.w);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) gold[row] = acc;
+}
+
+hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_embeds, const uint16_t* tokens, float* gold, int rows,
+                            const int* rows_dev, int T, int L, int d, int V, float eps, float post, hipStream_t s, const __half* x_h,
+                            size_t x_ps) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tail_gold_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ln, out_embeds, tokens, gold, rows, rows_dev, T, L, d, V,
+                     eps, post, x_h, x_ps);
+  return hipGetLastError();
+}
+
+// One block per forced query: replay of the remaining L - T selection steps and the finalize step on the B forced
+// candidates. Per step the B winners are the beams' single valid children; new slot order = (cumulative score desc,
+// parent slot asc) — the sort order of the sequential select_kernel restricted to those candidates. Then
+// finalize_kernel's rule: rank by float64 sum/(L+1) desc, exact ties in reverse slot order, float32 store.
+__global__ __launch_bounds__(256) void tail_rank_kernel(TailRankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (i >= *a.nf_dev) return;
+  const int B = a.B, T = a.T, L = a.L, Lt = L - T;
+  double* S = reinterpret_cast<double*>(smem_raw);       // [B] cumulative score of the beam that started in slot b
+  int* pos = reinterpret_cast<int*>(S + B);              // [B] its current slot
+  int* npos = pos + B;                                   // [B]
+  const int q = a.flist[i];
+  const size_t r0 = (size_t)q * B;
+  for (int b = tid; b < B; b += 256) { S[b] = a.st.score[r0 + b]; pos[b] = b; }
+  __syncthreads();
+  for (int t = 0; t < Lt; ++t) {
+    for (int b = tid; b < B; b += 256) S[b] = ((double)a.gold[((size_t)i * B + b) * Lt + t] + 0.0) + S[b];
+    __syncthreads();
+    for (int b = tid; b < B; b += 256) {
+      const double s = S[b];
+      const int pb = pos[b];
+      int rk = 0;
+      for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] < pb);
+      npos[b] = rk;
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += 256) pos[b] = npos[b];
+    __syncthreads();
+  }
+  for (int b = tid; b < B; b += 256) S[b] = S[b] / (double)(L + 1);
+  __syncthreads();
+  const size_t o0 = (size_t)a.qmap[i] * B;
+  for (int b = tid; b < B; b += 256) {
+    const double s = S[b];
+    const int pb = pos[b];
+    int rk = 0;
+    for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] > pb);
+    npos[b] = rk;
+    a.out_scores[o0 + rk] = (float)s;
+    a.out_lo[o0 + rk] = a.st.lo[r0 + b];
+    a.out_hi[o0 + rk] = a.st.hi[r0 + b];
+  }
+  __syncthreads();
+  for (int k = tid; k < B * L; k += 256) {
+    const int b = k / L, p = k - b * L;
+    a.out_tokens[(o0 + npos[b]) * L + p] = (int32_t)a.tokens[((size_t)i * B + b) * L + p];
+  }
+}
+
+hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)a.B * (sizeof(double) + 2 * sizeof(int)) + 16;
+  hipLaunchKernelGGL(tail_rank_kernel, dim3(a.Qcap), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// max over rows of || E[r] (*) w ||_2, as the bit pattern of a non-negative float through atomicMax (out zeroed)
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, const float* __restrict__ w, int rows, int d,
+                                                            float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float ss = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float v = E[(size_t)row * d + k] * (w ? w[k] : 1.0f);
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) {
+    float n = sqrtf(ss);
+    if (!(n >= 0.f)) n = INFINITY;   // NaN: no bound
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(n));
+  }
+}
+
+hipError_t launch_max_row_norm(const float* E, const float* w, int rows, int d, float* out, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(max_row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, E, w, rows, d, out);
+  return hipGetLastError();
+}
+
+hipError_t init_tail_kernel_attributes() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(tail_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
+
+}  // namespace rpr

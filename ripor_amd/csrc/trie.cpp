@@ -94,6 +94,39 @@ int sort_codes(const uint16_t* codes, int64_t N, int L, std::vector<uint16_t>& s
   return 0;
 }
 
+// ---- forced-tail statistics ----------------------------------------------------------------------------------------------
+// For a search of length L over the sorted matrix: frac[t] (t = 0..L) = the fraction of the trie nodes at depth t
+// (distinct t-prefixes) under which exactly ONE distinct L-token sequence remains. A beam standing on such a node has
+// a single valid child at every remaining step, so its tokens are known and only its scores are missing; a query
+// whose beams all stand on such nodes is "forced" (api.hip: forced-tail evaluation). One pass over adjacent rows:
+// c_i = min(lcp(row i-1, row i), L); the rows between two boundaries with c < L are one distinct sequence ("run");
+// with a / b the c of its left / right boundary (-1 at the ends of the matrix) the run opens a new node at every
+// depth t > a and is alone in its node at every depth t > max(a, b).
+void trie_single_frac(const uint16_t* sorted, int64_t N, int Lc, int L, std::vector<double>& frac) {
+  std::vector<int64_t> nodes((size_t)L + 2, 0), single((size_t)L + 2, 0);   // histograms over a + 1 and max(a, b) + 1
+  int a = -1;
+  for (int64_t i = 1; i <= N; ++i) {
+    int c = -1;                                  // right boundary of the run that ends at row i - 1
+    if (i < N) {
+      const uint16_t* p = sorted + (size_t)(i - 1) * Lc;
+      const uint16_t* q = p + Lc;
+      c = 0;
+      while (c < L && p[c] == q[c]) ++c;
+      if (c == L) continue;                      // same sequence: the run goes on
+    }
+    nodes[(size_t)(a + 1)] += 1;
+    single[(size_t)((a > c ? a : c) + 1)] += 1;
+    a = c;
+  }
+  frac.assign((size_t)L + 1, 0.0);
+  int64_t n = 0, s = 0;
+  for (int t = 0; t <= L; ++t) {                 // nodes at depth t: runs with a < t; single: runs with max(a, b) < t
+    n += nodes[(size_t)t];
+    s += single[(size_t)t];
+    frac[(size_t)t] = n ? (double)s / (double)n : 0.0;
+  }
+}
+
 // ---- docid_to_smtid.json ------------------------------------------------------------------------------------
 // One pass over the file with a 4 MB read buffer; no DOM. The reference loads this file with ujson into a dict of
 // 8.8 M Python lists (minutes and tens of GB, evaluate.py:400-402); here it becomes a uint16 matrix directly.

@@ -9,6 +9,8 @@ int save_trie_file(const char* path, const std::vector<uint16_t>& sorted, const 
                    int64_t N, int L, int V, const std::string& keys, int64_t src_size, int64_t src_mtime_ns);
 int load_trie_file(const char* path, std::vector<uint16_t>& sorted, std::vector<int64_t>& perm, int64_t& N, int& L,
                    int& V, std::string& keys, std::string& err);
+// forced-tail statistics: frac[t] = share of the depth-t trie nodes that hold a single distinct L-token sequence
+void trie_single_frac(const uint16_t* sorted, int64_t N, int Lc, int L, std::vector<double>& frac);
 // header words {N, L, V, key_bytes, src_size, src_mtime_ns} of a trie file (no payload read)
 int trie_file_info(const char* path, int64_t hdr_out[6]);
 // Streaming reader of the reference's docid_to_smtid.json: {"docid": [-1, c1, ..., cL], ...}

@@ -67,6 +67,36 @@ class Context:
         """The threshold in force; 0 when splitting is off or masked streams are unavailable."""
         return int(self.lib.rpr_lane_split(self.handle))
 
+    def set_forced_tail(self, on: bool):
+        """Forced-tail evaluation (``rpr_set_forced_tail``; default on): queries whose beams can no longer be pruned
+        leave the step-by-step loop at a fork and get their remaining positions scored in one teacher-forced pass."""
+        check(self.lib.rpr_set_forced_tail(self.handle, 1 if on else 0), "rpr_set_forced_tail")
+
+    def set_fork_depths(self, depths: Optional[Sequence[int]]):
+        """Explicit fork depths (ascending, at most two; ``[]`` = never fork); ``None`` = choose from the trie statistics."""
+        if depths is None:
+            check(self.lib.rpr_set_fork_depths(self.handle, -1, None), "rpr_set_fork_depths")
+        else:
+            arr = (C.c_int32 * max(1, len(depths)))(*[int(d) for d in depths])
+            check(self.lib.rpr_set_fork_depths(self.handle, len(depths), arr), "rpr_set_fork_depths")
+
+    def fork_depths(self, model: "DeviceModel", trie: "DeviceTrie", Q: int, B: int, L: int, log_softmax: bool = False) -> List[int]:
+        """The fork depths a search of this shape would use (``rpr_fork_depths``)."""
+        out = (C.c_int32 * 2)()
+        n = int(self.lib.rpr_fork_depths(self.handle, model.handle, trie.handle, Q, B, L,
+                                         _lib.FLAG_LOG_SOFTMAX if log_softmax else 0, out))
+        if n < 0:
+            check(n, "rpr_fork_depths")
+        return [int(out[i]) for i in range(n)]
+
+    def last_fork_stats(self) -> List[dict]:
+        """Per fork of the last search: depth, queries forced there, queries that walked on (synchronises the device)."""
+        d, f, l = (C.c_int32 * 2)(), (C.c_int32 * 2)(), (C.c_int32 * 2)()
+        n = int(self.lib.rpr_last_fork_stats(self.handle, d, f, l))
+        if n < 0:
+            check(n, "rpr_last_fork_stats")
+        return [dict(depth=int(d[i]), forced=int(f[i]), left=int(l[i])) for i in range(n)]
+
     def status(self, clear: bool = True) -> int:
         """Synchronises the current stream and returns the sticky status flags of the work enqueued so far
         (``_lib.STATUS_SATURATED``: an activation left the f16 plane range in f16x2 mode and was clamped — the results
@@ -152,6 +182,18 @@ def build_trie_file(codes: np.ndarray, V: int, path: str, docids: Optional[Seque
         size, mtime = st.st_size, st.st_mtime_ns
     check(lib.rpr_trie_build_file(codes.ctypes.data_as(C.c_void_p), N, L, int(V), keys, len(keys), size, mtime,
                                   path.encode()), "rpr_trie_build_file")
+
+
+def trie_single_frac(codes: np.ndarray, L: Optional[int] = None) -> np.ndarray:
+    """HOST ONLY: share of the depth-t trie nodes (t = 0..L) that hold a single distinct L-token sequence
+    (``rpr_trie_single_frac``) — the statistic behind the automatic fork depths of the forced-tail search."""
+    lib = _lib.load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint16)
+    N, Lc = codes.shape
+    L = Lc if L is None else int(L)
+    out = (C.c_double * (L + 1))()
+    check(lib.rpr_trie_single_frac(codes.ctypes.data_as(C.c_void_p), N, Lc, L, out), "rpr_trie_single_frac")
+    return np.asarray(list(out), dtype=np.float64)
 
 
 def trie_file_info(path: str) -> dict:

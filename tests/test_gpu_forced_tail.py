@@ -1,0 +1,196 @@
+"""-m gpu: the forced-tail evaluation (rpr_search's forks + teacher-forced tail passes, ripor_amd/csrc/api.hip,
+tail_kernels.hip) against the plain step-by-step loop and against the CPU oracle.
+
+The step-by-step loop is what the reference does (tasks/generation.py:423-540, one model call + mask + top-k per
+position) and is itself pinned to the reference's golden vectors (test_gpu_parity.py, which also runs every golden with
+forks). Here: shapes the goldens do not reach — tries dense enough that most queries are forced by the automatic
+depths while some are not, duplicated smtids (ranges of many rows holding one sequence), prefix search, skewed codes,
+beam 1, the exact-fp32 mode, and the lane split.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ORDER_TOL, SCORE_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from ripor_amd import engine
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return engine
+
+
+def _setup(E, codes, L_model, V, seed=3, Q=24):
+    from ripor_amd.utils import synth
+    dims = synth.mini_dims(L=L_model, V=V, enc_layers=1, d_ff=128)
+    sd = synth.make_state_dict(dims, seed=seed)
+    ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=14)
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    return ctx, model, trie, sd, dims, ids, mask
+
+
+def _same_as_plain(ctx, E, model, trie, ids, mask, B, L, label):
+    """forced-tail result == step-by-step result: identical sequences and row ranges at every rank outside score
+    near-ties, scores within 0.3 of the parity tolerance (the step loop takes a logit from the split-precision GEMM, the tail from an exact fp32 dot product)."""
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ctx.set_forced_tail(False)
+    plain = E.search(model, trie, ti, tm, B, L)
+    ctx.set_forced_tail(True)
+    res = E.search(model, trie, ti, tm, B, L)
+    torch.cuda.synchronize()
+    stats = ctx.last_fork_stats()
+    same = (res.tokens == plain.tokens).all(dim=2)
+    close = (res.scores - plain.scores).abs() <= ORDER_TOL
+    live = plain.scores > -1e6                   # dead beams (-1e9) carry arbitrary masked tokens in both paths
+    assert bool((same | close | ~live).all()), f"{label}: sequences differ from the step-by-step loop"
+    err = float(((res.scores - plain.scores).abs() * live).max())
+    assert err <= 0.3 * SCORE_TOL, (label, err)
+    both = same & live
+    assert torch.equal(res.row_lo[both], plain.row_lo[both]) and torch.equal(res.row_hi[both], plain.row_hi[both])
+    print(f"[forced tail] {label}: forks {stats}, max score diff {err:.2e}, {int(same.sum())}/{same.numel()} ranks identical")
+    return res, plain, stats
+
+
+def test_dense_trie_most_queries_forced_some_not(E):
+    """60k docs under 256^2 = 65k depth-2 prefixes: the automatic first fork takes most queries, the rest walk on
+    through the second stage; both populations must reproduce the plain loop, and the oracle."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd.utils import synth
+    L, V, B, N = 8, 256, 10, 60_000
+    codes = synth.make_codes(N, L, V, seed=11)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=48)
+    depths = ctx.fork_depths(model, trie, ids.shape[0], B, L)
+    assert len(depths) >= 1 and depths[0] in (2, 3, 4), depths
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "dense 60k")
+    assert stats[0]["forced"] + stats[0]["left"] == ids.shape[0]
+    assert stats[0]["forced"] > 0, "the fork took no query: the test does not exercise the tail pass"
+    # explicit early fork: a good share of the queries is NOT forced at depth 2 and takes the compacted stages
+    ctx.set_fork_depths([2, 3])
+    try:
+        res2, _, st2 = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "dense 60k forks [2,3]")
+        assert st2[0]["left"] > 0 and st2[1]["forced"] > 0, st2
+    finally:
+        ctx.set_fork_depths(None)
+    # oracle on a few queries (the KV-cached CPU restatement of the reference loop)
+    nq = 6
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids[:nq], mask[:nq], B, L, use_kv_cache=True)
+    ref_tok = seqs.numpy().reshape(nq, B, L + 1)[:, :, 1:]
+    ref_sc = sc.numpy().reshape(nq, B)
+    got_tok, got_sc = res.tokens[:nq].cpu().numpy(), res.scores[:nq].cpu().numpy()
+    near = np.zeros((nq, B), dtype=bool)
+    near[:, 1:] |= (ref_sc[:, :-1] - ref_sc[:, 1:]) <= ORDER_TOL
+    near[:, :-1] |= (ref_sc[:, :-1] - ref_sc[:, 1:]) <= ORDER_TOL
+    assert ((got_tok == ref_tok).all(axis=2) | near).all(), "forced-tail sequences differ from the oracle"
+    np.testing.assert_allclose(got_sc, ref_sc, atol=SCORE_TOL, rtol=0)
+
+
+def test_duplicated_smtids_are_single_sequences(E):
+    """Many docs per smtid (evaluate.py:439-446 appends every docid of an smtid): a beam's range holds several ROWS
+    but one distinct sequence, so it is forced; the returned ranges must cover all duplicates."""
+    from ripor_amd.utils import synth
+    L, V, B = 6, 256, 8
+    base = synth.make_codes(3000, L, V, seed=21)
+    rep = 1 + (synth.randint("dup", (3000,), 0, 5, seed=21))
+    codes = np.repeat(base, rep, axis=0)
+    perm = synth.randint("dupperm", (codes.shape[0],), 0, 1 << 30, seed=21).argsort(kind="stable")
+    codes = codes[perm]
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V)
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "duplicated smtids")
+    assert stats and stats[0]["forced"] > 0
+    n = (res.row_hi - res.row_lo).cpu().numpy()
+    assert n.max() > 1 and n.min() >= 1, "ranges of duplicated smtids must hold all their docs"
+
+
+def test_prefix_search_shorter_than_the_trie(E):
+    """max_new_token < trie depth (evaluate.py:134-178, the training-data generation callers): 'one distinct
+    sequence' is judged on the first L columns only, the final ranges hold every doc sharing the L-prefix."""
+    from ripor_amd.utils import synth
+    Lc, L, V, B = 8, 3, 256, 10
+    codes = synth.make_codes(30_000, Lc, V, seed=31)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, Lc, V)
+    ctx.set_fork_depths([1])
+    try:
+        res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=3 of 8, fork [1]")
+    finally:
+        ctx.set_fork_depths(None)
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=3 of 8, automatic")
+    L = 5
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=5 of 8, automatic")
+    assert stats and stats[0]["forced"] > 0, stats
+
+
+def test_skewed_codes_and_beam_one(E):
+    from ripor_amd.utils import synth
+    L, V = 8, 256
+    codes = synth.make_codes(40_000, L, V, seed=41, skew=True)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=32)
+    for B in (1, 4, 10):
+        _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"skewed 40k beam {B}")
+    ctx.set_fork_depths([2, 4])
+    try:
+        _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, 10, L, "skewed 40k forks [2,4]")
+        assert st[0]["left"] > 0
+    finally:
+        ctx.set_fork_depths(None)
+
+
+def test_exact_fp32_mode_and_lane_split(E):
+    from ripor_amd.utils import synth
+    L, V, B = 8, 256, 10
+    codes = synth.make_codes(50_000, L, V, seed=51)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=40)
+    ctx.set_precision("f32")
+    try:
+        _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "exact fp32")
+    finally:
+        ctx.set_precision("f16x2")
+    saved = ctx.lane_split()
+    ctx.set_lane_split(64)           # 40 queries x 10 beams >= 64 rows: two lanes of 20 queries
+    try:
+        if ctx.lane_split() > 0:
+            res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "two lanes")
+            assert sum(s["forced"] + s["left"] for s in stats[:1]) == ids.shape[0]
+    finally:
+        ctx.set_lane_split(saved)
+
+
+def test_large_beam_forced_tail(E):
+    """beam 100 and beam 300 (> 256 takes the sorted select path) on a trie with enough leaves."""
+    from ripor_amd.utils import synth
+    L, V = 6, 256
+    codes = synth.make_codes(200_000, L, V, seed=61)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=6)
+    for B in (100, 300):
+        _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"200k docs beam {B}")
+    ctx.set_fork_depths([3])
+    try:
+        _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, 100, L, "200k docs beam 100 fork [3]")
+        assert st[0]["forced"] > 0
+    finally:
+        ctx.set_fork_depths(None)
+
+
+def test_log_softmax_and_taps_never_fork(E):
+    from ripor_amd.utils import synth
+    L, V, B = 8, 256, 4
+    codes = synth.make_codes(50_000, L, V, seed=71)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=8)
+    assert ctx.fork_depths(model, trie, 8, B, L) != []
+    assert ctx.fork_depths(model, trie, 8, B, L, log_softmax=True) == []
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    a = E.search(model, trie, ti, tm, B, L, apply_log_softmax_for_scores=True)
+    torch.cuda.synchronize()
+    assert ctx.last_fork_stats() == []
+    b = E.search(model, trie, ti, tm, B, L, taps=True)
+    torch.cuda.synchronize()
+    assert ctx.last_fork_stats() == []
+    c = E.search(model, trie, ti, tm, B, L)
+    torch.cuda.synchronize()
+    assert len(ctx.last_fork_stats()) >= 1
+    assert torch.equal(b.tokens, c.tokens)

@@ -70,6 +70,30 @@ def test_search_matches_reference_golden(engine, golden_cache, name):
         compare_ranked(g, res4.tokens.cpu().numpy(), res4.scores.cpu().numpy(), label=" (exact fp32)")
     finally:
         ctx.set_precision("f16x2")
+    # Forced-tail evaluation. The runs above used the fork depths chosen from the trie (printed); here the plain
+    # step-by-step loop and explicit forks (first step, two adjacent forks, the last possible depth) face the same bar,
+    # and every variant must return the sequences of the plain loop with scores within 0.3 of the tolerance.
+    auto = ctx.fork_depths(model, trie, g.Q, g.B, g.L, g.log_softmax)
+    print(f"[forced tail] {name}: automatic fork depths {auto}")
+    try:
+        ctx.set_forced_tail(False)
+        plain = _run(engine, g, model, trie)
+        compare_ranked(g, plain.tokens.cpu().numpy(), plain.scores.cpu().numpy(), label=" (no forced tail)")
+        ctx.set_forced_tail(True)
+        for depths in ([1], [2, 3], [g.L - 1], [1, g.L - 1]):
+            if any(t >= g.L for t in depths) or len(set(depths)) != len(depths):
+                continue
+            ctx.set_fork_depths(depths)
+            r = _run(engine, g, model, trie)
+            compare_ranked(g, r.tokens.cpu().numpy(), r.scores.cpu().numpy(), label=f" (forks {depths})")
+            same = (r.tokens == plain.tokens).all(dim=2)          # [Q, B]
+            close = (r.scores - plain.scores).abs() <= ORDER_TOL
+            assert bool((same | close).all()), f"{name} forks {depths}: sequences differ from the step-by-step loop outside near-ties"
+            assert float((r.scores - plain.scores).abs().max()) <= 0.3 * SCORE_TOL
+            assert torch.equal(r.row_lo[same], plain.row_lo[same]) and torch.equal(r.row_hi[same], plain.row_hi[same])
+    finally:
+        ctx.set_fork_depths(None)
+        ctx.set_forced_tail(True)
 
 
 def _unpack_valid(words, B, V):

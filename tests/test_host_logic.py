@@ -483,3 +483,28 @@ def test_auto_batch_aligns_decoder_rows_to_whole_gemm_rounds():
     for q_max, beams, d in ((2048, 10, 768), (1000, 10, 768), (48, 1000, 768), (300, 100, 1024)):
         q = align(q_max, beams, d)
         assert 0.75 * q_max - 1 <= q <= q_max
+
+
+def test_trie_single_frac_matches_brute_force():
+    """Statistic behind the automatic fork depths of the forced-tail search (rpr_trie_single_frac, host only): share of
+    the depth-t trie nodes under which one distinct L-token sequence remains, against a dict-of-sets count; uniform and
+    skewed codes, duplicates (tiny vocab), prefix length L < trie depth, a single doc."""
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+
+    def brute(codes, L):
+        full = [tuple(int(x) for x in r[:L]) for r in codes]
+        out = []
+        for t in range(L + 1):
+            nodes = {}
+            for r in full:
+                nodes.setdefault(r[:t], set()).add(r)
+            out.append(sum(1 for v in nodes.values() if len(v) == 1) / len(nodes))
+        return np.asarray(out)
+
+    for (N, Lc, V, L, skew) in [(500, 6, 8, 6, False), (2000, 5, 16, 3, False), (300, 4, 4, 4, True), (1, 3, 4, 3, False),
+                                (4000, 8, 256, 8, False), (4000, 8, 256, 5, True)]:
+        codes = synth.make_codes(N, Lc, V, seed=N + L, skew=skew)
+        np.testing.assert_allclose(E.trie_single_frac(codes, L), brute(codes, L), rtol=0, atol=1e-12)
+    f = E.trie_single_frac(synth.make_codes(4000, 8, 256, seed=1))
+    assert f[0] == 0.0 and f[-1] == 1.0 and (np.diff(f) >= -1e-12).all()
