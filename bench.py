@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-lanes", action="store_true",
                     help="one stream for the whole batch instead of two half batches on two CU-masked streams")
+    ap.add_argument("--forced-tail", type=int, default=2, choices=[0, 1, 2], dest="forced_tail",
+                    help="0 = plain step-by-step loop, 1 = forced tail, exact on the device, 2 = optimistic (default; "
+                         "falls back to 1 if a query was left unforced)")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"],
                     help="GEMM arithmetic: f16x2 = fp32 operands as two f16 planes, 3 f16 MFMAs per product "
                          "(fp32-equivalent to ~2^-22); f32 = exact fp32 MFMA")
@@ -192,6 +195,10 @@ def main():
     sd = synth.make_state_dict(dims)
     ctx = E.Context.get(local_rank)
     ctx.set_precision(args.precision)
+    # forced-tail evaluation: 2 = optimistic (no stage after the last fork; a query left unforced there raises the
+    # sticky TAIL_LEFTOVER word, checked after the timed region — the number is then void and the run is repeated in
+    # the exact mode 1), 1 = exact on the device, 0 = plain step-by-step loop
+    ctx.set_forced_tail(args.forced_tail)
     if args.no_lanes:
         ctx.set_lane_split(0)
     if args.batch is None:
@@ -229,59 +236,77 @@ def main():
         ids, mask, _ = batches[i]
         return E.search(model, trie, ids, mask, B, L, use_graph=not args.no_graph)
 
-    for i in range(W):
-        res = run_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    results = []
-    for i in range(K):
-        results.append(run_step(W + i))
-    if world > 1:  # the path's only collective: gather the ranked results (run.json merge)
-        tok = torch.stack([r.tokens for r in results])
-        sc = torch.stack([r.scores for r in results])
-        tok_all = torch.empty((world * tok.shape[0],) + tuple(tok.shape[1:]), dtype=tok.dtype, device=dev)
-        sc_all = torch.empty((world * sc.shape[0],) + tuple(sc.shape[1:]), dtype=sc.dtype, device=dev)
-        dist.all_gather_into_tensor(tok_all, tok)
-        dist.all_gather_into_tensor(sc_all, sc)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region():
+        for i in range(W):
+            res = run_step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        results = []
+        for i in range(K):
+            results.append(run_step(W + i))
+        if world > 1:  # the path's only collective: gather the ranked results (run.json merge)
+            tok = torch.stack([r.tokens for r in results])
+            sc = torch.stack([r.scores for r in results])
+            tok_all = torch.empty((world * tok.shape[0],) + tuple(tok.shape[1:]), dtype=tok.dtype, device=dev)
+            sc_all = torch.empty((world * sc.shape[0],) + tuple(sc.shape[1:]), dtype=sc.dtype, device=dev)
+            dist.all_gather_into_tensor(tok_all, tok)
+            dist.all_gather_into_tensor(sc_all, sc)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
 
-    # Second timed loop, same K steps, with the boundary's PCIe legs inside (SURVEY §8d wording of the metric): ids and
-    # mask start in pinned host memory, results end in pinned host memory. Reported as value_pcie_inclusive; `value`
-    # stays the resident-input rate.
-    host_in = [(b[0].cpu().pin_memory(), b[1].cpu().pin_memory()) for b in batches[W:W + K]]
-    host_out = None
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t_pcie = time.perf_counter()
-    for i in range(K):
-        ids_d = host_in[i][0].to(dev, non_blocking=True)
-        mask_d = host_in[i][1].to(dev, non_blocking=True)
-        r = E.search(model, trie, ids_d, mask_d, B, L, use_graph=not args.no_graph)
-        if host_out is None:
-            host_out = [torch.empty(x.shape, dtype=x.dtype).pin_memory() for x in (r.tokens, r.scores, r.row_lo, r.row_hi)]
-        for dst, src in zip(host_out, (r.tokens, r.scores, r.row_lo, r.row_hi)):
-            dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_pcie = time.perf_counter() - t_pcie
-    if world > 1:
-        t = torch.tensor([elapsed_pcie], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_pcie = float(t.item())
-    status_flags = ctx.status(clear=True)   # sticky saturation / empty-query word over everything run so far
+        # Second timed loop, same K steps, with the boundary's PCIe legs inside (SURVEY §8d wording of the metric): ids and
+        # mask start in pinned host memory, results end in pinned host memory. Reported as value_pcie_inclusive; `value`
+        # stays the resident-input rate.
+        host_in = [(b[0].cpu().pin_memory(), b[1].cpu().pin_memory()) for b in batches[W:W + K]]
+        host_out = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_pcie = time.perf_counter()
+        for i in range(K):
+            ids_d = host_in[i][0].to(dev, non_blocking=True)
+            mask_d = host_in[i][1].to(dev, non_blocking=True)
+            r = E.search(model, trie, ids_d, mask_d, B, L, use_graph=not args.no_graph)
+            if host_out is None:
+                host_out = [torch.empty(x.shape, dtype=x.dtype).pin_memory() for x in (r.tokens, r.scores, r.row_lo, r.row_hi)]
+            for dst, src in zip(host_out, (r.tokens, r.scores, r.row_lo, r.row_hi)):
+                dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_pcie = time.perf_counter() - t_pcie
+        if world > 1:
+            t = torch.tensor([elapsed_pcie], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_pcie = float(t.item())
+        status_flags = ctx.status(clear=True)   # sticky saturation / empty-query word over everything run so far
+        return elapsed, elapsed_pcie, status_flags, results, (tok if world > 1 else None), (sc if world > 1 else None)
 
+    elapsed, elapsed_pcie, status_flags, results, tok, sc = timed_region()
+    tail_mode = args.forced_tail
+    leftover = bool(status_flags & 4)
+    if world > 1:   # every rank must take the same path
+        t = torch.tensor([1 if leftover else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        leftover = bool(t.item())
+    if leftover and tail_mode == 2:
+        # optimistic forced tail: a query was still unforced at the last fork, its outputs are unspecified -> the timed
+        # region is void; repeat it in the exact mode
+        log("[bench] TAIL_LEFTOVER raised in optimistic mode: repeating the timed region in the exact forced-tail mode")
+        tail_mode = 1
+        ctx.set_forced_tail(1)
+        elapsed, elapsed_pcie, status_flags, results, tok, sc = timed_region()
+
+    fork_stats = ctx.last_fork_stats()   # of the last search (the PCIe-inclusive loop's last step: same shapes)
     # sanity on the timed outputs: every returned smtid of the last step is a trie leaf range
     last = results[-1]
     n_leaf = int((last.row_hi > last.row_lo).sum().item())
@@ -307,6 +332,12 @@ def main():
             "rccl_world_size": dist.get_world_size() if world > 1 else 1,
             "gather_bytes_per_rank": int(tok.numel() * tok.element_size() + sc.numel() * sc.element_size()) if world > 1 else 0,
             "saturated": bool(status_flags & 1), "model_f32_only": bool(model.f32_only),
+            "forced_tail": {"mode": {0: "off (step-by-step loop)", 1: "exact", 2: "optimistic"}[tail_mode],
+                            "forks_last_step": fork_stats,
+                            "leftover_fallback_taken": bool(leftover and args.forced_tail == 2),
+                            "note": "forks: depth at which queries whose beams can no longer be pruned leave the sequential "
+                                    "steps (forced = scored by one teacher-forced tail pass, left = walked on); depths chosen "
+                                    "from the trie statistics (rpr_trie_single_frac)"},
             "config": {"workload": f"{args.model} dims, {trie.N}-doc synthetic 32x256 docid trie, beams={B}, len={L}, "
                                    f"{Q} queries/step/GPU (MSMARCO-dev-shaped, mean {mean_len:.1f} tokens, padded to {lq_used})",
                        "queries_per_step_per_gpu": Q, "beams": B, "len": L, "docs": trie.N, "enc_len_padded": lq_used,

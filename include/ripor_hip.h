@@ -232,12 +232,19 @@ int32_t rpr_lane_split(rpr_ctx* ctx);
  * step replayed, sum/(L+1) finalize with ties in reverse slot order); a fork only takes a query whose beams are all
  * live, single-sequence and close enough in score that no masked (-1e9) candidate could be selected (bound on |logit|
  * from the output codebooks, computed at rpr_load_model). Calls with debug taps or RPR_FLAG_LOG_SOFTMAX never fork.
- *   rpr_set_forced_tail(ctx, 0/1)            switch (1 = default);
+ *   rpr_set_forced_tail(ctx, mode)           0 = off; 1 = exact (default): whoever is still unforced after the last fork
+ *                                            walks on to L on the device; 2 = optimistic: when the trie statistics promise
+ *                                            an (almost always) empty last stage, it is not enqueued at all (~100 launches
+ *                                            per remaining step for nobody) — a query left unforced by the last fork raises
+ *                                            the sticky RPR_STATUS_TAIL_LEFTOVER and the results of that call are NOT valid:
+ *                                            repeat it in mode 1 (ripor_amd/tasks/generation.py and bench.py do).
+ *   rpr_forced_tail(ctx)                     the mode in force;
  *   rpr_set_fork_depths(ctx, n, depths)      n = -1: depths from the trie statistics (default); n = 0..2: explicit,
  *                                            ascending, each in [1, L-1] (entries >= L are ignored at search time);
  *   rpr_fork_depths(...)                     the depths a search of this shape would use -> out_depths[2]; returns
  *                                            their number (>= 0) or a negative rpr_status. */
-int rpr_set_forced_tail(rpr_ctx* ctx, int32_t enable);
+int rpr_set_forced_tail(rpr_ctx* ctx, int32_t mode);
+int32_t rpr_forced_tail(const rpr_ctx* ctx);
 int rpr_set_fork_depths(rpr_ctx* ctx, int32_t n, const int32_t* depths);
 int rpr_fork_depths(rpr_ctx* ctx, rpr_model* model, rpr_trie* trie, int32_t Q, int32_t B, int32_t L, uint32_t flags,
                     int32_t* out_depths);
@@ -295,7 +302,10 @@ int rpr_lngknp_forward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids,
  * rpr_adamw_step: global L2 norm of flat_grads (-> out_grad_norm [dev, 1], nullable), clip coefficient
  *   min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no clipping), AdamW update of every tensor with the
  *   bias corrections of `step` (1-based), then the f16 weight planes of the search path are refreshed (synchronises
- *   the stream). exp_avg / exp_avg_sq: [dev, rpr_param_total], zero before the first step. */
+ *   the stream). weight_decay applies to every tensor except the two relative-attention-bias tables (HF 4.17
+ *   Trainer.create_optimizer excludes nn.LayerNorm parameters and names containing "bias"; T5LayerNorm is not an
+ *   nn.LayerNorm there, so layer-norm weights decay). The reference's default is weight_decay = 0.
+ *   exp_avg / exp_avg_sq: [dev, rpr_param_total], zero before the first step. */
 int64_t rpr_param_count(rpr_model* model);
 int64_t rpr_param_total(rpr_model* model);
 int rpr_param_info(rpr_model* model, int64_t index, const float** ptr, int64_t* numel, int64_t* offset);
@@ -318,7 +328,17 @@ int rpr_adamw_step(rpr_ctx* ctx, rpr_model* model, const float* flat_grads, floa
  * resets them. */
 #define RPR_STATUS_SATURATED 1u
 #define RPR_STATUS_EMPTY_QUERY 2u
+/* RPR_STATUS_TAIL_LEFTOVER: a search in the optimistic forced-tail mode (rpr_set_forced_tail(ctx, 2)) met a query that
+ *   was still unforced at its last fork; the outputs of that query are unspecified — repeat the call in mode 1. */
+#define RPR_STATUS_TAIL_LEFTOVER 4u
 int rpr_get_status(rpr_ctx* ctx, void* stream, uint32_t* out_flags, int clear);
+/* The same words WITHOUT a synchronisation: enqueues on `stream` a copy of the four raw status words ([0] != 0:
+ * SATURATED, [1] != 0: EMPTY_QUERY, [2] != 0: TAIL_LEFTOVER, [3] reserved) into host_words ([host], pinned, 16 bytes;
+ * NULL = no copy) and, if clear != 0, their reset behind it. A caller that records an event after this call reads the
+ * flags of exactly the work enqueued before it once the event has completed — the search loop of
+ * ripor_amd/evaluate.py checks batch n this way while batch n + 1 runs (the reference loop synchronises >= 2*B*Q times
+ * per step). */
+int rpr_status_words_async(rpr_ctx* ctx, void* stream, uint32_t* host_words, int clear);
 int rpr_model_f32_only(const rpr_model* model);
 
 /* ---- measurement ---- */

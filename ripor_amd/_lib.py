@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
  K_COUNT) = range(11)
 KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rmsnorm", "select", "other", "gemm_small",
                       "tail_self_attn", "fork"]
-STATUS_SATURATED, STATUS_EMPTY_QUERY = 1, 2
+STATUS_SATURATED, STATUS_EMPTY_QUERY, STATUS_TAIL_LEFTOVER = 1, 2, 4
 ABI_VERSION = 3
 
 PREC_F32, PREC_F16X2 = 0, 1
@@ -103,6 +103,7 @@ SIGNATURES = {
     "rpr_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rpr_get_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "rpr_status_words_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "rpr_model_f32_only": (C.c_int, [C.c_void_p]),
     "rpr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rpr_profile_reset": (C.c_int, [C.c_void_p]),
@@ -111,6 +112,7 @@ SIGNATURES = {
     "rpr_set_lane_split": (C.c_int, [C.c_void_p, C.c_int32]),
     "rpr_lane_split": (C.c_int32, [C.c_void_p]),
     "rpr_set_forced_tail": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rpr_forced_tail": (C.c_int32, [C.c_void_p]),
     "rpr_set_fork_depths": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "rpr_fork_depths": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                   C.POINTER(C.c_int32)]),

@@ -46,14 +46,16 @@ int rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
 }
 
 int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
-  RPR_HIP(hipMemsetAsync(c->status, 0, 4, s));
+  // the weight-range probe has its own device word (status[8]): the ctx's sticky flags (status[0..3]) may hold something
+  // nobody has read yet — searches on another model, a forward enqueued before the optimizer step
+  unsigned int* probe = c->status + 8;
+  RPR_HIP(hipMemsetAsync(probe, 0, 4, s));
   for (const auto& j : m->plane_jobs)
-    RPR_HIP(launch_split_planes(j.w, j.dst, j.n, j.n, s, W_PLANE_SCALE * j.pre, j.ln, m->d.d_model, c->status));
+    RPR_HIP(launch_split_planes(j.w, j.dst, j.n, j.n, s, W_PLANE_SCALE * j.pre, j.ln, m->d.d_model, probe));
   unsigned int sat = 0;
-  RPR_HIP(hipMemcpyAsync(&sat, c->status, 4, hipMemcpyDeviceToHost, s));
+  RPR_HIP(hipMemcpyAsync(&sat, probe, 4, hipMemcpyDeviceToHost, s));
   RPR_HIP(hipStreamSynchronize(s));
   m->f32_only = sat != 0;
-  if (sat) RPR_HIP(hipMemsetAsync(c->status, 0, 4, s));
   return RPR_OK;
 }
 
@@ -136,7 +138,9 @@ int flush_profile(rpr_ctx* c) {
 }
 
 // forks: depths at which forced queries leave the sequential steps (ascending, each in [1, L-1]; empty = plain search)
-int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L, const std::vector<int>& forks = {}) {
+// drop_last: no stage after the last fork (optimistic mode, see choose_forks): its caches are not needed
+int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L, const std::vector<int>& forks = {},
+                    bool drop_last = false) {
   const auto& d = m->d;
   const size_t T = (size_t)Q * Lq, R = (size_t)Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
   const size_t nd = d.num_decoder_layers, ne = d.num_layers, f = sizeof(float);
@@ -166,12 +170,14 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
   for (size_t k = 0; k < forks.size(); ++k) {
     const size_t depth = k + 1 < forks.size() ? (size_t)forks[k + 1] : (size_t)L, Lt = (size_t)(L - forks[k]);
     StageBufs& sb = w.stage[k];
-    E(sb.qmap, (size_t)Q * 4); E(sb.cnt, 16); E(sb.src, (size_t)Q * 4);
-    E(sb.offs, (size_t)Q * 4); E(sb.last, (size_t)Q * 4); E(sb.mask, T * 4);
-    E(sb.kcache, nd * depth * R * inner * f); E(sb.vcache, nd * depth * R * inner * f);
-    for (int i = 0; i < 2; ++i) {
-      E(sb.score[i], R * 8); E(sb.lo[i], R * 4); E(sb.hi[i], R * 4);
-      E(sb.tokens[i], R * (size_t)L * 2); E(sb.anc[i], R * (size_t)L * 2);
+    E(sb.cnt, 16); E(sb.src, (size_t)Q * 4);
+    if (!(drop_last && k + 1 == forks.size())) {
+      E(sb.qmap, (size_t)Q * 4); E(sb.offs, (size_t)Q * 4); E(sb.last, (size_t)Q * 4); E(sb.mask, T * 4);
+      E(sb.kcache, nd * depth * R * inner * f); E(sb.vcache, nd * depth * R * inner * f);
+      for (int i = 0; i < 2; ++i) {
+        E(sb.score[i], R * 8); E(sb.lo[i], R * 4); E(sb.hi[i], R * 4);
+        E(sb.tokens[i], R * (size_t)L * 2); E(sb.anc[i], R * (size_t)L * 2);
+      }
     }
     TailBufs& tb = w.tail[k];
     E(tb.flag, (size_t)Q * 4); E(tb.flist, (size_t)Q * 4); E(tb.cnt, 16);
@@ -413,8 +419,10 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
 
 // The fork after step T-1 of stage `sv`: which of its queries are forced (tail job `tb`), the others compacted into
 // the next stage (`nb` / returned view): beam state, the K/V of the T positions walked so far, the cross-attention inputs.
+// compact = false (optimistic mode, last fork): nobody walks on — a query that is not forced here only raises the ctx's
+// sticky RPR_STATUS_TAIL_LEFTOVER word and the caller repeats the batch in the exact mode.
 StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, const SearchDims& sd, const StageView& sv,
-                       int T, int next_depth, TailBufs& tb, StageBufs& nb) {
+                       int T, int next_depth, TailBufs& tb, StageBufs& nb, bool compact) {
   const auto& d = m->d;
   const int Q = sv.Qcap, B = sd.B, L = sd.L, Lq = sd.Lq, inner = m->inner(), nd = d.num_decoder_layers, H = d.num_heads;
   hipStream_t s = Ln.s;
@@ -439,6 +447,10 @@ StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_t
   });
   // next stage
   StageView nv{};
+  if (!compact) {
+    Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_flag_nonzero(P<int>(nb.cnt), c->status + 2, s); });
+    return nv;
+  }
   nv.Qcap = Q; nv.nq_dev = P<int>(nb.cnt); nv.nrows_dev = P<int>(nb.cnt) + 1;
   nv.io = StageIO{P<int32_t>(nb.qmap), P<int32_t>(nb.offs), P<int32_t>(nb.last), P<int32_t>(nb.mask)};
   nv.kcache = P<float>(nb.kcache); nv.vcache = P<float>(nb.vcache); nv.depth = next_depth;
@@ -507,7 +519,7 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
       DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(tb.mask), attn, Q, B * Lt, H, Lq, h2 ? attn_h : nullptr, ps_i,
                          P<int32_t>(tb.last), P<int32_t>(tb.offs), 0, c->status, nf_dev};
       Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ra * H * (double)Lq * DKV, 4.0 * ((double)Ra * inner * 2 + 2.0 * (Ra / (B * Lt)) * (double)Lq * inner),
-             [&] { return launch_dec_cross_attn(a, s); });
+             [&] { return launch_tail_cross_attn(a, s); });
     }
     linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), nrows_dev, Ra);
     if (!h2) norm(m->dec_ln2[i]);
@@ -527,7 +539,7 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
 
 // Everything between the staged inputs (ws.ids/ws.mask) and the staged outputs (ws.o_*).
 void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie* tr, int Q, int Lq, int B, int L,
-                    unsigned flags, const rpr_debug_taps* taps, const std::vector<int>& forks) {
+                    unsigned flags, const rpr_debug_taps* taps, const std::vector<int>& forks, bool drop_last) {
   const auto& d = m->d;
   Workspace& w = c->ws;
   const int T = Q * Lq, inner = m->inner(), dm = d.d_model;
@@ -581,8 +593,10 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
     enqueue_steps(Ln, c, m, tr, sd, sv, t0, t1, shared0, taps, sel_clk);
     if (k < forks.size()) {
       const int next_depth = k + 1 < forks.size() ? forks[k + 1] : L;
-      const StageView nv = enqueue_fork(Ln, c, m, tr, sd, sv, t1, next_depth, w.tail[k], w.stage[k]);
+      const bool last_dropped = drop_last && k + 1 == forks.size();
+      const StageView nv = enqueue_fork(Ln, c, m, tr, sd, sv, t1, next_depth, w.tail[k], w.stage[k], !last_dropped);
       enqueue_tail(Ln, c, m, sd, sv, t1, w.tail[k]);
+      if (last_dropped) return;   // every query was finished by a tail pass (or flagged)
       sv = nv;
     }
     t0 = t1;
@@ -710,7 +724,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   c->device = device;
   if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
   if (const char* e = getenv("RPR_LANE_MIN_ROWS")) c->lane_min_rows = atoi(e) > 0 ? atoi(e) : 0;
-  if (const char* e = getenv("RPR_FORCED_TAIL")) c->forced_tail = atoi(e) != 0;
+  if (const char* e = getenv("RPR_FORCED_TAIL")) c->forced_tail = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   if (const char* e = getenv("RPR_FORK_DEPTHS")) {   // "4,6": explicit fork depths; "" or "0": none
     c->n_fork_override = 0;
     for (const char* p = e; *p && c->n_fork_override < MAX_FORKS;) {
@@ -819,7 +833,8 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   {
     const size_t inner = (size_t)m->inner(), dm = d->d_model, dff = d->d_ff;
     int err = 0;
-    RPR_HIP(hipMemset(c->status, 0, 4));
+    unsigned int* probe = c->status + 8;   // weight-range probe word, apart from the sticky flags (refresh_weight_planes)
+    RPR_HIP(hipMemset(probe, 0, 4));
     // ln (nullable): layer-norm weight folded into the columns (length = the projection's input dim, always d_model);
     // pre = extra scalar on the weights (scaleup_output_hidden on the codebooks)
     auto mk = [&](const float* wf, size_t n, __half** outp, const float* ln = nullptr, float pre = 1.0f) {
@@ -829,7 +844,7 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
       if (e == hipSuccess) {
         m->owned.push_back(p);
         m->plane_jobs.push_back({wf, n, (__half*)p, ln, pre});
-        e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE * pre, ln, (int)dm, c->status);
+        e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE * pre, ln, (int)dm, probe);
       }
       if (e != hipSuccess) { err = hip_fail(e, "weight split", __FILE__, __LINE__); return; }
       *outp = (__half*)p;
@@ -852,8 +867,8 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
     // a weight (times its folded layer-norm weight, times 2^8) outside the f16 range cannot be carried by the planes:
     // the model is pinned to the exact-fp32 kernels instead of being clipped silently
     unsigned int sat = 0;
-    RPR_HIP(hipMemcpy(&sat, c->status, 4, hipMemcpyDeviceToHost));
-    if (sat) { m->f32_only = true; RPR_HIP(hipMemset(c->status, 0, 4)); }
+    RPR_HIP(hipMemcpy(&sat, probe, 4, hipMemcpyDeviceToHost));
+    if (sat) m->f32_only = true;
   }
   {  // |logit| <= sqrt(d_model) * max_row |E_out[r] * ln_final| * scaleup factor (forced-tail fork, see internal.h)
     DevTmp nb;
@@ -1113,8 +1128,10 @@ bool ensure_lanes(rpr_ctx* c) {
 // forced with probability ~ f_t^B. First fork: the first depth where that reaches one half; second fork: the first
 // depth after it where fewer than 0.05 queries of the call are expected to stay unforced, so that the last stage is
 // almost always empty (a stage with a handful of live rows still pays ~100 launches per step).
-std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int Q, int B, int L, unsigned flags, bool taps) {
+std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int Q, int B, int L, unsigned flags, bool taps,
+                              bool* drop_last) {
   std::vector<int> forks;
+  *drop_last = false;
   if (!c->forced_tail || taps || (flags & RPR_FLAG_LOG_SOFTMAX) || L < 3 || !std::isfinite(m->logit_bound)) return forks;
   if (1e8 - 2.0 * L * (double)m->logit_bound <= 1e7) return forks;   // logits too large for the masked-candidate proof
   if (c->n_fork_override >= 0) {
@@ -1123,6 +1140,7 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
       const int t = c->fork_override[i];
       if (t > prev && t <= L - 1) { forks.push_back(t); prev = t; }
     }
+    *drop_last = c->forced_tail == 2 && !forks.empty();
     return forks;
   }
   auto it = tr->single_frac.find(L);
@@ -1139,11 +1157,15 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   forks.push_back(t0);
   for (int t = t0 + 1; t <= L - 2 && t <= t0 + 12; ++t)
     if ((double)Q * (1.0 - p_forced(t)) <= 0.05) { forks.push_back(t); break; }
+  // Optimistic mode (rpr_set_forced_tail(ctx, 2)): when the statistics promise an (almost always) empty last stage, that
+  // stage is not enqueued at all — ~100 launches per step for nobody — and a query that is still unforced at the last
+  // fork raises RPR_STATUS_TAIL_LEFTOVER instead; the caller then repeats the batch in the exact mode (1).
+  *drop_last = c->forced_tail == 2 && forks.size() == 2;
   return forks;
 }
 
-int pack_forks(const std::vector<int>& forks) {
-  int v = 0;
+int pack_forks(const std::vector<int>& forks, bool drop_last) {
+  int v = drop_last ? (1 << 30) : 0;
   for (size_t i = 0; i < forks.size(); ++i) v |= forks[i] << (8 * i);
   return v;
 }
@@ -1160,8 +1182,9 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
   if (m->f32_only) c->precision = RPR_PREC_F32;
-  const std::vector<int> forks = choose_forks(c, m, tr, Q, B, L, flags, taps != nullptr);
-  int e = alloc_workspace(c, m, Q, Lq, B, L, forks);
+  bool drop_last = false;
+  const std::vector<int> forks = choose_forks(c, m, tr, Q, B, L, flags, taps != nullptr, &drop_last);
+  int e = alloc_workspace(c, m, Q, Lq, B, L, forks, drop_last);
   if (e) return e;
   c->last_forks = forks;
   c->last_ws_mask |= lane >= 0 ? (2 << lane) : 1;
@@ -1173,16 +1196,16 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   const bool eager = (flags & RPR_FLAG_NO_GRAPH) || taps || c->profiling;
   if (eager) {
     Launcher Ln{c, s};
-    enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps, forks);
+    enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps, forks, drop_last);
     if (Ln.err) return Ln.err;
   } else {
-    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane, pack_forks(forks)};
+    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane, pack_forks(forks, drop_last)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;
       RPR_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
       Launcher Ln{c, c->cap_stream};
-      enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, nullptr, forks);
+      enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, nullptr, forks, drop_last);
       hipError_t ce = hipStreamEndCapture(c->cap_stream, &graph);
       if (Ln.err) { if (graph) (void)hipGraphDestroy(graph); return Ln.err; }
       if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
@@ -1223,6 +1246,20 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   // query is processed on its own rows. The caller's stream waits for both lanes.
   if (c->lane_min_rows > 0 && (int64_t)Q * B >= c->lane_min_rows && Q >= 2 && !taps && ensure_lanes(c)) {
     const int32_t Qh[2] = {(Q + 1) / 2, Q / 2};
+    // both lane workspaces are sized BEFORE either half is enqueued: growing a buffer drops every cached graph of the
+    // ctx (ensure()), which must not happen while the other lane's graph is in flight — and an allocation failure then
+    // leaves nothing running
+    for (int i = 0; i < 2; ++i) {
+      std::swap(c->ws, c->lanes[i].ws);
+      const int saved_prec = c->precision;
+      if (m->f32_only) c->precision = RPR_PREC_F32;
+      bool drop_last = false;
+      const std::vector<int> forks = choose_forks(c, m, tr, Qh[i], B, L, flags, false, &drop_last);
+      const int e = alloc_workspace(c, m, Qh[i], Lq, B, L, forks, drop_last);
+      c->precision = saved_prec;
+      std::swap(c->ws, c->lanes[i].ws);
+      if (e) return e;
+    }
     RPR_HIP(hipEventRecord(c->fork_ev, s));
     int32_t q0 = 0;
     for (int i = 0; i < 2; ++i) {
@@ -1232,7 +1269,10 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
       int e = search_one(c, m, tr, input_ids + (size_t)q0 * Lq, attention_mask + (size_t)q0 * Lq, Qh[i], Lq, B, L, flags,
                          out_tokens + r0 * L, out_scores + r0, out_row_lo ? out_row_lo + r0 : nullptr,
                          out_row_hi ? out_row_hi + r0 : nullptr, nullptr, ln.stream, i);
-      if (e) return e;
+      if (e) {   // the other half may already be writing the caller's buffers: let it finish before reporting the error
+        for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(c->lanes[k].stream);
+        return e;
+      }
       RPR_HIP(hipEventRecord(ln.done, ln.stream));
       q0 += Qh[i];
     }
@@ -1254,11 +1294,12 @@ int32_t rpr_lane_split(rpr_ctx* c) {
   return ensure_lanes(c) ? c->lane_min_rows : 0;
 }
 
-int rpr_set_forced_tail(rpr_ctx* c, int32_t enable) {
-  RPR_REQUIRE(c, "NULL ctx");
-  c->forced_tail = enable != 0;
+int rpr_set_forced_tail(rpr_ctx* c, int32_t mode) {
+  RPR_REQUIRE(c && mode >= 0 && mode <= 2, "mode must be 0 (off), 1 (exact) or 2 (optimistic)");
+  c->forced_tail = mode;
   return RPR_OK;
 }
+int32_t rpr_forced_tail(const rpr_ctx* c) { return c ? c->forced_tail : -1; }
 
 int rpr_set_fork_depths(rpr_ctx* c, int32_t n, const int32_t* depths) {
   RPR_REQUIRE(c && n >= -1 && n <= MAX_FORKS && (n <= 0 || depths), "n out of range (-1 = automatic, 0..2 explicit depths)");
@@ -1273,7 +1314,8 @@ int rpr_set_fork_depths(rpr_ctx* c, int32_t n, const int32_t* depths) {
 int rpr_fork_depths(rpr_ctx* c, rpr_model* m, rpr_trie* tr, int32_t Q, int32_t B, int32_t L, uint32_t flags, int32_t* out_depths) {
   RPR_REQUIRE(c && m && tr && out_depths, "NULL argument");
   RPR_REQUIRE(Q >= 1 && B >= 1 && L >= 1 && L <= tr->L, "Q, B or L out of range");
-  const std::vector<int> f = choose_forks(c, m, tr, Q, B, L, flags, false);
+  bool drop_last = false;
+  const std::vector<int> f = choose_forks(c, m, tr, Q, B, L, flags, false, &drop_last);
   for (size_t i = 0; i < f.size(); ++i) out_depths[i] = f[i];
   return (int)f.size();
 }
@@ -1396,10 +1438,20 @@ int rpr_get_status(rpr_ctx* c, void* stream, uint32_t* out_flags, int clear) {
   RPR_REQUIRE(c && out_flags, "NULL argument");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  RPR_HIP(hipMemcpyAsync(c->status_host, c->status, 8, hipMemcpyDeviceToHost, s));
-  if (clear) RPR_HIP(hipMemsetAsync(c->status, 0, 8, s));
+  RPR_HIP(hipMemcpyAsync(c->status_host, c->status, 12, hipMemcpyDeviceToHost, s));
+  if (clear) RPR_HIP(hipMemsetAsync(c->status, 0, 12, s));
   RPR_HIP(hipStreamSynchronize(s));
-  *out_flags = (c->status_host[0] ? RPR_STATUS_SATURATED : 0u) | (c->status_host[1] ? RPR_STATUS_EMPTY_QUERY : 0u);
+  *out_flags = (c->status_host[0] ? RPR_STATUS_SATURATED : 0u) | (c->status_host[1] ? RPR_STATUS_EMPTY_QUERY : 0u) |
+               (c->status_host[2] ? RPR_STATUS_TAIL_LEFTOVER : 0u);
+  return RPR_OK;
+}
+
+int rpr_status_words_async(rpr_ctx* c, void* stream, uint32_t* host_words, int clear) {
+  RPR_REQUIRE(c, "NULL ctx");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (host_words) RPR_HIP(hipMemcpyAsync(host_words, c->status, 16, hipMemcpyDeviceToHost, s));
+  if (clear) RPR_HIP(hipMemsetAsync(c->status, 0, 16, s));
   return RPR_OK;
 }
 

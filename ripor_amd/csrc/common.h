@@ -334,6 +334,8 @@ struct TailSelfAttnArgs {
   int nseq_cap, B, H, T, L;
 };
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s);
+// cross-attention of the tail rows (a.B = rows per query): fp32-MFMA tiles for Lq <= 64, else the block kernel
+hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 // gold[row] = <final RMSNorm of the row's stream (x post), E_out[p][token p]>, exact fp32 (as launch_gold_scores)
 hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_embeds, const uint16_t* tokens, float* gold, int rows,
                             const int* rows_dev, int T, int L, int d, int V, float eps, float post, hipStream_t s,
@@ -348,6 +350,8 @@ struct TailRankArgs {
 };
 hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s);
 // max over the rows of |E[r] (*) w|_2 (w nullable): bound of the logits after the final RMSNorm (model load)
+// *flag = 1 if *cnt != 0 (sticky status word)
+hipError_t launch_flag_nonzero(const int* cnt, unsigned int* flag, hipStream_t s);
 hipError_t launch_max_row_norm(const float* E, const float* w, int rows, int d, float* out /*zeroed*/, hipStream_t s);
 hipError_t init_tail_kernel_attributes();
 

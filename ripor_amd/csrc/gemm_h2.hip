@@ -396,7 +396,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // the staggered groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's
 // last reads are retired before the other group starts overwriting it.
 template <bool FULL, bool TRACE = false>
-__global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n, int skew_ticks) {
   // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
   // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
   const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
@@ -405,31 +405,45 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
   __shared__ float rs_tile[BM];                      // fused RMSNorm: rsqrt(mean(x^2) + eps) of the tile's rows
 
+  // PERSISTENT: the grid is (at most) one block per CU and a block walks the tiles bid, bid + gridDim.x, ... — the
+  // stores of a tile's epilogue drain under the first K-tiles of the block's next tile instead of holding the CU until
+  // the block retires, and blocks started with different offsets (skew_ticks) stay out of phase for the whole launch:
+  // the HBM bursts of the epilogues of some CUs run under the power-bound K-loops of the others.
   int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
-    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
-    if (bid >= nt) return;
-  }
-  {
-    const int q = nt >> 3, r = nt & 7, x = bid & 7, k = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int bm = tm * BM, bn = tn * BN;
+  if (g.m_dev) nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;   // packed rows: only the tiles holding live rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  if (skew_ticks > 0 && (int)blockIdx.x < nt) {     // 100 MHz ticks; every other block of an XCD starts late
+    const int ph = (blockIdx.x >> 3) & 3;
+    if (ph) {
+      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(skew_ticks * ph);
+      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  // tile order: XCD x = block & 7 owns a contiguous chunk of the live tiles; its blocks walk the chunk side by side
+  // (blocks of XCD x: those with index = x mod 8, (gridDim.x - x + 7) / 8 of them — with one block per tile that is the
+  // chunk size and every block handles exactly one tile)
+  const int xq = nt >> 3, xr = nt & 7, xcd = blockIdx.x & 7, xk = blockIdx.x >> 3, xstep = ((int)gridDim.x - xcd + 7) >> 3;
+  const int chunk0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, chunk_n = xcd < xr ? xq + 1 : xq;
+  for (int ti = xk; ti < chunk_n; ti += xstep) {
+  const int bid = chunk0 + ti;
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
   if (g.row_ssq && tid < BM) {   // one dependent load + rsqrt per row, hidden behind the first K-tile's DMA; the epilogue
     const int m = bm + tid;      // (after the K-loop's barriers) reads the scales from LDS instead of global memory
     rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
   }
 
+  // (the lane index is laundered per tile: otherwise the compiler hoists the eight per-piece row / segment terms out of
+  // the tile loop and the 256-register kernel spills)
+  int lane_t = lane;
+  asm volatile("" : "+v"(lane_t));
   const __half* src[PER_WAVE];
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
-    const int lrow = 16 * (wave + NW * j) + (lane >> 2);
-    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const int lrow = 16 * (wave + NW * j) + (lane_t >> 2);
+    const int seg = (lane_t & 3) ^ ((lrow >> 2) & 3);
     const __half* base;
     int trow, limit;
     size_t ld;
@@ -568,7 +582,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 #undef PP_M_END
 #undef PP_STAMP
 
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
+  int lane_e = lane;   // laundered like lane_t: the epilogue's per-lane offsets must not live through the K-loop
+  asm volatile("" : "+v"(lane_e));
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
+  __syncthreads();   // the staging strips alias the operand buffers the next tile's LDS-DMA writes; rs_tile is rewritten
+  }
 }
 
 // ---- skinny variant: M <= 400 rows (one to a few dozen queries in flight) ---------------------------------------
@@ -726,13 +744,20 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
-  const dim3 gr(tiles_m * tiles_n), bl(512);
+  // persistent blocks: one per CU of the stream (a whole number per XCD), fewer when the launch has fewer tiles
+  static const int persist = [] { const char* e = getenv("RPR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int skew = [] { const char* e = getenv("RPR_GEMM_SKEW"); return e ? atoi(e) : 0; }();   // 100 MHz ticks per K = 768
+  const int cus = a.cus > 0 ? a.cus : 256, nt = tiles_m * tiles_n;
+  const int grid = (persist && nt > cus) ? cus : nt;
+  // skew only pays when a block walks several tiles (the late blocks idle for up to 3/4 of a tile time once per launch)
+  const int skew_ticks = (grid < nt && nt >= 4 * cus) ? (int)((long)skew * a.K / 768) : 0;
+  const dim3 gr(grid), bl(512);
   if (full && a.trace)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
   else if (full)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n, skew_ticks);
   else
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n, skew_ticks);
   return hipGetLastError();
 }
 

@@ -8,6 +8,8 @@
 // with exact ties in reverse slot order and stores float32 (:532-540). For a forced query every beam has exactly one
 // valid child per step, so the B winners of a step are those B candidates (fork_classify_kernel proves that no masked
 // candidate can reach them) and only their ORDER has to be replayed: tail_rank_kernel.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernel_utils.h"
 
@@ -268,10 +270,257 @@ __global__ __launch_bounds__(256) void tail_self_attn_kernel(TailSelfAttnArgs a)
   }
 }
 
+// ---- fp32-MFMA attention tiles (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) ---------------------
+// One wave handles 32 query rows x up to 32*NKT keys of one head. Scores are computed TRANSPOSED, S^T = K Q^T, so that
+// in the MFMA result layout a lane owns ONE query row (n = lane & 31) and 16 of its keys per key tile
+// (m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = register): the softmax of a row is 16*NKT in-register values plus one
+// exchange with the partner lane (lane ^ 32) instead of 32-lane butterflies. The probabilities then feed the P.V
+// product as its A operand WITHOUT moving: an MFMA reduces over its k slots in any order, so slot (kk, half) is
+// declared to be key kappa(kk, half) = (kk & 3) + 8 (kk >> 2) + 4 half — exactly the key register kk already holds —
+// and the B operand reads V[kappa][d] from the wave's LDS strip. K and Q come straight from global memory: a lane
+// reads the eight 16-byte pieces {8c + 4 half .. +3} of its row, MFMA 4c + x consumes component x of piece c (the
+// same k-slot freedom). The VALU version of the tail self-attention spent 64 LDS reads + 64 FMAs per (row, key lane)
+// and ran at 4.3 ms per layer; this one is bound by the 64 fp32 MFMAs per 32-row tile.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int kappa(int kk, int half) { return (kk & 3) + 8 * (kk >> 2) + 4 * half; }
+
+// the eight 16-byte pieces of a 64-float row owned by this lane half; null pointer -> zeros
+__device__ __forceinline__ void load_row_pieces(const float* row, int half, float4 (&r)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    r[c] = row ? *reinterpret_cast<const float4*>(row + c * 8 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void mfma_scores(const float4 (&k)[8], const float4 (&q)[8], f32x16& s) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].x, q[c].x, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].y, q[c].y, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].z, q[c].z, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].w, q[c].w, s, 0, 0, 0);
+  }
+}
+
+// softmax of this lane's row over its 16*NKT keys and the partner lane's (scores of masked keys are -inf); returns
+// the normalised probabilities in place. A row without any valid key gets all zeros.
+template <int NKT>
+__device__ __forceinline__ void softmax_rows(f32x16 (&s)[NKT]) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = (s[kt][r] == -INFINITY) ? 0.f : expf(s[kt][r] - mx);
+      s[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+}
+
+// O[row][d] += sum_key P[row][key] V[key][d] for the two 32-column halves of the head; Vs = [32*NKT][64] in LDS
+template <int NKT>
+__device__ __forceinline__ void mfma_pv(const f32x16 (&p)[NKT], const float* Vs, int lane, f32x16 (&o)[2]) {
+  const int d = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float* vr = Vs + (kt * 32 + kappa(kk, half)) * 64 + d;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kt][kk], vr[0], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kt][kk], vr[32], o[1], 0, 0, 0);
+    }
+}
+
+// rows i0 + (r & 3) + 8 (r >> 2) + 4 half of the tile -> out / out_h at row_base + row, columns head*64 + {d, d + 32}
+__device__ __forceinline__ void store_o_tile(const f32x16 (&o)[2], int lane, int i0, int nrows, size_t row_base, int inner, int hcol,
+                                             float* out, __half* out_h, size_t o_ps, unsigned int* sat) {
+  const int d = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (i >= nrows) continue;
+    const size_t oidx = (row_base + i) * inner + hcol + d;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float v = o[t][r];
+      if (out_h) {
+        __half hi, lo;
+        split_f16(v * A_PLANE_SCALE, hi, lo, sat);
+        out_h[oidx + 32 * t] = hi;
+        out_h[o_ps + oidx + 32 * t] = lo;
+      } else {
+        out[oidx + 32 * t] = v;
+      }
+    }
+  }
+}
+
+// Tail self-attention on the fp32 matrix cores: one wave per (sequence, head), NKT = ceil(L / 32) key tiles.
+template <int NKT>
+__global__ __launch_bounds__(256) void tail_self_attn_mfma_kernel(TailSelfAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+  const int w = blockIdx.x * 4 + wave;
+  const int seq = w / H, h = w - seq * H;
+  if (seq >= *a.nseq_dev) return;                       // wave-uniform
+  float* Vs = smem + (size_t)wave * (NKT * 32 * 64 + 64);
+  float* Bs = Vs + NKT * 32 * 64;
+  const int fi = seq / a.B, b = seq - fi * a.B;
+  const int qi = a.flist[fi];
+  const uint16_t* ancr = a.anc + ((size_t)qi * a.B + b) * a.anc_ld;
+  const size_t cbase = (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
+  const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * DKV;
+  {  // V rows -> LDS, four coalesced 256-B rows per instruction; rows past L are zero (0 * garbage must stay 0)
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int it = 0; it < NKT * 8; ++it) {
+      const int j = it * 4 + g;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < L) {
+        const float* vr = j < T ? a.vcache + cbase + (size_t)j * a.pos_stride + (size_t)ancr[j] * a.slot_stride
+                                : tbase + (size_t)(j - T) * ld + 2 * inner;
+        v = *reinterpret_cast<const float4*>(vr + li * 4);
+      }
+      *reinterpret_cast<float4*>(Vs + j * 64 + li * 4) = v;
+    }
+  }
+  Bs[lane] = a.rel_bias[a.bucket[lane] * H + h];         // bias of distance n = query position - key position
+  float4 kreg[NKT][8];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int j = kt * 32 + (lane & 31);
+    const float* kr = nullptr;
+    if (j < L)
+      kr = j < T ? a.kcache + cbase + (size_t)j * a.pos_stride + (size_t)ancr[j] * a.slot_stride : tbase + (size_t)(j - T) * ld + inner;
+    load_row_pieces(kr, half, kreg[kt]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = 0; i0 < Lt; i0 += 32) {
+    const int i = i0 + (lane & 31);                      // this lane's query row (position T + i)
+    float4 qreg[8];
+    load_row_pieces(i < Lt ? tbase + (size_t)i * ld : nullptr, half, qreg);
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      mfma_scores(kreg[kt], qreg, s[kt]);
+    }
+    const int pq = T + (i < Lt ? i : Lt - 1);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kt * 32 + kappa(r, half);
+        s[kt][r] = j <= pq ? s[kt][r] + Bs[pq - j] : -INFINITY;
+      }
+    softmax_rows<NKT>(s);
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    mfma_pv<NKT>(s, Vs, lane, o);
+    store_o_tile(o, lane, i0, Lt, (size_t)seq * Lt, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
+  }
+}
+
+// Cross-attention of the tail rows on the fp32 matrix cores: one wave per (query, head, tile of 32 of the query's
+// rows); keys = the query's own encoder rows (<= 32 * NKT, padding keys masked), no position bias.
+template <int NKT>
+__global__ __launch_bounds__(256) void tail_cross_attn_mfma_kernel(DecCrossAttnArgs a, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, inner = H * DKV, nrows = a.B;       // a.B = rows of one query (beams x tail positions)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+  const int w = blockIdx.x * 4 + wave;
+  const int tile = w % tiles, qh = w / tiles, h = qh % H, qi = qh / H;
+  if (qi >= a.Q || (a.nq_dev && qi >= *a.nq_dev)) return;   // wave-uniform
+  float* Vs = smem + (size_t)wave * (NKT * 32 * 64);
+  const int nk = min(a.last[qi], NKT * 32);
+  const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
+  const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;
+  const float* kb = a.xk + xrow0 * a.xld + h * DKV;
+  const float* vb = a.xv + xrow0 * a.xld + h * DKV;
+  {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int it = 0; it < NKT * 8; ++it) {
+      const int j = it * 4 + g;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nk && mrow[j] != 0) v = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + li * 4);
+      *reinterpret_cast<float4*>(Vs + j * 64 + li * 4) = v;
+    }
+  }
+  float4 kreg[NKT][8];
+  bool kok[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int j = kt * 32 + (lane & 31);
+    kok[kt] = j < nk && mrow[j] != 0;
+    load_row_pieces(kok[kt] ? kb + (size_t)j * a.xld : nullptr, half, kreg[kt]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int i0 = tile * 32, i = i0 + (lane & 31);
+  const size_t row_base = (size_t)qi * nrows;
+  float4 qreg[8];
+  load_row_pieces(i < nrows ? a.q + (row_base + i) * inner + h * DKV : nullptr, half, qreg);
+  f32x16 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    mfma_scores(kreg[kt], qreg, s[kt]);
+  }
+  // validity of key kappa(r, half) of tile kt: held by the lane whose (lane & 31) is that key — one ballot per tile
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const unsigned long long okm = __ballot(kok[kt]) & 0xffffffffull;   // bit j: key kt*32 + j is attended
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (!((okm >> kappa(r, half)) & 1ull)) s[kt][r] = -INFINITY;
+  }
+  softmax_rows<NKT>(s);
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  mfma_pv<NKT>(s, Vs, lane, o);
+  store_o_tile(o, lane, i0, nrows, row_base, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
+}
+
+hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
+  static const bool off = [] { const char* e = getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  if (off || a.Lq > 64) return launch_dec_cross_attn(a, s);   // long queries: the block kernel (any Lq <= 256)
+  const int tiles = (a.B + 31) / 32;
+  const long waves = (long)a.Q * a.H * tiles;
+  const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  if (a.Lq <= 32) hipLaunchKernelGGL(tail_cross_attn_mfma_kernel<1>, grid, blk, 4 * 32 * 64 * sizeof(float), s, a, tiles);
+  else hipLaunchKernelGGL(tail_cross_attn_mfma_kernel<2>, grid, blk, 4 * 64 * 64 * sizeof(float), s, a, tiles);
+  return hipGetLastError();
+}
+
 static size_t tail_self_attn_smem(int L) { return ((size_t)L * 65 + (size_t)L * 64 + 4 * 64 + 64) * sizeof(float); }
 
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
   if (a.L > MAX_DEC_LEN || a.T < 1 || a.T >= a.L) return hipErrorInvalidValue;
+  static const bool off = [] { const char* e = getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  if (!off) {
+    const long waves = (long)a.nseq_cap * a.H;
+    const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    if (a.L <= 32) hipLaunchKernelGGL(tail_self_attn_mfma_kernel<1>, grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
+    else hipLaunchKernelGGL(tail_self_attn_mfma_kernel<2>, grid, blk, 4 * (64 * 64 + 64) * sizeof(float), s, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(tail_self_attn_kernel, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L), s, a);
   return hipGetLastError();
 }
@@ -382,6 +631,15 @@ hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void flag_nonzero_kernel(const int* __restrict__ cnt, unsigned int* __restrict__ flag) {
+  if (threadIdx.x == 0 && *cnt != 0) *flag = 1u;
+}
+
+hipError_t launch_flag_nonzero(const int* cnt, unsigned int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(flag_nonzero_kernel, dim3(1), dim3(64), 0, s, cnt, flag);
+  return hipGetLastError();
+}
+
 // max over rows of || E[r] (*) w ||_2, as the bit pattern of a non-negative float through atomicMax (out zeroed)
 __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, const float* __restrict__ w, int rows, int d,
                                                             float* __restrict__ out) {
@@ -409,6 +667,10 @@ hipError_t launch_max_row_norm(const float* E, const float* w, int rows, int d, 
 hipError_t init_tail_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_cross_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(tail_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }

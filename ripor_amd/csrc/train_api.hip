@@ -497,9 +497,16 @@ int rpr_adamw_step(rpr_ctx* c, rpr_model* m, const float* flat_grads, float* exp
   RPR_HIP(launch_grad_norm(flat_grads, m->params_total, P<double>(w.gn_part), 1024, max_grad_norm, P<float>(w.gn_out), s));
   const float bc1 = 1.0f - (float)pow((double)beta1, (double)step);
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  for (const auto& p : m->params)
+  // Weight decay follows HF 4.17's Trainer.create_optimizer (what the reference trains with, tasks/trainer.py:477):
+  // every parameter decays except those of nn.LayerNorm modules and those whose name contains "bias". T5LayerNorm is
+  // not an nn.LayerNorm in that version, so the T5 layer-norm weights DO decay; `relative_attention_bias.weight` is
+  // excluded by its name. (Restated from memory of transformers 4.17 — its source is not available offline; the
+  // reference's default weight_decay is 0, where the rule is moot.)
+  for (const auto& p : m->params) {
+    const float wd = (p.kind == K_ENC_REL || p.kind == K_DEC_REL) ? 0.0f : weight_decay;
     RPR_HIP(launch_adamw(p.ptr, flat_grads + p.offset, exp_avg + p.offset, exp_avg_sq + p.offset, p.numel, P<float>(w.gn_out), lr, beta1,
-                         beta2, eps, weight_decay, bc1, bc2s, s));
+                         beta2, eps, wd, bc1, bc2s, s));
+  }
   if (out_grad_norm) RPR_HIP(hipMemcpyAsync(out_grad_norm, w.gn_out.p, 4, hipMemcpyDeviceToDevice, s));
   // the search / forward paths read the f16 planes of the weights: refresh them (synchronises the stream)
   return refresh_weight_planes(c, m, s);

@@ -67,10 +67,16 @@ class Context:
         """The threshold in force; 0 when splitting is off or masked streams are unavailable."""
         return int(self.lib.rpr_lane_split(self.handle))
 
-    def set_forced_tail(self, on: bool):
-        """Forced-tail evaluation (``rpr_set_forced_tail``; default on): queries whose beams can no longer be pruned
-        leave the step-by-step loop at a fork and get their remaining positions scored in one teacher-forced pass."""
-        check(self.lib.rpr_set_forced_tail(self.handle, 1 if on else 0), "rpr_set_forced_tail")
+    def set_forced_tail(self, mode):
+        """Forced-tail evaluation (``rpr_set_forced_tail``): queries whose beams can no longer be pruned leave the
+        step-by-step loop at a fork and get their remaining positions scored in one teacher-forced pass.
+        ``False``/0 = off, ``True``/1 = exact (library default), 2 = optimistic: no stage after the last fork; a query
+        left unforced there raises ``STATUS_TAIL_LEFTOVER`` and the call must be repeated in mode 1 (see
+        :func:`search_checked`)."""
+        check(self.lib.rpr_set_forced_tail(self.handle, int(mode)), "rpr_set_forced_tail")
+
+    def forced_tail(self) -> int:
+        return int(self.lib.rpr_forced_tail(self.handle))
 
     def set_fork_depths(self, depths: Optional[Sequence[int]]):
         """Explicit fork depths (ascending, at most two; ``[]`` = never fork); ``None`` = choose from the trie statistics."""
@@ -96,6 +102,19 @@ class Context:
         if n < 0:
             check(n, "rpr_last_fork_stats")
         return [dict(depth=int(d[i]), forced=int(f[i]), left=int(l[i])) for i in range(n)]
+
+    def status_async(self, clear: bool = True):
+        """Flags of the work enqueued so far WITHOUT synchronising (``rpr_status_words_async``): returns a
+        :class:`StatusTicket` whose ``flags()`` waits only for the copy enqueued here."""
+        words = torch.zeros(4, dtype=torch.int32).pin_memory()
+        check(self.lib.rpr_status_words_async(self.handle, _stream_ptr(self.device), words.data_ptr(), 1 if clear else 0),
+              "rpr_status_words_async")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return StatusTicket(words, ev)
+
+    def clear_status_async(self):
+        check(self.lib.rpr_status_words_async(self.handle, _stream_ptr(self.device), None, 1), "rpr_status_words_async")
 
     def status(self, clear: bool = True) -> int:
         """Synchronises the current stream and returns the sticky status flags of the work enqueued so far
@@ -138,6 +157,19 @@ class Context:
         check(self.lib.rpr_op_rmsnorm(self.handle, x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
                                       eps, _stream_ptr(x.device)), "rpr_op_rmsnorm")
         return out
+
+
+class StatusTicket:
+    """Status words of a ctx as of one point of a stream (``Context.status_async``)."""
+
+    def __init__(self, words: torch.Tensor, event):
+        self._words, self._event = words, event
+
+    def flags(self) -> int:
+        self._event.synchronize()
+        w = self._words
+        return ((_lib.STATUS_SATURATED if int(w[0]) else 0) | (_lib.STATUS_EMPTY_QUERY if int(w[1]) else 0) |
+                (_lib.STATUS_TAIL_LEFTOVER if int(w[2]) else 0))
 
 
 def rel_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:
@@ -470,6 +502,75 @@ def search(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attent
                              C.byref(tap_struct) if tap_struct is not None else None, _stream_ptr(dev)), "rpr_search")
     # ids/mask must stay alive until the async D2D staging copies have been enqueued (they have).
     return SearchResult(tokens, scores, lo, hi, tap_out)
+
+
+class GuardedSearch:
+    """A search whose device-side guards are checked LATER (no host synchronisation when it is issued).
+
+    ``result()`` waits for the status words copied right behind the search and, if a guard fired, repeats the batch
+    synchronously with the safe settings before returning: ``STATUS_TAIL_LEFTOVER`` (optimistic forced-tail mode: a
+    query was still unforced at the last fork) -> exact forced-tail mode; ``STATUS_SATURATED`` (an activation left the
+    f16 plane range of the split-precision GEMMs) -> exact fp32 MFMA. ``STATUS_EMPTY_QUERY`` raises ``ValueError``.
+    ``repeated`` tells whether the returned result is a second run (its tensors are then new ones)."""
+
+    def __init__(self, model, trie, ids, mask, B, L, log_softmax, res, ticket):
+        self._args = (model, trie, ids, mask, B, L, log_softmax)
+        self._res, self._ticket = res, ticket
+        self.repeated = False
+        self._done = False
+
+    def result(self) -> SearchResult:
+        if self._done:
+            return self._res
+        self._done = True
+        st = self._ticket.flags()
+        if st & _lib.STATUS_EMPTY_QUERY:
+            raise ValueError("a query has an all-zero attention_mask (no token to attend to)")
+        if st & (_lib.STATUS_SATURATED | _lib.STATUS_TAIL_LEFTOVER):
+            model, trie, ids, mask, B, L, log_softmax = self._args
+            ctx = model.ctx
+            saved_mode, saved_prec = ctx.forced_tail(), ctx.get_precision()
+            if (st & _lib.STATUS_SATURATED) and saved_prec != "f32":
+                import warnings
+                warnings.warn("activation outside the f16 plane range of the split-precision GEMMs: repeating this batch "
+                              "with exact fp32 MFMA (RPR_PRECISION=f32 avoids the retry)")
+                ctx.set_precision("f32")
+            if saved_mode == 2:
+                ctx.set_forced_tail(1)
+            try:
+                ctx.status(clear=True)
+                self._res = search(model, trie, ids, mask, B, L, apply_log_softmax_for_scores=log_softmax)
+                ctx.status(clear=True)
+            finally:
+                ctx.set_precision(saved_prec)
+                ctx.set_forced_tail(saved_mode)
+            self.repeated = True
+        return self._res
+
+
+def search_guarded(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                   num_beams: int, max_new_tokens: int, apply_log_softmax_for_scores: bool = False,
+                   optimistic: Optional[bool] = None) -> GuardedSearch:
+    """``search`` plus the status guards, checked when ``result()`` is called (see :class:`GuardedSearch`). With
+    ``optimistic`` (default: on unless ``RPR_OPTIMISTIC_TAIL=0``) a ctx in the exact forced-tail mode runs this call in
+    the optimistic mode — the last, almost always empty, step-by-step stage is not enqueued — and the guard repeats the
+    batch exactly in the rare case a query needed it."""
+    import os
+    ctx = model.ctx
+    if optimistic is None:
+        optimistic = os.environ.get("RPR_OPTIMISTIC_TAIL", "1") != "0"
+    mode = ctx.forced_tail()
+    ctx.clear_status_async()
+    if optimistic and mode == 1:
+        ctx.set_forced_tail(2)
+    try:
+        res = search(model, trie, input_ids, attention_mask, num_beams, max_new_tokens,
+                     apply_log_softmax_for_scores=apply_log_softmax_for_scores)
+    finally:
+        ctx.set_forced_tail(mode)
+    ticket = ctx.status_async(clear=True)
+    return GuardedSearch(model, trie, input_ids, attention_mask, int(num_beams), int(max_new_tokens),
+                         bool(apply_log_softmax_for_scores), res, ticket)
 
 
 def lngknp_forward(model: DeviceModel, input_ids: torch.Tensor, attention_mask: torch.Tensor, doc_codes: torch.Tensor,

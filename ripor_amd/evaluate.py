@@ -105,8 +105,12 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
     pending = None   # (qids, event, host tensors) of the previous batch: decoded while the GPU runs the current one
 
     def finish(p):
-        qids, done, (sc, lo, hi) = p
+        qids, done, (sc, lo, hi), guard = p
         done.synchronize()
+        if guard is not None:
+            r = guard.result()               # waits for this batch's status words only; repeats the batch if a guard fired
+            if guard.repeated:
+                sc, lo, hi = r.scores[:, :topk].cpu(), r.row_lo[:, :topk].cpu(), r.row_hi[:, :topk].cpu()
         perm = prefix_constrain_processor.trie(device).perm
         rankdata_from_ranges(qids, lo.tolist(), hi.tolist(), sc.tolist(), perm, smtid_to_docids.docids, max_new_token,
                              apply_log_softmax_for_scores, into=qid_to_rankdata)
@@ -118,7 +122,8 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                 model, prefix_constrain_processor, input_ids=inputs["input_ids"].long(),
                 attention_mask=inputs["attention_mask"].long(), max_new_tokens=max_new_token, output_scores=True,
                 return_dict=True, return_dict_in_generate=True, num_beams=topk, num_return_sequences=topk,
-                apply_log_softmax_for_scores=apply_log_softmax_for_scores)
+                apply_log_softmax_for_scores=apply_log_softmax_for_scores,
+                defer_status=copier is not None)   # the side-stream path checks the guards in finish(), one batch later
         batch_qids = batch["id"].cpu().tolist()
         if gather:
             kept.append((batch["id"].to(outputs.row_lo.device), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk),
@@ -128,7 +133,7 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
             # the search is asynchronous: its results travel to pinned host memory on a side stream, and the previous
             # batch is turned into {docid: score} dicts while this one runs (the reference synchronises Q*B times a step)
             res = (outputs.sequences_scores.view(-1, topk), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk))
-            nxt = (batch_qids,) + (copier.to_host(*res) if copier else (_Done(), tuple(t.cpu() for t in res)))
+            nxt = (batch_qids,) + (copier.to_host(*res) if copier else (_Done(), tuple(t.cpu() for t in res))) + (getattr(outputs, "guard", None),)
             if pending is not None:
                 finish(pending)
             pending = nxt

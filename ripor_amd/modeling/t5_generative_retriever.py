@@ -266,9 +266,26 @@ class T5SeqAQEncoderForLngKnpMarginMSE(T5SeqAQEncoder):
         tp = torch.stack([inputs[p + "teacher_pos_scores"] for _, p in self._PREFIXES[L]]).float()
         tn = torch.stack([inputs[p + "teacher_neg_scores"] for _, p in self._PREFIXES[L]]).float()
         codes = torch.stack([pos_codes, neg_codes], dim=1)
-        losses, self.last_position_scores = E.lngknp_forward(
-            self.base_model.engine_model(), pos_q["input_ids"], pos_q["attention_mask"], codes, tp, tn,
-            [k for k, _ in self._PREFIXES[L]])
+        em = self.base_model.engine_model()
+        ctx = em.ctx
+        ctx.clear_status_async()
+        args = (em, pos_q["input_ids"], pos_q["attention_mask"], codes, tp, tn, [k for k, _ in self._PREFIXES[L]])
+        losses, self.last_position_scores = E.lngknp_forward(*args)
+        # same guard as the search path (tasks/generation.py): this forward runs on the static-scale f16 planes; an
+        # activation outside their range is clamped and flagged, and the pass is then repeated on the exact-fp32 GEMMs
+        st = ctx.status(clear=True)
+        if st & E._lib.STATUS_EMPTY_QUERY:
+            raise ValueError("a query has an all-zero attention_mask (no token to attend to)")
+        if (st & E._lib.STATUS_SATURATED) and ctx.get_precision() != "f32":
+            import warnings
+            warnings.warn("activation outside the f16 plane range of the split-precision GEMMs: repeating this forward "
+                          "with exact fp32 MFMA (RPR_PRECISION=f32 avoids the retry)")
+            ctx.set_precision("f32")
+            try:
+                losses, self.last_position_scores = E.lngknp_forward(*args)
+                ctx.status(clear=True)
+            finally:
+                ctx.set_precision("f16x2")
         return {n: losses[i] for i, n in enumerate(names)}
 
     __call__ = forward

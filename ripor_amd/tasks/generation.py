@@ -37,6 +37,8 @@ class BeamSearchEncoderDecoderOutput:
     # extras of this implementation: sorted-row range of every returned smtid (docids = perm[lo:hi])
     row_lo: Optional[torch.Tensor] = None
     row_hi: Optional[torch.Tensor] = None
+    # with defer_status=True: the E.GuardedSearch whose result() must be consulted before the tensors above are trusted
+    guard: Optional[object] = None
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -174,27 +176,16 @@ def generate_for_constrained_prefix_beam_search(
 
     em = model.engine_model()
     trie = valid_smtids.trie(model.device)
-    ctx = em.ctx
-    ctx.status(clear=True)
-    res = E.search(em, trie, input_ids, attention_mask, num_beams, L,
-                   apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
-    # Saturation guard (the reference call is synchronous too: it syncs >= 2*B*Q times per step). The split-precision
-    # GEMMs carry activations in f16 planes; a value outside their range is clamped and flagged on the device, and the
-    # call is then repeated on the exact-fp32 MFMA path instead of returning rankings computed from clipped tensors.
-    st = ctx.status(clear=True)
-    if st & E._lib.STATUS_EMPTY_QUERY:
-        raise ValueError("a query has an all-zero attention_mask (no token to attend to)")
-    if (st & E._lib.STATUS_SATURATED) and ctx.get_precision() != "f32":
-        import warnings
-        warnings.warn("activation outside the f16 plane range of the split-precision GEMMs: repeating this batch with "
-                      "exact fp32 MFMA (RPR_PRECISION=f32 avoids the retry)")
-        ctx.set_precision("f32")
-        try:
-            res = E.search(em, trie, input_ids, attention_mask, num_beams, L,
-                           apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
-            ctx.status(clear=True)
-        finally:
-            ctx.set_precision("f16x2")
+    # Guards (E.GuardedSearch): the split-precision GEMMs carry activations in f16 planes — a value outside their range is
+    # clamped and flagged on the device and the batch is then repeated on the exact-fp32 MFMA path instead of returning
+    # rankings computed from clipped tensors; the forced-tail search runs in its optimistic mode and is repeated exactly
+    # when a query was left unforced at the last fork. The reference call is synchronous (>= 2*B*Q syncs per step) and so
+    # is this one by default; with defer_status=True the check happens when the caller asks for `outputs.guard.result()`
+    # (ripor_amd/evaluate.py: while the next batch runs).
+    guard = E.search_guarded(em, trie, input_ids, attention_mask, num_beams, L,
+                             apply_log_softmax_for_scores=bool(apply_log_softmax_for_scores))
+    defer = bool(model_kwargs.pop("defer_status", False)) and bool(return_dict_in_generate)
+    res = guard._res if defer else guard.result()
     Q, B, K = input_ids.shape[0], num_beams, num_return_sequences
     tok = res.tokens[:, :K, :].to(torch.long)
     seqs = torch.cat([torch.zeros((Q, K, 1), dtype=torch.long, device=tok.device), tok], dim=2).reshape(Q * K, L + 1)
@@ -203,4 +194,4 @@ def generate_for_constrained_prefix_beam_search(
     return BeamSearchEncoderDecoderOutput(
         sequences=seqs,
         sequences_scores=res.scores[:, :K].reshape(Q * K) if output_scores else None,
-        row_lo=res.row_lo[:, :K].reshape(Q * K), row_hi=res.row_hi[:, :K].reshape(Q * K))
+        row_lo=res.row_lo[:, :K].reshape(Q * K), row_hi=res.row_hi[:, :K].reshape(Q * K), guard=guard if defer else None)

@@ -194,3 +194,46 @@ def test_log_softmax_and_taps_never_fork(E):
     torch.cuda.synchronize()
     assert len(ctx.last_fork_stats()) >= 1
     assert torch.equal(b.tokens, c.tokens)
+
+
+def test_optimistic_mode_flags_leftovers_and_the_guard_repeats(E):
+    """Mode 2 does not enqueue the stage after the last fork; a query that is still unforced there raises
+    STATUS_TAIL_LEFTOVER (its outputs are unspecified) and E.search_guarded repeats the batch in the exact mode."""
+    from ripor_amd.utils import synth
+    L, V, B = 8, 256, 10
+    codes = synth.make_codes(60_000, L, V, seed=11)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=48)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ctx.set_forced_tail(False)
+    plain = E.search(model, trie, ti, tm, B, L)
+    torch.cuda.synchronize()
+    try:
+        # forks [1, 2]: at depth 2 many queries of this trie are not forced yet -> leftovers
+        ctx.set_fork_depths([1, 2])
+        ctx.set_forced_tail(2)
+        ctx.status(clear=True)
+        E.search(model, trie, ti, tm, B, L)
+        torch.cuda.synchronize()
+        st = ctx.last_fork_stats()
+        assert st[-1]["left"] > 0, st
+        assert ctx.status(clear=True) & E._lib.STATUS_TAIL_LEFTOVER
+        # the guard: optimistic first, exact repeat
+        ctx.set_forced_tail(1)
+        g = E.search_guarded(model, trie, ti, tm, B, L, optimistic=True)
+        r = g.result()
+        assert g.repeated and ctx.forced_tail() == 1
+        same = (r.tokens == plain.tokens).all(dim=2) | ((r.scores - plain.scores).abs() <= ORDER_TOL)
+        assert bool(same.all()) and float((r.scores - plain.scores).abs().max()) <= 0.3 * SCORE_TOL
+        # automatic depths: the statistics promise an empty last stage -> no flag, no repeat, same results
+        ctx.set_fork_depths(None)
+        g = E.search_guarded(model, trie, ti, tm, B, L, optimistic=True)
+        r = g.result()
+        st = ctx.last_fork_stats()
+        if len(st) == 2 and st[-1]["left"] == 0:
+            assert not g.repeated
+        same = (r.tokens == plain.tokens).all(dim=2) | ((r.scores - plain.scores).abs() <= ORDER_TOL)
+        assert bool(same.all())
+        assert ctx.status(clear=True) == 0
+    finally:
+        ctx.set_fork_depths(None)
+        ctx.set_forced_tail(True)
