@@ -112,6 +112,169 @@ def cpu_baseline(sd, dims, B, L, n_queries=16, trie_docs=10_000):
                       f"value_batch1 = the same loop at the reference script's batch size 1 ({dt1:.2f}s per query)"}
 
 
+
+# --------------------------------------------------------------------------------------------------------------------
+# Secondary legs (outside the timed region, a few seconds each): the other BASELINE configurations and SURVEY §8 "next"
+# rows, so that the driver's bench record carries a number for each of them. Same library, same C ABI.
+
+def _time_search(E, model, trie, batches, B, L, steps, warmup=1):
+    for i in range(warmup):
+        E.search(model, trie, batches[i % len(batches)][0], batches[i % len(batches)][1], B, L)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r = E.search(model, trie, batches[(warmup + i) % len(batches)][0], batches[(warmup + i) % len(batches)][1], B, L)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, r
+
+
+def _query_batches(synth, dims, Q, n, dev, seed):
+    ids, mask = synth.make_queries(Q * n, vocab_size=dims.vocab_size, seed=seed)
+    lq = (int(mask.sum(1).max()) + 7) // 8 * 8
+    ids = np.pad(ids, ((0, 0), (0, max(0, lq - ids.shape[1]))))[:, :lq]
+    mask = np.pad(mask, ((0, 0), (0, max(0, lq - mask.shape[1]))))[:, :lq]
+    return [(torch.from_numpy(ids[i * Q:(i + 1) * Q]).to(dev, torch.int32), torch.from_numpy(mask[i * Q:(i + 1) * Q]).to(dev, torch.int32))
+            for i in range(n)]
+
+
+def _leftover_guard(ctx, fn):
+    """Run fn() in the ctx's forced-tail mode; if the optimistic mode left a query unforced, repeat in the exact mode."""
+    ctx.status(clear=True)
+    out = fn()
+    if ctx.status(clear=True) & 4:
+        mode = ctx.forced_tail()
+        ctx.set_forced_tail(1)
+        try:
+            out = fn()
+        finally:
+            ctx.set_forced_tail(mode)
+        out = (out, True)
+    else:
+        out = (out, False)
+    return out
+
+
+def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=2):
+    """BASELINE config 4: t5-large dims, the same 8.8M-doc trie, beam 100, len 32."""
+    dims = synth.t5_large_dims(L=L)
+    t0 = time.time()
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+    t_w = time.time() - t0
+    batches = _query_batches(synth, dims, queries, 2, dev, seed=404)
+    (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, 100, L, steps))
+    ok = int((r.row_hi > r.row_lo).sum().item())
+    out = {"workload": f"t5-large dims (d 1024, d_ff 4096, 24+24 layers), {trie.N}-doc trie, beams=100, len={L}, {queries} queries/step",
+           "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps, "queries_per_step": queries,
+           "dtype": "f32 via f16x2-split MFMA (fp32 accumulate)", "valid_leaves": f"{ok}/{queries * 100}",
+           "forks_last_step": ctx.last_fork_stats(), "leftover_fallback_taken": fb, "weights_s": round(t_w, 1)}
+    del model
+    return out
+
+
+def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=3):
+    """the training-data generation callers (evaluate.py:134-178; full_evaluate_t5seq_aq_encoder.sh:117-147):
+    the same search at max_new_token 4 / 8 / 16 with topk = 100."""
+    out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams=100, {queries} queries/step, prefix search", "unit": "queries/s"}
+    batches = _query_batches(synth, dims, queries, 2, dev, seed=202)
+    for Lp in (4, 8, 16):
+        (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, 100, Lp, steps))
+        out[f"len{Lp}"] = {"value": queries / dt, "ms_per_step": dt * 1e3, "forks_last_step": ctx.last_fork_stats(),
+                           "leftover_fallback_taken": fb}
+    return out
+
+
+def secondary_skew(E, synth, ctx, model, dims, dev, docs, B, L, V, queries, steps=2):
+    """The clustered trie of SURVEY §8(d): residual-quantiser codes are imbalanced (aq_preprocess/
+    create_customized_smtid_file.py:33-59) — squared-uniform tokens on the first three levels plus 10 % of the docs
+    sharing their smtid with another doc. Beams stay on wide ranges longer, forks come later."""
+    t0 = time.time()
+    codes = synth.make_codes_fast(docs, L, V, seed=synth.SEED + 1)
+    lv = min(3, L)
+    u = (synth.hash_u64(f"bench_skew/{docs}", docs * lv, synth.SEED).reshape(docs, lv) >> np.uint64(44)).astype(np.float64) / float(1 << 20)
+    codes[:, :lv] = np.minimum((u * u * V).astype(np.int64), V - 1).astype(codes.dtype)
+    ndup = docs // 10
+    src = (synth.hash_u64(f"bench_dup/{docs}", ndup, synth.SEED) % np.uint64(docs)).astype(np.int64)
+    codes[docs - ndup:] = codes[src]
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    frac = E.trie_single_frac(codes[:: max(1, docs // 2_000_000)], L) if docs > 4_000_000 else E.trie_single_frac(codes, L)
+    del codes
+    t_trie = time.time() - t0
+    batches = _query_batches(synth, dims, queries, 2, dev, seed=303)
+    (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, B, L, steps))
+    forks = ctx.last_fork_stats()
+    ctx.profile_reset(); ctx.profile_enable(True)
+    E.search(model, trie, batches[0][0], batches[0][1], B, L)
+    torch.cuda.synchronize()
+    st = ctx.profile_get(); ctx.profile_enable(False)
+    tot = sum(v["total_ms"] for v in st.values())
+    ok = int((r.row_hi > r.row_lo).sum().item())
+    multi = int((r.row_hi - r.row_lo > 1).sum().item())
+    out = {"workload": f"t5-base dims, {docs}-doc SKEWED trie (squared-uniform codes on levels 1-3, 10 % duplicated smtids), "
+                       f"beams={B}, len={L}, {queries} queries/step",
+           "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "forks_last_step": forks, "leftover_fallback_taken": fb,
+           "select_share_of_kernel_time": st["select"]["total_ms"] / max(1e-9, tot),
+           "kernel_breakdown_ms": {k: round(v["total_ms"], 3) for k, v in st.items()},
+           "valid_leaves": f"{ok}/{queries * B}", "returned_smtids_with_several_docs": multi, "trie_build_s": round(t_trie, 1),
+           "single_sequence_node_share_by_depth": [round(float(x), 4) for x in frac[:10]]}
+    del trie
+    return out
+
+
+def secondary_train_step(E, synth, ctx, dev, world, rank, bz=128, L=32, steps=5, precision=None):
+    """BASELINE config 5 / SURVEY §8 row f4: one optimisation step of the prefix-oriented ranking fine-tune
+    (forward + backward + gradient all-reduce over the ranks + clip + AdamW), t5-base dims, bz examples per GPU."""
+    import torch.distributed as dist
+    V = 256
+    dims = synth.t5_base_dims(L=L, V=V)
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+    state = E.TrainState(model)
+    ids, mask = synth.make_queries(bz * world, vocab_size=dims.vocab_size, seed=5, mean_len=16, std_len=5, min_len=6, max_len=64)
+    ids, mask = ids[rank::world], mask[rank::world]
+    Lq = (ids.shape[1] + 7) // 8 * 8
+    ids = np.pad(ids, ((0, 0), (0, Lq - ids.shape[1]))); mask = np.pad(mask, ((0, 0), (0, Lq - mask.shape[1])))
+    codes = synth.make_codes(2 * bz, L, V, seed=5).astype(np.int64).reshape(2, bz, L).transpose(1, 0, 2).copy()
+    prefix = [L, 4, 8, 16][: {8: 2, 16: 3, 32: 4}[L]]
+    tp = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/p{k}", (bz,), 30.0) for k in prefix]))
+    tn = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/n{k}", (bz,), 30.0) for k in prefix]))
+    ids_t, mask_t, codes_t = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(codes).to(dev)
+    saved = ctx.get_precision()
+    if precision:
+        ctx.set_precision(precision)
+    try:
+        def step():
+            return E.train_step(model, state, ids_t, mask_t, codes_t, tp, tn, prefix, lr=1e-6)
+
+        first = step()
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / steps
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prec = ctx.get_precision()
+    finally:
+        ctx.set_precision(saved)
+    out = {"workload": f"lng_knp margin-MSE fine-tune step (forward + backward + gradient all-reduce + clip + AdamW), t5-base dims, "
+                       f"bz={bz}/GPU, smtid len {L}, queries padded to {int(Lq)}",
+           "value": world * bz / dt, "unit": "examples/s", "ms_per_step": dt * 1e3, "steps": steps, "n_gpus": world,
+           "gemm_arithmetic": prec, "loss_first": [float(x) for x in first], "loss_last": [float(x) for x in last],
+           "allreduce_bytes_per_step_per_rank": int(state.total * 4) if world > 1 else 0,
+           "allreduce": E.allreduce_mode() if world > 1 else "none (1 rank)", "params": int(state.total)}
+    del model, state
+    return out
+
+
 def launch_command(gpus, env, argv):
     """The N>1 contract is one process per GPU under torch.distributed.run. When --gpus N > 1 is given without a
     launcher (no WORLD_SIZE in the environment), return the command that re-runs this script as N ranks on
@@ -140,6 +303,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--secondary", default="train,config4,f2,skew",
+                    help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
+                         "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie); '' = none. config4 / f2 / "
+                         "skew run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
     ap.add_argument("--no-lanes", action="store_true",
                     help="one stream for the whole batch instead of two half batches on two CU-masked streams")
     ap.add_argument("--forced-tail", type=int, default=2, choices=[0, 1, 2], dest="forced_tail",
@@ -462,23 +629,52 @@ def main():
                                                   "whole-chip launches: profiles/r02f_q2176_hbm_pmc.json" if lanes_on else "")}
                 out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
         if world == 1 and args.precision != "f32" and not args.no_exact_fp32:
-            # secondary figure: the same step on the exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), 1 warm-up + 2 timed
+            # secondary figure: the same step on the exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), 1 warm-up + 5 timed
             ctx.set_precision("f32")
             run_step(W); torch.cuda.synchronize()
+            n_fp32 = 5
             t0 = time.perf_counter()
-            for i in range(2):
+            for i in range(n_fp32):
                 run_step(W + (i % K))
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 2
+            dt = (time.perf_counter() - t0) / n_fp32
             ctx.set_precision("f16x2")
-            out["exact_fp32"] = {"value": Q / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": 2,
-                                 "dtype": "f32 (exact fp32 MFMA GEMMs)"}
+            out["exact_fp32"] = {"value": Q / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": n_fp32,
+                                 "dtype": "f32 (exact fp32 MFMA GEMMs)", "tail_leftover": bool(ctx.status(clear=True) & 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd, dims, B, L)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": len(os.sched_getaffinity(0)),
                                        "kind": "port", "sample": f"failed: {e!r}"}
+    # ---- secondary legs: the other BASELINE configurations (see the helpers above). `train` runs on every rank (its
+    # gradient all-reduce is a collective), the search legs on a single-GPU run only.
+    legs = [x for x in args.secondary.split(",") if x]
+    sec = {}
+
+    def leg(name, fn):
+        t0 = time.time()
+        try:
+            sec[name] = fn()
+        except Exception as e:   # a secondary leg never takes the headline down with it
+            sec[name] = {"error": repr(e)}
+        if rank == 0:
+            log(f"[bench] secondary {name}: {time.time() - t0:.1f}s -> "
+                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8")}))
+
+    if "train" in legs:
+        leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank))
+        if ctx.has_bf16():
+            leg("train_step_bf16", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, precision="bf16"))
+    if world == 1:
+        if "f2" in legs:
+            leg("f2", lambda: secondary_f2(E, synth, ctx, model, trie, dims, dev))
+        if "skew" in legs:
+            leg("skew", lambda: secondary_skew(E, synth, ctx, model, dims, dev, args.docs, B, L, V, Q))
+        if "config4" in legs and args.model == "t5-base":
+            leg("config4", lambda: secondary_config4(E, synth, ctx, trie, dev, L))
+    if rank == 0:
+        out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -89,6 +89,12 @@ typedef struct {
  *                  fp32-equivalent to ~2^-22 at 5.3x the fp32-MFMA rate (default). */
 #define RPR_PREC_F32 0
 #define RPR_PREC_F16X2 1
+/*  RPR_PREC_BF16   (training step only: rpr_lngknp_backward) every GEMM operand rounded to bf16, one bf16 MFMA per
+ *                  product, fp32 accumulation and fp32 results — the arithmetic of the reference's bf16 autocast
+ *                  (main.py:152 bf16=args.use_fp16, full_lng_knp_train_pipline.sh:93; tasks/trainer.py:229), BASELINE
+ *                  config 5 as stated. The search / inference entry points need fp32-equivalent scores (1e-4) and run as
+ *                  RPR_PREC_F16X2 under this setting. */
+#define RPR_PREC_BF16 2
 
 /* rpr_search flags */
 #define RPR_FLAG_LOG_SOFTMAX 1u /* apply_log_softmax_for_scores (generation.py:453-455)           */
@@ -301,8 +307,8 @@ int rpr_lngknp_forward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids,
  *   Lq <= 128, L <= the model's decoder length.
  * rpr_adamw_step: global L2 norm of flat_grads (-> out_grad_norm [dev, 1], nullable), clip coefficient
  *   min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no clipping), AdamW update of every tensor with the
- *   bias corrections of `step` (1-based), then the f16 weight planes of the search path are refreshed (synchronises
- *   the stream). weight_decay applies to every tensor except the two relative-attention-bias tables (HF 4.17
+ *   bias corrections of `step` (1-based); the f16 weight planes of the search / inference paths are marked stale and
+ *   re-split by the next rpr_search / rpr_lngknp_forward / rpr_encode on this model (a training loop never pays for it). weight_decay applies to every tensor except the two relative-attention-bias tables (HF 4.17
  *   Trainer.create_optimizer excludes nn.LayerNorm parameters and names containing "bias"; T5LayerNorm is not an
  *   nn.LayerNorm there, so layer-norm weights decay). The reference's default is weight_decay = 0.
  *   exp_avg / exp_avg_sq: [dev, rpr_param_total], zero before the first step. */
@@ -312,6 +318,20 @@ int rpr_param_info(rpr_model* model, int64_t index, const float** ptr, int64_t* 
 int rpr_lngknp_backward(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,
                         int32_t Lq, const int32_t* doc_codes, int32_t L, const float* teacher_pos, const float* teacher_neg,
                         const int32_t* prefix_lens, int32_t n_prefix, float* out_losses, float* flat_grads, void* stream);
+/* The same pass with the gradient exchange overlapped (reference: DistributedDataParallel's bucketed all-reduce running
+ * under the backward pass, tasks/trainer.py:486). The flat gradient buffer is handed over in BUCKETS: one per
+ * transformer layer (decoder layers last to first, then encoder layers last to first: the order the backward finishes
+ * them; a layer's tensors are contiguous in the flat layout) and a final one for everything in front of the first layer
+ * (embeddings, codebooks, cross K/V, final norms, bias tables). For each bucket the library makes `comm_stream` wait for
+ * the kernels that produce it (main stream and the internal weight-gradient stream) and then calls, on the calling host
+ * thread and before returning, on_bucket(user, offset, numel): the callback enqueues the bucket's all-reduce (RCCL) on
+ * comm_stream, where it runs beside the remaining backward kernels. The caller joins comm_stream before rpr_adamw_step.
+ * on_bucket == NULL: exactly rpr_lngknp_backward. */
+typedef void (*rpr_grad_bucket_cb)(void* user, int64_t offset, int64_t numel);
+int rpr_lngknp_backward_buckets(rpr_ctx* ctx, rpr_model* model, const int32_t* input_ids, const int32_t* attention_mask,
+                                int32_t bz, int32_t Lq, const int32_t* doc_codes, int32_t L, const float* teacher_pos,
+                                const float* teacher_neg, const int32_t* prefix_lens, int32_t n_prefix, float* out_losses,
+                                float* flat_grads, void* stream, void* comm_stream, rpr_grad_bucket_cb on_bucket, void* user);
 int rpr_adamw_step(rpr_ctx* ctx, rpr_model* model, const float* flat_grads, float* exp_avg, float* exp_avg_sq, int64_t step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                    float* out_grad_norm, void* stream);

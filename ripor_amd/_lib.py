@@ -19,7 +19,7 @@ KERNEL_CLASS_NAMES = ["gemm", "dec_self_attn", "dec_cross_attn", "enc_attn", "rm
 STATUS_SATURATED, STATUS_EMPTY_QUERY, STATUS_TAIL_LEFTOVER = 1, 2, 4
 ABI_VERSION = 3
 
-PREC_F32, PREC_F16X2 = 0, 1
+PREC_F32, PREC_F16X2, PREC_BF16 = 0, 1, 2
 FLAG_LOG_SOFTMAX = 1
 FLAG_NO_GRAPH = 2
 
@@ -28,6 +28,7 @@ class RiporHipError(RuntimeError):
     pass
 
 
+GRAD_BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 c_f32p = C.POINTER(C.c_float)
 c_f32pp = C.POINTER(c_f32p)
 
@@ -100,6 +101,9 @@ SIGNATURES = {
     "rpr_param_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rpr_lngknp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rpr_lngknp_backward_buckets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rpr_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rpr_get_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),

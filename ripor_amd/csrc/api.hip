@@ -111,6 +111,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     if (dbg & 2) g.row_ssq = nullptr;
     g.sat = L.c->status;
     g.cus = L.c->cur_cus;
+    g.small_live = m_dev ? L.c->cur_small_live : 0;
     g.part = P<float>(L.c->ws.part); g.part_cap = L.c->ws.part.cap / sizeof(float); g.mid_split = 1;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
@@ -393,7 +394,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
         g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
         g.row_ssq = a.ssq; g.inv_d_fix = a.inv_d_fix; g.eps = a.eps; g.sat = c->status;
-        g.m_dev = sv.nrows_dev; g.cus = c->cur_cus;
+        g.m_dev = sv.nrows_dev; g.cus = c->cur_cus; g.small_live = sv.nrows_dev ? c->cur_small_live : 0;
         Ln.run(RPR_K_GEMM, 2.0 * Ma * (double)V * dm, 4.0 * ((double)Ma * dm + (double)V * dm + (double)Ma * V),
                [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
       } else {
@@ -587,9 +588,14 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // Stages: stage 0 (all queries) walks steps [0, forks[0]); at every fork the forced queries get their tail pass and
   // the others are compacted into the next stage, which walks on to the next fork (or to L); finalize ranks whoever is
   // still stepping at L. Without forks this is the plain loop of the reference.
+  // Everything after the first fork works on what that fork left over — usually a handful of queries in buffers sized for
+  // all of them: those GEMMs are enqueued as large-tile / small-tile pairs gated on the live count (GemmH2Args.small_live)
+  struct SmallLive { rpr_ctx* c; ~SmallLive() { c->cur_small_live = 0; } } small_guard{c};
+  static const int small_live_rows = [] { const char* e = getenv("RPR_SMALL_LIVE"); return e ? atoi(e) : 1024; }();
   int t0 = 0;
   for (size_t k = 0; k <= forks.size(); ++k) {
     const int t1 = k < forks.size() ? forks[k] : L;
+    c->cur_small_live = k >= 1 ? small_live_rows : 0;
     enqueue_steps(Ln, c, m, tr, sd, sv, t0, t1, shared0, taps, sel_clk);
     if (k < forks.size()) {
       const int next_depth = k + 1 < forks.size() ? forks[k + 1] : L;
@@ -722,7 +728,8 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   RPR_HIP(init_tail_kernel_attributes());
   auto* c = new rpr_ctx();
   c->device = device;
-  if (const char* e = getenv("RPR_PRECISION")) c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : RPR_PREC_F16X2;
+  if (const char* e = getenv("RPR_PRECISION"))
+    c->precision = (std::string(e) == "f32") ? RPR_PREC_F32 : (std::string(e) == "bf16") ? RPR_PREC_BF16 : RPR_PREC_F16X2;
   if (const char* e = getenv("RPR_LANE_MIN_ROWS")) c->lane_min_rows = atoi(e) > 0 ? atoi(e) : 0;
   if (const char* e = getenv("RPR_FORCED_TAIL")) c->forced_tail = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   if (const char* e = getenv("RPR_FORK_DEPTHS")) {   // "4,6": explicit fork depths; "" or "0": none
@@ -783,7 +790,7 @@ int64_t rpr_workspace_bytes(const rpr_ctx* c) { return c ? (int64_t)c->ws_bytes 
 
 int rpr_set_precision(rpr_ctx* c, int precision) {
   RPR_REQUIRE(c, "NULL ctx");
-  RPR_REQUIRE(precision == RPR_PREC_F32 || precision == RPR_PREC_F16X2, "unknown precision");
+  RPR_REQUIRE(precision == RPR_PREC_F32 || precision == RPR_PREC_F16X2 || precision == RPR_PREC_BF16, "unknown precision");
   c->precision = precision;
   return RPR_OK;
 }
@@ -1153,7 +1160,10 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   auto p_forced = [&](int t) { return std::pow(f[(size_t)t], (double)B); };
   int t0 = 0;
   for (int t = 1; t <= L - 2 && !t0; ++t) if (p_forced(t) >= 0.5) t0 = t;
-  if (!t0) return forks;
+  // a tail pass costs what its positions cost step by step minus the K/V gathering, plus a fork (~100 launches, two
+  // partly filled launches for the leftovers): below 8 remaining positions the plain loop is as fast (measured at
+  // beam 100, len 8: 1890 queries/s without forks, 1510 with)
+  if (!t0 || L - t0 < 8) return forks;
   forks.push_back(t0);
   for (int t = t0 + 1; t <= L - 2 && t <= t0 + 12; ++t)
     if ((double)Q * (1.0 - p_forced(t)) <= 0.05) { forks.push_back(t); break; }
@@ -1181,6 +1191,7 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   } ws_guard(c, lane);
   // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;   // bf16 is a training-GEMM mode; scores need fp32-equivalent
   if (m->f32_only) c->precision = RPR_PREC_F32;
   bool drop_last = false;
   const std::vector<int> forks = choose_forks(c, m, tr, Q, B, L, flags, taps != nullptr, &drop_last);
@@ -1241,6 +1252,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  { const int pe = ensure_weight_planes(c, m, s); if (pe) return pe; }   // after an optimizer step
   c->last_ws_mask = 0;
   // Large batches: two halves on the two CU-masked lanes, side by side (see Lane). Results are those of one call: every
   // query is processed on its own rows. The caller's stream waits for both lanes.
@@ -1252,6 +1264,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     for (int i = 0; i < 2; ++i) {
       std::swap(c->ws, c->lanes[i].ws);
       const int saved_prec = c->precision;
+      if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;
       if (m->f32_only) c->precision = RPR_PREC_F32;
       bool drop_last = false;
       const std::vector<int> forks = choose_forks(c, m, tr, Qh[i], B, L, flags, false, &drop_last);
@@ -1354,7 +1367,9 @@ int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const
   RPR_REQUIRE(out_losses || out_position_scores, "nothing to return");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int e = alloc_train_workspace(c, m, bz, Lq, n_docs, L);
+  int e = ensure_weight_planes(c, m, s);
+  if (e) return e;
+  e = alloc_train_workspace(c, m, bz, Lq, n_docs, L);
   if (e) return e;
   Workspace& w = c->ws;
   const size_t T = (size_t)bz * Lq, R = (size_t)bz * n_docs * L;
@@ -1364,6 +1379,7 @@ int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const
   int32_t* codes = reinterpret_cast<int32_t*>(scores + R);
   RPR_HIP(hipMemcpyAsync(codes, doc_codes, R * 4, hipMemcpyDeviceToDevice, s));
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;
   if (m->f32_only) c->precision = RPR_PREC_F32;
   Launcher Ln{c, s};
   enqueue_train_forward(Ln, c, m, bz, Lq, n_docs, L, codes, scores);
@@ -1380,13 +1396,16 @@ int rpr_encode(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t
   RPR_REQUIRE(Q >= 1 && Lq >= 1 && Lq <= MAX_LQ, "Q or Lq out of range");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int e = alloc_workspace(c, m, Q, Lq, 1, 1);
+  int e = ensure_weight_planes(c, m, s);
+  if (e) return e;
+  e = alloc_workspace(c, m, Q, Lq, 1, 1);
   if (e) return e;
   Workspace& w = c->ws;
   const size_t T = (size_t)Q * Lq;
   RPR_HIP(hipMemcpyAsync(w.ids.p, input_ids, T * 4, hipMemcpyDeviceToDevice, s));
   RPR_HIP(hipMemcpyAsync(w.mask.p, attention_mask, T * 4, hipMemcpyDeviceToDevice, s));
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;
   if (m->f32_only) c->precision = RPR_PREC_F32;
   Launcher Ln{c, s};
   enqueue_encoder(Ln, c, m, Q, Lq, false);
@@ -1403,6 +1422,8 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Launcher Ln{c, s};
   DevTmp At, Wt;
+  struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
+  if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;
   if (c->precision == RPR_PREC_F16X2) {  // test hook: split the operands on the fly
     RPR_HIP(At.alloc((size_t)M * K * 2 * sizeof(__half)));
     RPR_HIP(Wt.alloc((size_t)N * K * 2 * sizeof(__half)));
@@ -1455,7 +1476,7 @@ int rpr_status_words_async(rpr_ctx* c, void* stream, uint32_t* host_words, int c
   return RPR_OK;
 }
 
-int rpr_model_f32_only(const rpr_model* m) { return m ? (m->f32_only ? 1 : 0) : -1; }
+int rpr_model_f32_only(const rpr_model* m) { return m ? (m->f32_only ? 1 : 0) : -1; }   // as of the last plane split
 
 int rpr_profile_enable(rpr_ctx* c, int enable) {
   RPR_REQUIRE(c, "NULL ctx");

@@ -114,6 +114,12 @@ struct GemmH2Args {
   float* part; size_t part_cap;            // floats
   int mid_split;                           // search path: allow the split-K + separate fused-epilogue route (mid-size M)
   int ksplit; size_t part_stride;          // set by the launcher
+  // Live-count window (launches with m_dev only; 0 / 0 = no window): the kernel runs iff live_lo < *m_dev <= live_hi.
+  // launch_gemm_h2 uses it to enqueue a compacted stage's GEMM twice when small_live > 0 — the large-tile kernel for many
+  // live rows and a small-tile one for at most small_live — one of which exits at once (the launch geometry of a
+  // hipGraph is static, the number of queries a fork leaves over is not).
+  int live_lo, live_hi, small_live;
+  int bf16;                                // 1: A and W are single bf16 planes (training GEMMs, RPR_PREC_BF16); fp32 output only
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 
@@ -373,6 +379,10 @@ hipError_t launch_absmax2(const float* x0, size_t n0, const float* x1, size_t n1
 hipError_t launch_split_dyn(const float* x, int R, int C, int ldi, __half* out, const float* amax, hipStream_t s);
 hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, __half* out_t, __half* out_plain, const float* amax,
                               hipStream_t s);
+// fp32 [R, C] (row stride ldi) -> one bf16 plane (round to nearest even): plain out[R][C] and / or transposed
+// out_t[C][Rpad] (columns r >= R zero); RPR_PREC_BF16 training GEMMs
+hipError_t launch_to_bf16(const float* x, int R, int C, int ldi, void* out, hipStream_t s);
+hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s);
 hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
 hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,

@@ -30,6 +30,7 @@
 namespace rpr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -50,7 +51,12 @@ constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 // 4: launches with fewer tiles than CUs (small in-flight batches) — one block per CU walks its whole K alone, and
 // with one tile of prefetch every K-tile paid a full L2/HBM latency (~1.2 us x 24 K-tiles per GEMM); three tiles
 // in flight and a counted s_waitcnt make the walk bandwidth-bound instead.
-template <int BM, int BN, int WM, int WN, bool FULL, int STAGES = 2>
+// BF16 = false: the split-precision f16 hi/lo planes (3 MFMAs per product, K-tile of 32). BF16 = true: ONE bf16 plane per
+// operand and one v_mfma_f32_32x32x16_bf16 per product with fp32 accumulation — the arithmetic of the reference's bf16
+// autocast for the training GEMMs (RPR_PREC_BF16; main.py:152, tasks/trainer.py:229), except that the result is not
+// rounded to bf16. The LDS layout is the same: where the split kernel keeps the lo planes, this one keeps the NEXT 32
+// columns of K, so a K-tile is 64 deep (16 MFMAs per wave and barrier for the 128x128 tile instead of 8).
+template <int BM, int BN, int WM, int WN, bool FULL, int STAGES = 2, bool BF16 = false>
 __global__ __launch_bounds__(64 * WM * WN, STAGES > 2 ? 1 : (WM * WN) / 4 * ((BM * BN >= 256 * 256) ? 1 : 2))
 void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
@@ -59,6 +65,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;                    // waves per block
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA 32x32 tiles per wave
   constexpr int ROWS = 2 * (BM + BN);            // LDS rows of 32 halves (64 B) per buffer
+  constexpr int KSTEP = BF16 ? 2 * HBK : HBK;    // K columns per tile
   constexpr int NINST = ROWS / 16;               // DMA wave-instructions per K-tile (16 rows each)
   constexpr int PER_WAVE = NINST / NW;
   static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
@@ -67,7 +74,9 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
   if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
-    nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;
+    const int live = min(*g.m_dev, g.M);
+    if (g.live_hi > 0 && (*g.m_dev <= g.live_lo || *g.m_dev > g.live_hi)) return;   // the other kernel of the pair runs
+    nt = ((live + BM - 1) / BM) * tiles_n;
     if (bid >= nt) return;
   }
   {
@@ -81,7 +90,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   const int wm = wave / WN, wn = wave % WN;
   // split-K (training weight gradients: few output tiles, K = thousands of rows): blockIdx.y walks its own range of
   // K-tiles and stores a partial result at out + blockIdx.y * part_stride; splitk_reduce_kernel adds them in order
-  int nkt = g.K / HBK, kbeg = 0;
+  int nkt = g.K / KSTEP, kbeg = 0;
   if (g.ksplit > 1) {
     const int per = (nkt + g.ksplit - 1) / g.ksplit;
     kbeg = blockIdx.y * per;
@@ -98,12 +107,13 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     const __half* base;
     int trow, limit;
     size_t ld;
+    const size_t second = BF16 ? (size_t)HBK : 0;                   // the "second plane" of the bf16 mode: the next 32 columns
     if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + (BF16 ? second : g.a_ps); trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
     else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
-    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    else { base = g.W + (BF16 ? second : g.w_ps); trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
     if (!FULL && trow >= limit) trow = limit - 1;                  // ragged tile: duplicate a valid row
-    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * HBK;
+    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;
   }
   auto stage = [&](int buf, int k0) {
 #pragma unroll
@@ -132,6 +142,28 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 #pragma unroll
     for (int c = 0; c < HBK / 16; ++c) {
       const int so = ((2 * c + hf) ^ sw) * 8;
+      if (BF16) {   // columns k .. k+31 in the first row groups, k+32 .. k+63 in the second
+        bf16x8 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          a0[i] = *reinterpret_cast<const bf16x8*>(base + (a_row + i * 32) * HBK + so);
+          a1[i] = *reinterpret_cast<const bf16x8*>(base + (BM + a_row + i * 32) * HBK + so);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          b0[j] = *reinterpret_cast<const bf16x8*>(base + (w_row + j * 32) * HBK + so);
+          b1[j] = *reinterpret_cast<const bf16x8*>(base + (BN + w_row + j * 32) * HBK + so);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        continue;
+      }
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -162,7 +194,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     stage(0, 0);
     __syncthreads();  // drains the DMA (vmcnt(0)) and publishes buffer 0
     for (int kt = 0; kt + 1 < nkt; ++kt) {
-      stage((kt + 1) & 1, (kt + 1) * HBK);
+      stage((kt + 1) & 1, (kt + 1) * KSTEP);
       compute(kt & 1);
       __syncthreads();
     }
@@ -176,14 +208,14 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     constexpr int WAIT_NONE = 0x0f70;
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t)
-      if (t < nkt) stage(t, t * HBK);
+      if (t < nkt) stage(t, t * KSTEP);
     for (int kt = 0; kt < nkt; ++kt) {
       // this wave's pieces of tile kt have landed once at most the pieces of the AHEAD-1 younger tiles are pending
       // (fewer tiles are in flight at the tail: wait for everything there)
       if (kt + AHEAD - 1 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_KEEP); else __builtin_amdgcn_s_waitcnt(WAIT_NONE);
       __builtin_amdgcn_s_barrier();                            // everyone's pieces landed; compute(kt-1) is over everywhere
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + AHEAD < nkt) stage((kt + AHEAD) % STAGES, (kt + AHEAD) * HBK);   // refills the buffer of tile kt-1
+      if (kt + AHEAD < nkt) stage((kt + AHEAD) % STAGES, (kt + AHEAD) * KSTEP);   // refills the buffer of tile kt-1
       compute(kt % STAGES);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -395,7 +427,10 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // `s_waitcnt vmcnt(0)` at the end of L_3 and first read in L_0 of tile t+1 (one phase after the wait, as
 // the staggered groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's
 // last reads are retired before the other group starts overwriting it.
-template <bool FULL, bool TRACE = false>
+// BF16 = true (training GEMMs, RPR_PREC_BF16): one bf16 plane per operand; the LDS rows of the lo planes hold the NEXT
+// 32 columns of K instead, a K-tile is 64 deep and a phase issues 8 v_mfma_f32_32x32x16_bf16 (slice 0 x slice 0 and
+// slice 1 x slice 1) on the same fragment reads — see gemm_h2_dma_kernel.
+template <bool FULL, bool TRACE = false, bool BF16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n, int skew_ticks) {
   // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
   // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
@@ -410,7 +445,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   // the block retires, and blocks started with different offsets (skew_ticks) stay out of phase for the whole launch:
   // the HBM bursts of the epilogues of some CUs run under the power-bound K-loops of the others.
   int nt = tiles_m * tiles_n;
-  if (g.m_dev) nt = ((*g.m_dev + BM - 1) / BM) * tiles_n;   // packed rows: only the tiles holding live rows
+  if (g.m_dev) {                                             // packed rows: only the tiles holding live rows
+    if (g.live_hi > 0 && (*g.m_dev <= g.live_lo || *g.m_dev > g.live_hi)) return;   // the other kernel of the pair runs
+    nt = ((min(*g.m_dev, g.M) + BM - 1) / BM) * tiles_n;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -448,9 +486,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     int trow, limit;
     size_t ld;
     if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + (BF16 ? (size_t)HBK : g.a_ps); trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
     else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
-    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    else { base = g.W + (BF16 ? (size_t)HBK : g.w_ps); trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
     if (!FULL && trow >= limit) trow = limit - 1;
     src[j] = base + (size_t)trow * ld + seg * 8;
   }
@@ -489,11 +527,24 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32) * HBK + (so));               \
     al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32 + 32) * HBK + (so));          \
   }
-#define PP_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define PP_MFMA(a, b, c)                                                                                 \
+  do {                                                                                                   \
+    if (BF16) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0); \
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);                                   \
+  } while (0)
 // the 12 MFMAs of a phase in three groups of four (lo*hi, hi*lo, hi*hi); D1..D3 are statements issued in the
 // MFMA shadows after the 2nd, 6th and 10th MFMA (LDS-DMA pieces of the next tile, or nothing)
 #define PP_MMA(i0, D1, D2, D3)                                                                          \
   {                                                                                                     \
+    if (BF16) {   /* slice 1 x slice 1 ("lo" rows), then slice 0 x slice 0 */                           \
+      PP_MFMA(al0, bl0, acc[(i0)][0]); PP_MFMA(al0, bl1, acc[(i0)][1]);                                 \
+      __builtin_amdgcn_sched_barrier(0); D1; __builtin_amdgcn_sched_barrier(0);                         \
+      PP_MFMA(al1, bl0, acc[(i0) + 1][0]); PP_MFMA(al1, bl1, acc[(i0) + 1][1]);                         \
+      __builtin_amdgcn_sched_barrier(0); D2; __builtin_amdgcn_sched_barrier(0);                         \
+      PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                 \
+      __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                         \
+      PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                         \
+    } else {                                                                                            \
     PP_MFMA(al0, bh0, acc[(i0)][0]); PP_MFMA(al0, bh1, acc[(i0)][1]);                                   \
     __builtin_amdgcn_sched_barrier(0); D1; __builtin_amdgcn_sched_barrier(0);                           \
     PP_MFMA(al1, bh0, acc[(i0) + 1][0]); PP_MFMA(al1, bh1, acc[(i0) + 1][1]);                           \
@@ -503,6 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                   \
     __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                           \
     PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                           \
+    }                                                                                                   \
   }
 // the 8 LDS-DMA pieces of the next tile go into the MFMA shadows of M_0 / M_1 / M_2 (3 + 3 + 2); issuing them in
 // the load segments instead (4+4 or 3+3+2), with or without s_setprio, measured the same within 0.5 % (DVFS)
@@ -525,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __builtin_amdgcn_sched_barrier(0)
   constexpr int WAIT_LGKM = 0xc07f, WAIT_ALL = 0x0070;   // lgkmcnt(0) | vmcnt(0) lgkmcnt(0)
 
-  const int nkt = g.K / HBK;
+  const int nkt = g.K / (BF16 ? 2 * HBK : HBK);
   // TRACE: block 0 stamps s_memtime (shader cycles) at the 4 segment edges of each phase -> 16 per (K-tile, wave),
   // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
   const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
@@ -540,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;
-    const int k1 = (kt + 1) * HBK;
+    const int k1 = (kt + 1) * (BF16 ? 2 * HBK : HBK);
     // phase 0: chunk 0, A rows 0..63
     if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + 16] = __builtin_amdgcn_s_memrealtime(); }
     PP_STAMP(0);
@@ -718,24 +770,24 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   }
 }
 
-template <int BM, int BN, int WM = 2, int WN = 2>
+template <int BM, int BN, int WM = 2, int WN = 2, bool BF16 = false>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const bool full = (a.M % BM == 0) && (a.N % BN == 0) && !a.m_dev;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const dim3 grid(tiles_m * tiles_n, ks), blk(64 * WM * WN);
   static const int deep_max = [] { const char* e = getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
-  if ((tiles_m * tiles_n * ks <= deep_max || BM < 128) && !a.m_dev) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
+  if ((tiles_m * tiles_n * ks <= deep_max || BM < 128) && (!a.m_dev || a.live_hi > 0)) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
     if (full)
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 4>), grid, blk, 0, s, a, tiles_m, tiles_n);
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 4, BF16>), grid, blk, 0, s, a, tiles_m, tiles_n);
     else
-      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false, 4>), grid, blk, 0, s, a, tiles_m, tiles_n);
+      hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false, 4, BF16>), grid, blk, 0, s, a, tiles_m, tiles_n);
     return hipGetLastError();
   }
   if (full)
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true>), grid, blk, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 2, BF16>), grid, blk, 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false>), grid, blk, 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, false, 2, BF16>), grid, blk, 0, s, a, tiles_m, tiles_n);
   return hipGetLastError();
 }
 
@@ -743,7 +795,8 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
+  static const int assume_full = [] { const char* e = getenv("RPR_GEMM_ASSUME_FULL"); return e ? atoi(e) : 0; }();   // diagnostic
+  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && (!a.m_dev || assume_full);
   // persistent blocks: one per CU of the stream (a whole number per XCD), fewer when the launch has fewer tiles
   static const int persist = [] { const char* e = getenv("RPR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   static const int skew = [] { const char* e = getenv("RPR_GEMM_SKEW"); return e ? atoi(e) : 0; }();   // 100 MHz ticks per K = 768
@@ -752,6 +805,11 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   // skew only pays when a block walks several tiles (the late blocks idle for up to 3/4 of a tile time once per launch)
   const int skew_ticks = (grid < nt && nt >= 4 * cus) ? (int)((long)skew * a.K / 768) : 0;
   const dim3 gr(grid), bl(512);
+  if (a.bf16) {
+    if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+    else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+    return hipGetLastError();
+  }
   if (full && a.trace)
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
   else if (full)
@@ -818,6 +876,47 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   a_in.kernel_cls = RPR_K_GEMM_SMALL;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
+  if (a.m_dev && a.small_live > 0 && a.M > a.small_live && !a.bf16) {
+    // a compacted stage: capacity M rows, usually a handful alive. The large-tile kernel would walk all of K with the
+    // one or two blocks that hold live rows (60-250 us per launch); pair it with a 128x64 launch sized for small_live
+    // rows, each gated on the device-side live count.
+    GemmH2Args big = a, sm = a;
+    big.small_live = 0; big.live_lo = a.small_live; big.live_hi = 0x7fffffff;
+    sm.small_live = 0; sm.live_lo = -1; sm.live_hi = a.small_live; sm.M = a.small_live;
+    hipError_t e = launch_gemm_h2(big, s);
+    if (e != hipSuccess) return e;
+    a_in.kernel_cls = big.kernel_cls;
+    return launch_cfg<128, 64>(sm, s);
+  }
+  if (a.bf16) {
+    // one bf16 plane per operand (training GEMMs, RPR_PREC_BF16): fp32 output, optional residual / ReLU, split-K for the
+    // long reductions into few tiles (weight gradients); K-tiles of 64 columns
+    if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63)) return hipErrorInvalidValue;
+    const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.part && a.K >= 2048 && t128b * 2 < 640 && !a.relu && a.split_n >= a.N && (a.N & 3) == 0 && (a.ldo[0] & 3) == 0 &&
+        (!a.resid || (a.ldr & 3) == 0)) {
+      const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+      long ks = std::min<long>((640 + t - 1) / t, a.K / 1024);
+      ks = std::min<long>(ks, (long)(a.part_cap / ((size_t)a.M * a.N)));
+      const int nkt = a.K / (2 * HBK);
+      while (ks > 1 && (ks - 1) * ((nkt + ks - 1) / ks) >= nkt) --ks;
+      if (ks > 1) {
+        GemmH2Args p = a;
+        p.ksplit = (int)ks; p.part_stride = (size_t)a.M * a.N;
+        p.out[0] = p.out[1] = p.out[2] = a.part; p.ldo[0] = p.ldo[1] = p.ldo[2] = a.N; p.split_n = a.N; p.resid = nullptr;
+        hipError_t e = launch_cfg<128, 64, 2, 2, true>(p, s);
+        if (e != hipSuccess) return e;
+        const size_t n4 = (size_t)a.M * (a.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.part, (int)ks, p.part_stride, a.M,
+                           a.N, a.out[0], a.ldo[0], a.resid, a.ldr);
+        return hipGetLastError();
+      }
+    }
+    const long t256b = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    static const int bf_pp = [] { const char* e = getenv("RPR_BF16_PP"); return e ? atoi(e) : 1; }();
+    if (bf_pp && t256b >= 200) return launch_256(a, s);     // ping-pong 256x256 tiles when they fill the chip
+    return t128b < 256 ? launch_cfg<128, 64, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, true>(a, s);
+  }
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   // 256-tile rounds on the 256 CUs: a launch just over a whole number of rounds (e.g. 288 tiles) leaves most of the

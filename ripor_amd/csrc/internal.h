@@ -38,6 +38,7 @@ struct rpr_model {
   // (enc_qkv: ln0, enc_wi: ln1, dec_qkv: ln0, dec_xq: ln1, dec_wi: ln2, out_embeds: final ln * scaleup factor);
   // the fp32 weights of the caller stay untouched and serve the exact-fp32 mode.
   bool f32_only = false;           // a weight does not fit the f16 planes: every search of this model runs exact fp32
+  bool planes_dirty = false;       // the fp32 weights changed (rpr_adamw_step) since the planes were split
   std::vector<void*> owned;
   // how every plane buffer was produced (replayed by refresh_weight_planes after an optimizer step changed the weights)
   struct PlaneJob { const float* w; size_t n; __half* dst; const float* ln; float pre; };
@@ -151,6 +152,7 @@ struct rpr_ctx {
   hipEvent_t fork_ev = nullptr;
   int cur_cus = 0;              // CUs of the lane the current enqueue runs on (0 = the whole chip)
   int lane_cus = 0;             // CUs per lane
+  int cur_small_live = 0;       // > 0 while a leftover stage is enqueued: its GEMMs are paired (GemmH2Args.small_live)
   int forced_tail = 1;          // 0 = every query runs all L steps sequentially, 1 = exact forced tail, 2 = optimistic (see choose_forks)
   int fork_override[MAX_FORKS] = {0, 0};   // explicit fork depths (rpr_set_fork_depths / RPR_FORK_DEPTHS); 0 = from the trie statistics
   int n_fork_override = -1;     // -1 = automatic
@@ -172,6 +174,12 @@ namespace rpr {
 
 // re-split every GEMM weight into its f16 planes (api.hip); sets model->f32_only if a weight no longer fits
 int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s);
+inline int ensure_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
+  if (!m->planes_dirty) return 0;
+  const int e = refresh_weight_planes(c, m, s);
+  if (!e) m->planes_dirty = false;
+  return e;
+}
 void free_train_ws(rpr_ctx* c);   // train_api.hip
 
 inline int ensure(rpr_ctx* c, DevBuf& b, size_t bytes) {

@@ -30,6 +30,7 @@ struct TrainWs {
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   bool done_pending[2] = {false, false};
   int flip = 0;
+  std::vector<hipEvent_t> bucket_ev;   // gradient buckets handed to the caller's communication stream (2 events each)
   int amax_next = 0;
   // forward GEMM site (keyed by its weight tensor) -> {amax of its input activations, amax of the weight}: the backward
   // multiplies the same two tensors again (dW = dY^T X, dX = dY W) and reuses both maxima
@@ -129,8 +130,33 @@ void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int l
 }
 
 // C[M, N] = act(A[M, K] B[N, K]^T) (+ resid): exact fp32 MFMA, or (split-precision mode) f16x2 planes with dynamic scales
+// one bf16 plane per operand, one MFMA per product (RPR_PREC_BF16)
+void gemm_bf16(Launcher& Ln, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const float* resid,
+               int relu, DevBuf* part = nullptr) {
+  GemmH2Args g{};
+  g.A = reinterpret_cast<const __half*>(A); g.lda = lda; g.W = reinterpret_cast<const __half*>(B); g.ldw = ldb;
+  g.resid = resid; g.ldr = ldc;
+  g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
+  g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.bf16 = 1;
+  if (!part) part = &Ln.c->tws->part;
+  g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float);
+  Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, [&] { return launch_gemm_h2(g, Ln.s); },
+         &g.kernel_cls);
+}
+
 void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
           const float* resid = nullptr, int relu = 0) {
+  if (Ln.c->precision == RPR_PREC_BF16) {
+    // the reference's bf16 autocast (main.py:152 bf16=args.use_fp16; tasks/trainer.py:229): operands rounded to bf16, fp32
+    // accumulation. One conversion pass per operand, no maxima, no second plane.
+    TrainWs& w = *Ln.c->tws;
+    if (lda != K || ldb != K) { Ln.err = RPR_ERR_INVALID; return; }
+    hipStream_t s = Ln.s;
+    Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16(A, M, K, lda, w.tA.p, s); });
+    Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16(B, N, K, ldb, w.wT.p, s); });
+    gemm_bf16(Ln, w.tA.p, K, w.wT.p, K, C, ldc, M, N, K, resid, relu);
+    return;
+  }
   if (Ln.c->precision == RPR_PREC_F16X2) {
     TrainWs& w = *Ln.c->tws;
     float* am = amax_slots(Ln.c, 2);
@@ -157,6 +183,33 @@ struct Bwd {
   void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K) {
     const int Mp = pad32(M);
     hipStream_t s = Ln.s;
+    if (c->precision == RPR_PREC_BF16) {
+      // bf16 operands (see gemm()): one read of dY gives its plain and its transposed copy; dW on the side stream.
+      // The bf16 kernel walks K in tiles of 64: the reduction length of the dW product (the rows) is padded to 64.
+      const int Mp = (M + 63) & ~63;
+      const int f = w.flip; w.flip ^= 1;
+      void *py = w.tA.p, *pyt = f ? w.tC2.p : w.tC.p, *pxt = f ? w.tB2.p : w.tB.p, *pwt = w.wT.p;
+      if (w.done_pending[f]) {
+        if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        w.done_pending[f] = false;
+      }
+      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s); });
+      Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16_T(X, M, K, K, Mp, pxt, nullptr, s); });
+      Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16_T(W, N, K, K, N, pwt, nullptr, s); });
+      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(w.side, w.ev_fork[f], 0) != hipSuccess) {
+        Ln.err = RPR_ERR_HIP; return;
+      }
+      static const bool side_on_b = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
+      {
+        Launcher L2{c, side_on_b ? w.side : s};
+        gemm_bf16(L2, pyt, Mp, pxt, Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2);
+        if (L2.err) { Ln.err = L2.err; return; }
+        if (hipEventRecord(w.ev_done[f], side_on_b ? w.side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        w.done_pending[f] = true;
+      }
+      gemm_bf16(Ln, py, N, pwt, N, dX, K, M, K, N, nullptr, 0);
+      return;
+    }
     if (c->precision == RPR_PREC_F16X2) {
       // one read of dY gives its plain planes (for dX) and its transposed planes (for dW); W is transposed straight
       // from the fp32 weight
@@ -216,7 +269,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   if (!c->tws) c->tws = new TrainWs();
   TrainWs& w = *c->tws;
   const size_t f = sizeof(float), R = D.R, T = D.T, dm = D.dm, inner = D.inner, dff = D.dff;
-  const size_t rows = std::max(R, T), rp = pad32((int)rows);
+  const size_t rows = std::max(R, T), rp = ((int)rows + 63) & ~63;   // rows padded to the K-tile of the bf16 kernel (64) / the split kernel (32)
   const size_t wide = std::max<size_t>(std::max<size_t>(dff, 3 * inner), (size_t)D.xld);
   int e = 0;
   auto E = [&](DevBuf& b, size_t bytes) { if (!e) e = tensure(c, b, bytes); };
@@ -317,10 +370,40 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   });
 }
 
-void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32_t* ids, const int32_t* mask, float* G) {
+// Gradient buckets for the data-parallel exchange (reference: DDP's bucketed all-reduce overlapped with the backward pass,
+// tasks/trainer.py:486 wraps the model in DistributedDataParallel): one bucket per transformer layer — its nine (six)
+// tensors are contiguous in the flat buffer — handed over the moment the layer's last gradient kernel has been ENQUEUED,
+// plus one for everything that is only final at the end (embeddings, codebooks, cross K/V, final norms, bias tables).
+// "Handed over" = the caller's communication stream is made to wait for the layer's producers on the main stream and on
+// the weight-gradient side stream, then the host callback runs: it enqueues the bucket's all-reduce on that stream, where
+// it overlaps the rest of the backward pass.
+struct BucketHook {
+  rpr_grad_bucket_cb cb; void* user; hipStream_t comm; int next = 0;
+};
+
+void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32_t* ids, const int32_t* mask, float* G,
+              BucketHook* hook = nullptr) {
   TrainWs& w = *c->tws;
   const auto& d = m->d;
   hipStream_t s = Ln.s;
+  auto bucket = [&](size_t off, size_t numel) {
+    if (!hook || !hook->cb || Ln.err) return;
+    while ((int)w.bucket_ev.size() < 2 * (hook->next + 1)) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+      w.bucket_ev.push_back(e);
+    }
+    hipEvent_t e0 = w.bucket_ev[(size_t)2 * hook->next], e1 = w.bucket_ev[(size_t)2 * hook->next + 1];
+    ++hook->next;
+    if (hipEventRecord(e0, s) != hipSuccess || hipStreamWaitEvent(hook->comm, e0, 0) != hipSuccess ||
+        hipEventRecord(e1, w.side) != hipSuccess || hipStreamWaitEvent(hook->comm, e1, 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    hook->cb(hook->user, (int64_t)off, (int64_t)numel);
+  };
+  auto layer_numel = [&](int first_kind, int last_kind, int layer) {
+    size_t lo = param_offset(m, first_kind, layer), hi = param_offset(m, last_kind, layer);
+    for (const auto& p : m->params) if (p.kind == last_kind && p.layer == layer) hi += p.numel;
+    return std::make_pair(lo, hi - lo);
+  };
   const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff, H = D.H;
   Bwd B{Ln, c, w, D};
   auto g = [&](int kind, int layer = -1) { return G + param_offset(m, kind, layer); };
@@ -371,6 +454,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.dxdw(dbig, m->dec_qkv[i], h, h, g(K_DEC_QKV, i), R, 3 * inner, dm);
     B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
+    { const auto b = layer_numel(K_DEC_LN0, K_DEC_WO, i); bucket(b.first, b.second); }
   }
   // decoder input embeddings: codebook rows and the start embedding
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, P<int32_t>(w.in_idx), fix, R, dm, s); });
@@ -399,6 +483,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.dxdw(dbig, m->enc_qkv[i], h, h, g(K_ENC_QKV, i), T, 3 * inner, dm);
     B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
     std::swap(dx, dx2);
+    { const auto b = layer_numel(K_ENC_LN0, K_ENC_WO, i); bucket(b.first, b.second); }
   }
   // token embeddings (the encoder's table is the shared one)
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, ids, fix, T, dm, s); });
@@ -409,6 +494,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
       if (hipStreamWaitEvent(s, w.ev_done[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;
       w.done_pending[i] = false;
     }
+  bucket(0, param_offset(m, K_ENC_LN0, 0));   // everything in front of the first layer: final only now
 }
 
 }  // namespace
@@ -421,6 +507,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
                    &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC, &w.part, &w.tB2, &w.tC2, &w.part2};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < 2; ++i) { if (w.ev_fork[i]) (void)hipEventDestroy(w.ev_fork[i]); if (w.ev_done[i]) (void)hipEventDestroy(w.ev_done[i]); }
+  for (hipEvent_t e : w.bucket_ev) (void)hipEventDestroy(e);
   if (w.side) (void)hipStreamDestroy(w.side);
   delete c->tws;
   c->tws = nullptr;
@@ -444,6 +531,14 @@ int rpr_param_info(rpr_model* m, int64_t index, const float** ptr, int64_t* nume
 int rpr_lngknp_backward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz, int32_t Lq,
                         const int32_t* doc_codes, int32_t L, const float* teacher_pos, const float* teacher_neg,
                         const int32_t* prefix_lens, int32_t n_prefix, float* out_losses, float* flat_grads, void* stream) {
+  return rpr_lngknp_backward_buckets(c, m, input_ids, attention_mask, bz, Lq, doc_codes, L, teacher_pos, teacher_neg, prefix_lens,
+                                     n_prefix, out_losses, flat_grads, stream, nullptr, nullptr, nullptr);
+}
+
+int rpr_lngknp_backward_buckets(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t* attention_mask, int32_t bz,
+                                int32_t Lq, const int32_t* doc_codes, int32_t L, const float* teacher_pos, const float* teacher_neg,
+                                const int32_t* prefix_lens, int32_t n_prefix, float* out_losses, float* flat_grads, void* stream,
+                                void* comm_stream, rpr_grad_bucket_cb on_bucket, void* user) {
   RPR_REQUIRE(c && m && input_ids && attention_mask && doc_codes && teacher_pos && teacher_neg && prefix_lens && out_losses &&
                   flat_grads, "NULL argument");
   RPR_REQUIRE(m->ctx == c, "model belongs to another ctx");
@@ -477,7 +572,8 @@ int rpr_lngknp_backward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, cons
   RPR_HIP(launch_margin_mse(P<float>(w.scores), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, out_losses, P<float>(w.margins), s));
   // total loss = sum of the task losses with weight 1 (reference arguments.py:109-119, trainer.py:228-240)
   RPR_HIP(launch_margin_mse_bwd(P<float>(w.margins), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, P<float>(w.dscores), s));
-  backward(Ln, c, m, D, input_ids, attention_mask, flat_grads);
+  BucketHook hook{on_bucket, user, reinterpret_cast<hipStream_t>(comm_stream)};
+  backward(Ln, c, m, D, input_ids, attention_mask, flat_grads, on_bucket ? &hook : nullptr);
   return Ln.err;
 }
 
@@ -508,8 +604,11 @@ int rpr_adamw_step(rpr_ctx* c, rpr_model* m, const float* flat_grads, float* exp
                          beta2, eps, wd, bc1, bc2s, s));
   }
   if (out_grad_norm) RPR_HIP(hipMemcpyAsync(out_grad_norm, w.gn_out.p, 4, hipMemcpyDeviceToDevice, s));
-  // the search / forward paths read the f16 planes of the weights: refresh them (synchronises the stream)
-  return refresh_weight_planes(c, m, s);
+  // the search / inference paths read the f16 planes of the weights: they are stale now and are re-split by the next call
+  // that needs them (ensure_weight_planes) — a training loop never does, and the refresh costs a pass over every weight
+  // plus a stream synchronisation per step
+  m->planes_dirty = true;
+  return RPR_OK;
 }
 
 }  // extern "C"

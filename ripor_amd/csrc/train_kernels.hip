@@ -846,6 +846,60 @@ hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, _
   return hipGetLastError();
 }
 
+// ---- bf16 operands for the training GEMMs (RPR_PREC_BF16): one conversion pass per operand, no maxima, no second plane --
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ x, int R, int C, int ldi, __bf16* __restrict__ out) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;          // float4 index over R * C / 4
+  const int c4n = C >> 2;
+  if (i4 >= (size_t)R * c4n) return;
+  const int r = (int)(i4 / c4n), c = (int)(i4 - (size_t)r * c4n) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldi + c);
+  __bf16 b[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<uint2*>(out + (size_t)r * C + c) = *reinterpret_cast<uint2*>(b);
+}
+hipError_t launch_to_bf16(const float* x, int R, int C, int ldi, void* out, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  if ((C & 3) || (ldi & 3)) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)R * (C >> 2);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, R, C, ldi, reinterpret_cast<__bf16*>(out));
+  return hipGetLastError();
+}
+
+// 64 x 64 tile through LDS (as split_dyn_T_kernel): transposed out_t[C][Rpad] and, when given, the plain out_p[R][C]
+__global__ __launch_bounds__(256) void to_bf16_T_kernel(const float* __restrict__ x, int R, int C, int ldi, int Rpad,
+                                                         __bf16* __restrict__ out_t, __bf16* __restrict__ out_p) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = (tid >> 4) + 16 * k, c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < R && c0 + c < C) {
+      v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ldi + c0 + c);
+      if (out_p) {
+        __bf16 b[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<uint2*>(out_p + (size_t)(r0 + r) * C + c0 + c) = *reinterpret_cast<uint2*>(b);
+      }
+    }
+    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = (tid >> 5) + 8 * k, r = (tid & 31) * 2;        // Rpad % 2 == 0
+    if (c0 + c < C && r0 + r < Rpad) {
+      __bf16 b[2] = {(__bf16)tile[r][c], (__bf16)tile[r + 1][c]};
+      *reinterpret_cast<unsigned int*>(out_t + (size_t)(c0 + c) * Rpad + r0 + r) = *reinterpret_cast<unsigned int*>(b);
+    }
+  }
+}
+hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  if ((C & 3) || (ldi & 3) || (Rpad & 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(to_bf16_T_kernel, dim3((C + 63) / 64, (Rpad + 63) / 64), dim3(256), 0, s, x, R, C, ldi, Rpad,
+                     reinterpret_cast<__bf16*>(out_t), reinterpret_cast<__bf16*>(out_plain));
+  return hipGetLastError();
+}
+
 hipError_t init_train_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(self_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;

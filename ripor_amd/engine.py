@@ -49,11 +49,15 @@ class Context:
 
     def set_precision(self, name: str):
         """'f32' = exact fp32 MFMA; 'f16x2' = split-precision f16 MFMA (default)."""
-        check(self.lib.rpr_set_precision(self.handle, {"f32": _lib.PREC_F32, "f16x2": _lib.PREC_F16X2}[name]),
+        check(self.lib.rpr_set_precision(self.handle, {"f32": _lib.PREC_F32, "f16x2": _lib.PREC_F16X2, "bf16": _lib.PREC_BF16}[name]),
               "rpr_set_precision")
 
     def get_precision(self) -> str:
-        return {_lib.PREC_F32: "f32", _lib.PREC_F16X2: "f16x2"}[int(self.lib.rpr_get_precision(self.handle))]
+        return {_lib.PREC_F32: "f32", _lib.PREC_F16X2: "f16x2", _lib.PREC_BF16: "bf16"}[int(self.lib.rpr_get_precision(self.handle))]
+
+    def has_bf16(self) -> bool:
+        """The bf16 arithmetic of the training GEMMs (RPR_PREC_BF16) is compiled into this library."""
+        return True
 
     def workspace_bytes(self) -> int:
         return int(self.lib.rpr_workspace_bytes(self.handle))
@@ -647,10 +651,68 @@ class TrainState:
         return out
 
 
+class GradExchange:
+    """Data-parallel gradient exchange overlapped with the backward pass (the reference wraps the model in
+    DistributedDataParallel, tasks/trainer.py:486: bucketed all-reduce running under ``loss.backward()``).
+
+    ``rpr_lngknp_backward_buckets`` hands the flat gradient buffer over in buckets (one per transformer layer in the order
+    the backward finishes them, then one for the embeddings / codebooks / cross K/V / norms in front of the first layer):
+    for each, ``on_bucket(offset, numel)`` enqueues an asynchronous all-reduce of that slice on a communication stream
+    that already waits for the slice's producers. ``finish()`` joins the stream and divides by the world size (DDP's
+    averaging). RCCL ("nccl" backend) on GPUs: a bucket is 28-38 MB for t5-base — large messages, as the per-link-bound
+    ring on the point-to-point xGMI mesh wants; any torch.distributed backend works (the CPU tests use gloo).
+    With one rank (or no process group) nothing is enqueued."""
+
+    def __init__(self, grads: torch.Tensor):
+        import torch.distributed as dist
+        self.grads = grads
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.active else 1
+        self.stream = torch.cuda.Stream(grads.device) if (self.active and grads.is_cuda) else None
+        self.works: List = []
+        self.buckets: List[tuple] = []
+        self._cb = _lib.GRAD_BUCKET_CB(self._on_bucket_c)
+
+    def _on_bucket_c(self, _user, offset, numel):
+        self.on_bucket(int(offset), int(numel))
+
+    def on_bucket(self, offset: int, numel: int):
+        import torch.distributed as dist
+        self.buckets.append((offset, numel))
+        if not self.active or numel <= 0:
+            return
+        sl = self.grads[offset:offset + numel]
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+
+    def comm_stream_ptr(self):
+        return C.c_void_p(self.stream.cuda_stream) if self.stream is not None else None
+
+    def callback(self):
+        return self._cb if self.active else C.cast(None, _lib.GRAD_BUCKET_CB)
+
+    def finish(self):
+        """Join the exchange (the current stream waits for every bucket) and average."""
+        for w in self.works:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream(self.grads.device).wait_stream(self.stream)
+        covered = sum(n for _, n in self.buckets)
+        if self.active:
+            assert covered == self.grads.numel(), (covered, self.grads.numel())   # every element exchanged exactly once
+            self.grads.div_(self.world)
+        self.works, self.buckets = [], []
+
+
 def lngknp_backward(model: DeviceModel, state: TrainState, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg,
-                    prefix_lens: Sequence[int]) -> torch.Tensor:
+                    prefix_lens: Sequence[int], exchange: Optional[GradExchange] = None) -> torch.Tensor:
     """Forward + backward of the sum of the margin-MSE losses (``rpr_lngknp_backward``): fills ``state.grads`` and
-    returns the losses ``[n_prefix]`` (device tensor). Asynchronous on the current stream."""
+    returns the losses ``[n_prefix]`` (device tensor). Asynchronous on the current stream. With ``exchange`` the
+    gradient all-reduce of every bucket is enqueued while the backward is still running (``GradExchange``); the caller
+    then calls ``exchange.finish()`` before the optimizer step."""
     ctx = model.ctx
     dev = ctx.device
     ids = input_ids.to(device=dev, dtype=torch.int32).contiguous()
@@ -665,17 +727,24 @@ def lngknp_backward(model: DeviceModel, state: TrainState, input_ids, attention_
     assert tuple(tp.shape) == (n_prefix, bz) and tuple(tn.shape) == (n_prefix, bz)
     pl = torch.tensor(list(prefix_lens), dtype=torch.int32, device=dev)
     losses = torch.empty((n_prefix,), dtype=torch.float32, device=dev)
-    check(ctx.lib.rpr_lngknp_backward(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq, codes.data_ptr(), L,
-                                      tp.data_ptr(), tn.data_ptr(), pl.data_ptr(), n_prefix, losses.data_ptr(),
-                                      state.grads.data_ptr(), _stream_ptr(dev)), "rpr_lngknp_backward")
+    if exchange is not None and exchange.active:
+        check(ctx.lib.rpr_lngknp_backward_buckets(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq,
+                                                  codes.data_ptr(), L, tp.data_ptr(), tn.data_ptr(), pl.data_ptr(), n_prefix,
+                                                  losses.data_ptr(), state.grads.data_ptr(), _stream_ptr(dev),
+                                                  exchange.comm_stream_ptr(), exchange.callback(), None),
+              "rpr_lngknp_backward_buckets")
+    else:
+        check(ctx.lib.rpr_lngknp_backward(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq, codes.data_ptr(), L,
+                                          tp.data_ptr(), tn.data_ptr(), pl.data_ptr(), n_prefix, losses.data_ptr(),
+                                          state.grads.data_ptr(), _stream_ptr(dev)), "rpr_lngknp_backward")
     return losses
 
 
 def allreduce_grads(state: TrainState, bucket_elems: int = 64 << 20) -> None:
-    """Data-parallel gradient exchange (the reference wraps the model in DDP: an NCCL ring all-reduce of ~0.94 GB fp32
-    per step for t5-base): sum ``state.grads`` over the ranks in a few large chunks and divide by the world size
-    (DDP's gradient averaging). RCCL ("nccl" backend) on GPUs; any torch.distributed backend works. The MI355X xGMI
-    mesh is point-to-point, so few large messages are what RCCL's ring needs: 256 MB chunks by default."""
+    """Serial data-parallel gradient exchange (``RPR_GRAD_OVERLAP=0``; the default is :class:`GradExchange`, overlapped
+    with the backward pass): sum ``state.grads`` over the ranks in a few large chunks after the backward and divide by
+    the world size (DDP's gradient averaging). RCCL ("nccl" backend) on GPUs; any torch.distributed backend works. The
+    MI355X xGMI mesh is point-to-point, so few large messages are what RCCL's ring needs: 256 MB chunks by default."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
@@ -684,6 +753,32 @@ def allreduce_grads(state: TrainState, bucket_elems: int = 64 << 20) -> None:
     for s in range(0, g.numel(), bucket_elems):
         dist.all_reduce(g[s:s + bucket_elems], op=dist.ReduceOp.SUM)
     g.div_(world)
+
+
+def allreduce_mode() -> str:
+    import os
+    return "serial" if os.environ.get("RPR_GRAD_OVERLAP", "1") == "0" else "bucketed, overlapped with the backward pass"
+
+
+def train_step(model: DeviceModel, state: TrainState, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg,
+               prefix_lens: Sequence[int], lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+               max_grad_norm: float = 1.0) -> torch.Tensor:
+    """One optimisation step as the reference's trainer performs it (tasks/trainer.py:203-275 + HF Trainer defaults):
+    forward + backward, gradient all-reduce across the data-parallel ranks — bucketed and overlapped with the backward
+    (``RPR_GRAD_OVERLAP=0``: one serial pass afterwards) —, clip_grad_norm_, AdamW. Returns the losses before the update."""
+    import os
+    if os.environ.get("RPR_GRAD_OVERLAP", "1") == "0":
+        losses = lngknp_backward(model, state, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg, prefix_lens)
+        allreduce_grads(state)
+    else:
+        ex = getattr(state, "_exchange", None)
+        if ex is None or ex.grads is not state.grads:
+            ex = state._exchange = GradExchange(state.grads)
+        losses = lngknp_backward(model, state, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg, prefix_lens,
+                                 exchange=ex)
+        ex.finish()
+    adamw_step(model, state, lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+    return losses
 
 
 def adamw_step(model: DeviceModel, state: TrainState, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,

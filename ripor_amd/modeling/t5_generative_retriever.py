@@ -320,13 +320,13 @@ class T5SeqAQEncoderForLngKnpMarginMSE(T5SeqAQEncoder):
         return {n: losses[i] for i, n in enumerate(names)}
 
     def training_step(self, lr, max_grad_norm=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, **inputs):
-        """One optimisation step as the reference's trainer performs it: backward, gradient all-reduce across the
-        data-parallel ranks (RCCL when torch.distributed is initialised), clip_grad_norm_, AdamW — weights updated in
-        place on the device. Returns the task losses of the batch (before the update)."""
+        """One optimisation step as the reference's trainer performs it: backward with the gradient all-reduce across the
+        data-parallel ranks overlapped (RCCL when torch.distributed is initialised; engine.GradExchange), clip_grad_norm_,
+        AdamW — weights updated in place on the device. Returns the task losses of the batch (before the update)."""
         from .. import engine as E
-        losses = self.backward(**inputs)
-        st = self.train_state()
-        E.allreduce_grads(st)
-        E.adamw_step(self.base_model.engine_model(), st, lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                     max_grad_norm=max_grad_norm)
+        pos_q, codes, tp, tn, prefix_lens, names = self._batch(inputs)
+        losses = E.train_step(self.base_model.engine_model(), self.train_state(), pos_q["input_ids"], pos_q["attention_mask"],
+                              codes, tp, tn, prefix_lens, lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                              max_grad_norm=max_grad_norm)
+        losses = {n: losses[i] for i, n in enumerate(names)}
         return losses

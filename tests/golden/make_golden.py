@@ -392,6 +392,10 @@ CASES = {
     # BeamSearchScorer refuses num_beams <= 1, so the restated scorer is allowed a single beam
     # here; everything else (model forward, processor, beam loop) is the imported reference.
     "g4_base_b1_l32_q64": dict(kind="base", N=1000, Q=64, B=1, L=32, V=256, seed=401, single_beam=True),
+    # BASELINE config 4 at the REAL t5-large dimensions (d_model 1024, d_ff 4096, 24 + 24 layers, 16 heads; the g3
+    # fixtures shrink d_ff and the encoder): beam 100, short smtids so that the reference's full-prefix recompute stays
+    # within minutes on the build container's 8 cores. Pins the K = 4096 FF path inside a 24-layer decoder end to end.
+    "g5_largefull_b100_l8": dict(kind="large_full", N=3000, Q=2, B=100, L=8, V=256, seed=501),
 }
 
 # SURVEY §8 row f4 (BASELINE config 5): T5SeqAQEncoderForLngKnpMarginMSE.forward on a seeded batch
@@ -414,11 +418,13 @@ def make_case(name, spec, gen, mod, utils, shim):
     elif kind == "large":
         dims = synth.ModelDims(vocab_size=512, d_model=1024, d_kv=64, d_ff=512, num_layers=1, num_decoder_layers=24,
                                num_heads=16, decoder_vocab_sizes=[V] * L, shared_output_input_embeds=shared)
+    elif kind == "large_full":
+        dims = synth.t5_large_dims(L=L, V=V, vocab_size=2048, shared_output_input_embeds=shared)
     else:
         raise ValueError(kind)
     t0 = time.time()
     sd = synth.make_state_dict(dims, seed=seed)
-    model = build_reference_model(mod, dims, sd, which="t5-large" if kind == "large" else "t5-base")
+    model = build_reference_model(mod, dims, sd, which="t5-large" if kind.startswith("large") else "t5-base")
     codes = synth.make_codes(N, L, V, seed=seed)
     d2s, lst = reference_trie(gen, codes)
     processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)

@@ -209,3 +209,51 @@ def test_gradient_allreduce_averages_over_ranks():
         assert p.exitcode == 0
     expect = ((torch.arange(1000, dtype=torch.float32) + 1.0) * 1.5).tolist()    # mean of x and 2x
     assert got == expect
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ripor_amd import engine as E
+        n = 1000
+        grads = (torch.arange(n, dtype=torch.float32) + 1.0) * (rank + 1)
+        ex = E.GradExchange(grads)
+        assert ex.active and ex.world == 2 and ex.stream is None    # CPU tensors: no communication stream
+        # the order rpr_lngknp_backward_buckets hands the buckets over: layers last to first, then the front of the buffer
+        for off, cnt in [(700, 300), (400, 300), (250, 150), (0, 250)]:
+            ex.on_bucket(off, cnt)
+        ex.finish()
+        if rank == 0:
+            out.put(grads.tolist())
+        # a bucket list that does not cover the buffer must be refused (an element would stay un-reduced)
+        ex.on_bucket(0, 10)
+        try:
+            ex.finish()
+            ok = False
+        except AssertionError:
+            ok = True
+        if rank == 0:
+            out.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_averages_over_ranks():
+    """engine.GradExchange (the overlapped exchange of the training step: one asynchronous all-reduce per bucket as the
+    backward hands it over, DDP's averaging at the end) on two gloo ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    refused = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == ((torch.arange(1000, dtype=torch.float32) + 1.0) * 1.5).tolist()
+    assert refused

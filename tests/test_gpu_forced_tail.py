@@ -61,11 +61,12 @@ def test_dense_trie_most_queries_forced_some_not(E):
     through the second stage; both populations must reproduce the plain loop, and the oracle."""
     from oracle import beam_ref, t5_ref
     from ripor_amd.utils import synth
-    L, V, B, N = 8, 256, 10, 60_000
+    L, V, B, N = 12, 256, 10, 60_000      # automatic forks need >= 8 positions left after the first one
     codes = synth.make_codes(N, L, V, seed=11)
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=48)
     depths = ctx.fork_depths(model, trie, ids.shape[0], B, L)
     assert len(depths) >= 1 and depths[0] in (2, 3, 4), depths
+    assert ctx.fork_depths(model, trie, ids.shape[0], B, 8) == [], "a tail of fewer than 8 positions is not worth a fork"
     res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "dense 60k")
     assert stats[0]["forced"] + stats[0]["left"] == ids.shape[0]
     assert stats[0]["forced"] > 0, "the fork took no query: the test does not exercise the tail pass"
@@ -101,8 +102,12 @@ def test_duplicated_smtids_are_single_sequences(E):
     perm = synth.randint("dupperm", (codes.shape[0],), 0, 1 << 30, seed=21).argsort(kind="stable")
     codes = codes[perm]
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V)
-    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "duplicated smtids")
-    assert stats and stats[0]["forced"] > 0
+    ctx.set_fork_depths([2, 3])
+    try:
+        res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "duplicated smtids")
+    finally:
+        ctx.set_fork_depths(None)
+    assert stats and stats[0]["forced"] + stats[1]["forced"] > 0
     n = (res.row_hi - res.row_lo).cpu().numpy()
     assert n.max() > 1 and n.min() >= 1, "ranges of duplicated smtids must hold all their docs"
 
@@ -121,8 +126,12 @@ def test_prefix_search_shorter_than_the_trie(E):
         ctx.set_fork_depths(None)
     res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=3 of 8, automatic")
     L = 5
-    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=5 of 8, automatic")
-    assert stats and stats[0]["forced"] > 0, stats
+    ctx.set_fork_depths([2, 3])
+    try:
+        res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "prefix search L=5 of 8, forks [2, 3]")
+    finally:
+        ctx.set_fork_depths(None)
+    assert stats and stats[0]["forced"] + stats[1]["forced"] > 0, stats
 
 
 def test_skewed_codes_and_beam_one(E):
@@ -130,8 +139,12 @@ def test_skewed_codes_and_beam_one(E):
     L, V = 8, 256
     codes = synth.make_codes(40_000, L, V, seed=41, skew=True)
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=32)
-    for B in (1, 4, 10):
-        _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"skewed 40k beam {B}")
+    ctx.set_fork_depths([3, 4])
+    try:
+        for B in (1, 4, 10):
+            _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"skewed 40k beam {B} forks [3, 4]")
+    finally:
+        ctx.set_fork_depths(None)
     ctx.set_fork_depths([2, 4])
     try:
         _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, 10, L, "skewed 40k forks [2,4]")
@@ -145,6 +158,7 @@ def test_exact_fp32_mode_and_lane_split(E):
     L, V, B = 8, 256, 10
     codes = synth.make_codes(50_000, L, V, seed=51)
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=40)
+    ctx.set_fork_depths([3, 4])
     ctx.set_precision("f32")
     try:
         _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "exact fp32")
@@ -158,6 +172,7 @@ def test_exact_fp32_mode_and_lane_split(E):
             assert sum(s["forced"] + s["left"] for s in stats[:1]) == ids.shape[0]
     finally:
         ctx.set_lane_split(saved)
+        ctx.set_fork_depths(None)
 
 
 def test_large_beam_forced_tail(E):
@@ -166,8 +181,13 @@ def test_large_beam_forced_tail(E):
     L, V = 6, 256
     codes = synth.make_codes(200_000, L, V, seed=61)
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=6)
-    for B in (100, 300):
-        _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"200k docs beam {B}")
+    ctx.set_fork_depths([3, 4])
+    try:
+        for B in (100, 300):
+            _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"200k docs beam {B} forks [3, 4]")
+            assert st[0]["forced"] + st[1]["forced"] > 0
+    finally:
+        ctx.set_fork_depths(None)
     ctx.set_fork_depths([3])
     try:
         _, _, st = _same_as_plain(ctx, E, model, trie, ids, mask, 100, L, "200k docs beam 100 fork [3]")
@@ -178,7 +198,7 @@ def test_large_beam_forced_tail(E):
 
 def test_log_softmax_and_taps_never_fork(E):
     from ripor_amd.utils import synth
-    L, V, B = 8, 256, 4
+    L, V, B = 12, 256, 4
     codes = synth.make_codes(50_000, L, V, seed=71)
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=8)
     assert ctx.fork_depths(model, trie, 8, B, L) != []

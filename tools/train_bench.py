@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bz", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--len", type=int, default=32, dest="L")
-ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"])
+ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32", "bf16"])
 args = ap.parse_args()
 L, V, bz = args.L, 256, args.bz
 dims = synth.t5_base_dims(L=L, V=V)
@@ -39,11 +39,8 @@ tn = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/n{k}", (bz,), 30.0) for k
 ids_t, mask_t, codes_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(codes).cuda()
 
 
-def step():
-    losses = E.lngknp_backward(model, state, ids_t, mask_t, codes_t, tp, tn, prefix)
-    E.allreduce_grads(state)
-    E.adamw_step(model, state, lr=1e-6)
-    return losses
+def step():   # backward with the bucketed gradient exchange overlapped (RPR_GRAD_OVERLAP=0: serial), clip, AdamW
+    return E.train_step(model, state, ids_t, mask_t, codes_t, tp, tn, prefix, lr=1e-6)
 
 
 first = step(); torch.cuda.synchronize()
