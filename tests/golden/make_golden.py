@@ -404,7 +404,9 @@ TRAIN_CASES = {
     "f4_mini_bz6_l32": dict(kind="mini", bz=6, L=32, V=256, seed=501),
     "f4_mini_bz4_l16": dict(kind="mini", bz=4, L=16, V=256, seed=502),
     "f4_mini_bz4_l8": dict(kind="mini", bz=4, L=8, V=256, seed=503),
-    "f4_base_bz4_l32": dict(kind="base", bz=4, L=32, V=256, seed=504),
+    # t5-base dims WITH the reference's gradients (sampled entries + norms): pins the backward at full dims to the reference
+    # directly, not through the oracle's autograd
+    "f4_base_bz4_l32": dict(kind="base", bz=4, L=32, V=256, seed=504, backward=True),
 }
 
 

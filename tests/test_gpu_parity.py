@@ -16,7 +16,8 @@ import torch
 from conftest import ORDER_TOL, compare_ranked, golden_names
 
 SCORE_TOL = 1e-4     # north_star: beam scores within 1e-4
-LOGIT_TOL = 2e-3     # fp32 logits O(10..100) through 12-24 layers; reference-vs-KV-cached differs by ~3e-5
+LOGIT_TOL = 5e-4     # fp32 logits O(10..100) through 12-24 layers; reference-vs-KV-cached differs by ~3e-5, the
+                     # split-precision GEMMs by <= ~1e-4 from exact fp32 (tools/precision_probe.py)
 
 pytestmark = pytest.mark.gpu
 
@@ -223,19 +224,26 @@ def test_encoder_and_step_logits_match_oracle(engine, golden_cache, name):
     seqs, sc = beam_ref.beam_search_ref(t5_ref.T5Ref(g.state_dict, g.dims), pm, g.input_ids, g.attention_mask,
                                         g.B, g.L, g.log_softmax, record=rec)
     assert (seqs.numpy() == g.sequences).all()  # the oracle itself is pinned to the reference
-    tok = res.tokens.cpu().numpy()
-    if (tok == g.sequences.reshape(g.Q, g.B, g.L + 1)[:, :, 1:]).all():
-        lg = res.taps["step_logits"].cpu().numpy()
-        for t in range(g.L):
-            ref = rec["steps"][t]["logits"]
-            if t == 0:
-                np.testing.assert_allclose(lg[t], ref, atol=LOGIT_TOL, rtol=1e-4)
-            else:
-                # beams of step t are in the same slot order iff the selections matched so far
-                sel_tok = res.taps["step_tokens"][t - 1].cpu().numpy().reshape(-1)
-                ref_tok = rec["steps"][t - 1]["top_tok"][:, : g.B].reshape(-1)
-                if (sel_tok == ref_tok).all():
-                    np.testing.assert_allclose(lg[t], ref, atol=LOGIT_TOL, rtol=1e-4)
+    # step 0 unconditionally; step t > 0 whenever the beams are still in the reference's slot order, i.e. every selection
+    # so far matched the reference's (a near-tie may permute slots: the rows of later steps then belong to other beams)
+    lg = res.taps["step_logits"].cpu().numpy()
+    checked = 0
+    in_order = True
+    for t in range(g.L):
+        if t > 0:
+            sel_tok = res.taps["step_tokens"][t - 1].cpu().numpy().reshape(-1)
+            sel_par = res.taps["step_parent"][t - 1].cpu().numpy().reshape(-1)
+            ref_tok = rec["steps"][t - 1]["top_tok"][:, : g.B].reshape(-1)
+            ref_par = rec["steps"][t - 1]["top_beam"][:, : g.B].reshape(-1) if "top_beam" in rec["steps"][t - 1] else sel_par
+            in_order = in_order and bool((sel_tok == ref_tok).all()) and bool((sel_par == ref_par).all())
+        if not in_order:
+            break
+        ref = rec["steps"][t]["logits"]
+        live = np.isfinite(ref) & (np.abs(ref) < 1e8)
+        np.testing.assert_allclose(lg[t][live], ref[live], atol=LOGIT_TOL, rtol=1e-5)
+        checked += 1
+    assert checked >= 1 and (checked >= g.L // 2 or "tiny_trie" in name), (name, checked)
+    print(f"[logits] {name}: {checked} of {g.L} steps compared with the oracle's logits at {LOGIT_TOL}")
 
 
 def test_trie_mask_matches_reference_processor(engine, golden_cache):

@@ -10,15 +10,19 @@ B="python $GRAFT_REPO_ROOT/bench.py $*"
 # 1. plain bench (with cpu_baseline)
 timeout 600 $B > $OUT/bench.json 2> $OUT/bench.log
 # 2. same command under rocprofv3 --kernel-trace --stats
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --no-cpu-baseline --no-exact-fp32 > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B --no-cpu-baseline --no-exact-fp32 --secondary "" > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 # 3. HBM traffic counters, separate passes (TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 > 4), kernel-trace only
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 > /dev/null 2> $OUT/pmc_fetch.log
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 > /dev/null 2> $OUT/pmc_write.log
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 --secondary "" > /dev/null 2> $OUT/pmc_fetch.log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 --secondary "" > /dev/null 2> $OUT/pmc_write.log
 # 4. matrix-pipe utilisation and effective clock: SQ_VALU_MFMA_BUSY_CYCLES (cycles, = 32 per 32x32x16 f16 MFMA) and
 #    GRBM_GUI_ACTIVE (shader-clock cycles the GPU was busy; / kernel duration = effective clock under DVFS)
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 > /dev/null 2> $OUT/pmc_mfma.log
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o p -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-exact-fp32 --secondary "" > /dev/null 2> $OUT/pmc_mfma.log
 python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $OUT/trace/bench_results.db $OUT/kernel_stats.csv
-python $GRAFT_REPO_ROOT/tools/gemm_sites.py $OUT/trace/bench_results.db $OUT/gemm_sites.json | tee $OUT/gemm_sites.txt
+python $GRAFT_REPO_ROOT/tools/trace_dump.py $OUT/trace/bench_results.db --json $OUT/trace_summary.json | tee $OUT/trace_summary.txt | head -30
+# per-site times of the tail-pass GEMMs on whole-chip launches (one more traced run without lanes)
+timeout 600 rocprofv3 --kernel-trace -d $OUT/trace_nolanes -o bench -- $B --no-lanes --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-roofline --secondary "" > $OUT/bench_nolanes_under_rocprof.json 2> $OUT/trace_nolanes.log
+python $GRAFT_REPO_ROOT/tools/tail_sites.py $OUT/trace_nolanes/bench_results.db $((2176 * 10 * 28)) $OUT/tail_gemm_sites.json | tee $OUT/tail_gemm_sites.txt
+rm -rf $OUT/trace_nolanes
 python - <<PY
 import csv, collections, json
 out = {}
