@@ -112,6 +112,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.sat = L.c->status;
     g.cus = L.c->cur_cus;
     g.small_live = m_dev ? L.c->cur_small_live : 0;
+    g.xcd_sync = L.c->status + 16 + 8 * (L.c->cur_lane + 1);   // 8 words per stream (ctx, lane 0, lane 1) behind the flags
     g.part = P<float>(L.c->ws.part); g.part_cap = L.c->ws.part.cap / sizeof(float); g.mid_split = 1;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
@@ -747,8 +748,8 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   }
   std::memset(c->done, 0, sizeof(c->done));
   hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), 64);
-  if (e == hipSuccess) e = hipMemset(c->status, 0, 64);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), 256);
+  if (e == hipSuccess) e = hipMemset(c->status, 0, 256);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 64, hipHostMallocDefault);
   if (e != hipSuccess) {
     if (c->status) (void)hipFree(c->status);
@@ -1186,8 +1187,8 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
                int64_t* out_row_hi, const rpr_debug_taps* taps, hipStream_t s, int lane) {
   struct WsGuard {
     rpr_ctx* c; int lane;
-    WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = c->lane_cus; } }
-    ~WsGuard() { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = 0; } }
+    WsGuard(rpr_ctx* c_, int l) : c(c_), lane(l) { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = c->lane_cus; c->cur_lane = lane; } }
+    ~WsGuard() { if (lane >= 0) { std::swap(c->ws, c->lanes[lane].ws); c->cur_cus = 0; c->cur_lane = -1; } }
   } ws_guard(c, lane);
   // a model whose weights do not fit the f16 planes runs on the exact-fp32 kernels whatever the ctx setting
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};

@@ -464,7 +464,19 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   // chunk size and every block handles exactly one tile)
   const int xq = nt >> 3, xr = nt & 7, xcd = blockIdx.x & 7, xk = blockIdx.x >> 3, xstep = ((int)gridDim.x - xcd + 7) >> 3;
   const int chunk0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, chunk_n = xcd < xr ? xq + 1 : xq;
-  for (int ti = xk; ti < chunk_n; ti += xstep) {
+  int round = 0;
+  for (int ti = xk; ti < chunk_n; ti += xstep, ++round) {
+  if (g.xcd_sync && round > 0) {   // wait (bounded) until every block of this XCD has finished its previous tile
+    if (tid == 0) {
+      __hip_atomic_fetch_add(g.xcd_sync + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int want = (unsigned int)(round * xstep);
+      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + 3000ull;   // 30 us at 100 MHz
+      while (__hip_atomic_load(g.xcd_sync + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+             __builtin_amdgcn_s_memrealtime() < until)
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
   const int bid = chunk0 + ti;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int bm = tm * BM, bn = tn * BN;
@@ -791,6 +803,8 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void zero_u32x8_kernel(unsigned int* p) { if (threadIdx.x < 8) p[threadIdx.x] = 0u; }
+
 // 256x256 tile, 8 waves (2x4) of 128x64, ping-pong schedule: half the staged bytes per MFMA of the 128x128 tile;
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
@@ -805,6 +819,13 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   // skew only pays when a block walks several tiles (the late blocks idle for up to 3/4 of a tile time once per launch)
   const int skew_ticks = (grid < nt && nt >= 4 * cus) ? (int)((long)skew * a.K / 768) : 0;
   const dim3 gr(grid), bl(512);
+  GemmH2Args ab = a;
+  static const int xsync = [] { const char* e = getenv("RPR_GEMM_XCD_SYNC"); return e ? atoi(e) : 0; }();
+  if (!(xsync && a.xcd_sync && grid < nt && nt >= 2 * cus)) ab.xcd_sync = nullptr;
+  if (ab.xcd_sync) {
+    hipLaunchKernelGGL(zero_u32x8_kernel, dim3(1), dim3(64), 0, s, ab.xcd_sync);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+  }
   if (a.bf16) {
     if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
     else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
@@ -813,9 +834,9 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   if (full && a.trace)
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
   else if (full)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n, skew_ticks);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
   else
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n, skew_ticks);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
   return hipGetLastError();
 }
 

@@ -141,7 +141,7 @@ struct Lane {
 struct rpr_ctx {
   int device;
   int precision = RPR_PREC_F16X2;
-  unsigned int* status = nullptr;       // [dev] sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing, [2] a query was left unforced by the last fork of an optimistic forced-tail search
+  unsigned int* status = nullptr;       // [dev, 64 words] [8] weight-range probe, [16..39] XCD round barriers of the persistent GEMM (8 per stream); sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing, [2] a query was left unforced by the last fork of an optimistic forced-tail search
   unsigned int* status_host = nullptr;  // pinned mirror filled by rpr_get_status
   struct TrainWs* tws = nullptr;        // activations / scratch of the training step (train_api.hip), freed by free_train_ws
   unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
@@ -152,6 +152,7 @@ struct rpr_ctx {
   hipEvent_t fork_ev = nullptr;
   int cur_cus = 0;              // CUs of the lane the current enqueue runs on (0 = the whole chip)
   int lane_cus = 0;             // CUs per lane
+  int cur_lane = -1;            // lane of the current enqueue (-1 = the ctx stream)
   int cur_small_live = 0;       // > 0 while a leftover stage is enqueued: its GEMMs are paired (GemmH2Args.small_live)
   int forced_tail = 1;          // 0 = every query runs all L steps sequentially, 1 = exact forced tail, 2 = optimistic (see choose_forks)
   int fork_override[MAX_FORKS] = {0, 0};   // explicit fork depths (rpr_set_fork_depths / RPR_FORK_DEPTHS); 0 = from the trie statistics
