@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -37,10 +38,22 @@ int main(int argc, char** argv) {
   std::vector<_Float16> h(n);
   _Float16* d; float* o;
   hipMalloc(&d, n * 2); hipMalloc(&o, (size_t)blocks * threads * 4);
-  for (int mode = 0; mode < 3; ++mode) {   // 0 zeros, 1 random in [-1, 1), 2 random small (lo-plane-like, ~2^-11)
+  // 0 zeros, 1 random in [-1, 1), 2 random small (lo-plane-like, ~2^-11); 3.. : random with the low mantissa bits of
+  // the B operands (modes 3-5: 3 / 6 / 9 bits) or of both operands (6: 5 bits each) cleared, 7: B = 0 — how much of the
+  // power wall is operand toggling that a coarser lo plane could avoid?
+  const char* names[8] = {"zeros", "random", "random small", "B low 3 bits clear", "B low 6 bits clear", "B low 9 bits clear",
+                          "A and B low 5 bits clear", "B zeros"};
+  for (int mode = 0; mode < 8; ++mode) {
     for (size_t i = 0; i < n; ++i) {
       const float u = (float)rand() / RAND_MAX * 2.f - 1.f;
-      h[i] = (_Float16)(mode == 0 ? 0.f : mode == 1 ? u : u * 4.8e-4f);
+      _Float16 v = (_Float16)(mode == 0 ? 0.f : mode == 2 ? u * 4.8e-4f : u);
+      const bool is_b = ((i / 8) % 8) >= 4;          // per thread: 4 A vectors of 8 halves, then 4 B vectors
+      unsigned short bits; memcpy(&bits, &v, 2);
+      if (mode >= 3 && mode <= 5 && is_b) bits &= (unsigned short)~((1u << (3 * (mode - 2))) - 1u);
+      if (mode == 6) bits &= (unsigned short)~31u;
+      if (mode == 7 && is_b) bits = 0;
+      memcpy(&v, &bits, 2);
+      h[i] = v;
     }
     hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
     for (int waves = 0; waves < 2; ++waves) {
@@ -53,8 +66,7 @@ int main(int argc, char** argv) {
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double flops = (double)blocks * (th / 64) * iters * 8 * 2.0 * 32 * 32 * 16;
-      printf("mode %d (%s) %d waves/SIMD: %.1f ms  %.0f TF/s f16 MFMA\n", mode, mode == 0 ? "zeros" : mode == 1 ? "random" : "random small",
-             th / 256, ms, flops / (ms * 1e-3) / 1e12);
+      printf("mode %d (%s) %d waves/SIMD: %.1f ms  %.0f TF/s f16 MFMA\n", mode, names[mode], th / 256, ms, flops / (ms * 1e-3) / 1e12);
     }
   }
   return 0;
