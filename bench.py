@@ -348,7 +348,9 @@ def main():
         else:
             print(json.dumps({"n_gpus": 1, "rccl_world_size": 1, "ranks_seen": [0]}), flush=True)
         return
-    dev = torch.device("cuda", local_rank)
+    # RPR_BENCH_DEVICE: test hook (tests/test_gpu_cli.py runs two gloo ranks on the one GPU of the test box to exercise the
+    # N > 1 code path end to end: sharding, the result gather, the bucketed gradient exchange of the train leg)
+    dev = torch.device("cuda", int(os.environ.get("RPR_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
 
     from ripor_amd import engine as E
@@ -360,7 +362,7 @@ def main():
     V = dims.decoder_vocab_sizes[0]
     t0 = time.time()
     sd = synth.make_state_dict(dims)
-    ctx = E.Context.get(local_rank)
+    ctx = E.Context.get(dev.index)
     ctx.set_precision(args.precision)
     # forced-tail evaluation: 2 = optimistic (no stage after the last fork; a query left unforced there raises the
     # sticky TAIL_LEFTOVER word, checked after the timed region — the number is then void and the run is repeated in

@@ -663,14 +663,18 @@ class GradExchange:
     ring on the point-to-point xGMI mesh wants; any torch.distributed backend works (the CPU tests use gloo).
     With one rank (or no process group) nothing is enqueued."""
 
-    def __init__(self, grads: torch.Tensor):
+    def __init__(self, grads: torch.Tensor, dry_run: bool = False):
+        """``dry_run`` (tests, one rank): take the buckets and touch each slice on the communication stream instead of
+        all-reducing it — the hand-off (callback order, stream dependencies, coverage) without a process group."""
         import torch.distributed as dist
         self.grads = grads
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = dist.get_world_size() if self.active else 1
+        self.dry_run = bool(dry_run)
+        self.active = self.dry_run or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.world = dist.get_world_size() if (self.active and not self.dry_run) else 1
         self.stream = torch.cuda.Stream(grads.device) if (self.active and grads.is_cuda) else None
         self.works: List = []
         self.buckets: List[tuple] = []
+        self.history: List[tuple] = []       # buckets of the last finished exchange, in hand-over order
         self._cb = _lib.GRAD_BUCKET_CB(self._on_bucket_c)
 
     def _on_bucket_c(self, _user, offset, numel):
@@ -682,6 +686,11 @@ class GradExchange:
         if not self.active or numel <= 0:
             return
         sl = self.grads[offset:offset + numel]
+        if self.dry_run:
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    sl.mul_(1.0)          # reads and rewrites the bucket on the communication stream
+            return
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
@@ -703,7 +712,9 @@ class GradExchange:
         covered = sum(n for _, n in self.buckets)
         if self.active:
             assert covered == self.grads.numel(), (covered, self.grads.numel())   # every element exchanged exactly once
-            self.grads.div_(self.world)
+            if self.world > 1:
+                self.grads.div_(self.world)
+        self.history = list(self.buckets)
         self.works, self.buckets = [], []
 
 

@@ -111,3 +111,31 @@ def test_shell_pipeline_end_to_end(tmp_path):
             assert set(got) == set(expect)
             for d in expect:
                 assert abs(got[d] - expect[d]) < 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu_through_gloo():
+    """The N > 1 path of bench.py end to end on the one GPU of the test box: two ranks (gloo instead of RCCL, both on
+    cuda:0 through the RPR_BENCH_DEVICE test hook) shard the query pool and gather the ranked results. (The training
+    leg's bucketed gradient exchange: tests/test_gpu_train.py::test_gradient_buckets_are_handed_over_during_the_backward for
+    the device-side hand-off, tests/test_dist_gloo.py for the collective; a gloo all-reduce of 0.94 GB of device memory
+    takes 30 s per step, too slow for this suite. RCCL itself cannot be exercised on a one-GPU box.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RPR_BENCH_BACKEND="gloo", RPR_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "64", "--docs", "200000", "--no-roofline", "--no-cpu-baseline", "--no-exact-fp32", "--secondary", ""]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["gather_bytes_per_rank"] > 0
+    assert d["value"] > 0 and d["config"]["queries_per_step_per_gpu"] == 64
+    print("[bench x2 gloo]", d["value"], d["forced_tail"])

@@ -422,3 +422,40 @@ def test_bf16_training_step_lowers_the_loss_like_the_fp32_step():
         assert after["bf16"][k] < g.losses[k], "the bf16 step did not lower the loss"
         assert abs(after["bf16"][k] - v) <= 0.1 * abs(g.losses[k] - v) + 5e-3 * abs(v), (k, after["bf16"][k], after["f16x2"][k], v)
     print(f"[train-bf16] losses after one step: bf16 {after['bf16']}, f16x2 {after['f16x2']}, reference {g.z['losses_after_step'].tolist()}")
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_gradient_buckets_are_handed_over_during_the_backward(precision):
+    """rpr_lngknp_backward_buckets (the overlapped gradient exchange): the buckets arrive in the order the
+    backward finishes the layers — decoder layers last to first, encoder layers last to first, then everything in front
+    of the first layer —, cover the flat buffer exactly once, each is a whole layer, and consuming them on the
+    communication stream (dry run: every slice is read and rewritten there) leaves the gradients of the plain backward
+    bit for bit: the stream dependencies the library sets up are sufficient."""
+    from ripor_amd import engine as E
+    g = TrainGolden("f4_mini_bz6_l32")
+    ctx = E.Context.get(0)
+    m = _train_model(g)
+    em, st = m.base_model.engine_model(), m.train_state()
+    pos_q, codes, tp, tn, prefix_lens, names = m._batch(_inputs(g))
+    ctx.set_precision(precision)
+    try:
+        E.lngknp_backward(em, st, pos_q["input_ids"], pos_q["attention_mask"], codes, tp, tn, prefix_lens)
+        torch.cuda.synchronize()
+        plain = st.grads.clone()
+        ex = E.GradExchange(st.grads, dry_run=True)
+        st.grads.fill_(float("nan"))
+        E.lngknp_backward(em, st, pos_q["input_ids"], pos_q["attention_mask"], codes, tp, tn, prefix_lens, exchange=ex)
+        ex.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(st.grads, plain)
+    finally:
+        ctx.set_precision("f16x2")
+    nd, ne = g.dims.num_decoder_layers, g.dims.num_layers
+    hist = ex.history
+    assert len(hist) == nd + ne + 1
+    offs = [o for o, _ in hist]
+    assert offs[:nd] == sorted(offs[:nd], reverse=True) and offs[nd:nd + ne] == sorted(offs[nd:nd + ne], reverse=True)
+    assert min(offs[:nd]) > max(offs[nd:nd + ne]) > 0 and hist[-1][0] == 0
+    assert len({n for _, n in hist[:nd]}) == 1 and len({n for _, n in hist[nd:nd + ne]}) == 1   # whole layers
+    spans = sorted((o, o + n) for o, n in hist)
+    assert spans[0][0] == 0 and spans[-1][1] == st.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
