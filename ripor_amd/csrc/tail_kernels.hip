@@ -343,41 +343,59 @@ __device__ __forceinline__ void mfma_pv(const f32x16 (&p)[NKT], const float* Vs,
     }
 }
 
-// rows i0 + (r & 3) + 8 (r >> 2) + 4 half of the tile -> out / out_h at row_base + row, columns head*64 + {d, d + 32}
-__device__ __forceinline__ void store_o_tile(const f32x16 (&o)[2], int lane, int i0, int nrows, size_t row_base, int inner, int hcol,
-                                             float* out, __half* out_h, size_t o_ps, unsigned int* sat) {
+// The 32 x 64 output tile (MFMA result layout: a lane holds one column and 16 scattered rows per 32-column half) goes
+// through the wave's LDS strip (the V rows are consumed by then) and leaves row-wise: a lane takes 8 consecutive columns
+// of a row = one 16-byte store per f16 plane (or two float4). Storing straight from the MFMA layout was 64 two-byte
+// stores per lane and tile.
+__device__ __forceinline__ void store_o_tile(const f32x16 (&o)[2], float* strip, int lane, int i0, int nrows, size_t row_base, int inner,
+                                             int hcol, float* out, __half* out_h, size_t o_ps, unsigned int* sat) {
   const int d = lane & 31, half = lane >> 5;
+  __builtin_amdgcn_wave_barrier();                       // every P.V read of the strip has been issued
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (i >= nrows) continue;
-    const size_t oidx = (row_base + i) * inner + hcol + d;
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+    strip[i * 64 + d] = o[0][r];
+    strip[i * 64 + 32 + d] = o[1][r];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = (lane & 7) * 8;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float v = o[t][r];
-      if (out_h) {
-        __half hi, lo;
-        split_f16(v * A_PLANE_SCALE, hi, lo, sat);
-        out_h[oidx + 32 * t] = hi;
-        out_h[o_ps + oidx + 32 * t] = lo;
-      } else {
-        out[oidx + 32 * t] = v;
-      }
+  for (int k = 0; k < 4; ++k) {
+    const int il = k * 8 + (lane >> 3), i = i0 + il;     // 8 rows per pass, 8 lanes per row
+    if (i >= nrows) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(strip + il * 64 + c8);
+    const float4 v1 = *reinterpret_cast<const float4*>(strip + il * 64 + c8 + 4);
+    const size_t oidx = (row_base + i) * inner + hcol + c8;
+    if (out_h) {
+      __half h[8], l[8];
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split_f16(x[e] * A_PLANE_SCALE, h[e], l[e], sat);
+      *reinterpret_cast<uint4*>(out_h + oidx) = *reinterpret_cast<uint4*>(h);
+      *reinterpret_cast<uint4*>(out_h + o_ps + oidx) = *reinterpret_cast<uint4*>(l);
+    } else {
+      *reinterpret_cast<float4*>(out + oidx) = v0;
+      *reinterpret_cast<float4*>(out + oidx + 4) = v1;
     }
   }
+  __builtin_amdgcn_wave_barrier();                       // the strip is rewritten by the next row tile's V / O
 }
 
 // Tail self-attention on the fp32 matrix cores: one wave per (sequence, head), NKT = ceil(L / 32) key tiles.
-template <int NKT>
-__global__ __launch_bounds__(256) void tail_self_attn_mfma_kernel(TailSelfAttnArgs a) {
+template <int NKT, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_kernel(TailSelfAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
   const int w = blockIdx.x * 4 + wave;
   const int seq = w / H, h = w - seq * H;
   if (seq >= *a.nseq_dev) return;                       // wave-uniform
-  float* Vs = smem + (size_t)wave * (NKT * 32 * 64 + 64);
+  // per wave: V rows [32 NKT][64], the bias table [64] and — only when a sequence has more than one tile of 32 tail rows
+  // (NKT == 2), where V must survive the first tile's output — a separate 32 x 64 output strip
+  constexpr int WAVE_FLOATS = NKT * 32 * 64 + 64 + (NKT > 1 ? 32 * 64 : 0);
+  float* Vs = smem + (size_t)wave * WAVE_FLOATS;
   float* Bs = Vs + NKT * 32 * 64;
+  float* Os = NKT > 1 ? Bs + 64 : Vs;
   const int fi = seq / a.B, b = seq - fi * a.B;
   const int qi = a.flist[fi];
   const uint16_t* ancr = a.anc + ((size_t)qi * a.B + b) * a.anc_ld;
@@ -432,14 +450,14 @@ __global__ __launch_bounds__(256) void tail_self_attn_mfma_kernel(TailSelfAttnAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     mfma_pv<NKT>(s, Vs, lane, o);
-    store_o_tile(o, lane, i0, Lt, (size_t)seq * Lt, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
+    store_o_tile(o, Os, lane, i0, Lt, (size_t)seq * Lt, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
   }
 }
 
 // Cross-attention of the tail rows on the fp32 matrix cores: one wave per (query, head, tile of 32 of the query's
 // rows); keys = the query's own encoder rows (<= 32 * NKT, padding keys masked), no position bias.
 template <int NKT>
-__global__ __launch_bounds__(256) void tail_cross_attn_mfma_kernel(DecCrossAttnArgs a, int tiles) {
+__global__ __launch_bounds__(256, 4) void tail_cross_attn_mfma_kernel(DecCrossAttnArgs a, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, inner = H * DKV, nrows = a.B;       // a.B = rows of one query (beams x tail positions)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(256) void tail_cross_attn_mfma_kernel(DecCrossAttnA
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   mfma_pv<NKT>(s, Vs, lane, o);
-  store_o_tile(o, lane, i0, nrows, row_base, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
+  store_o_tile(o, Vs, lane, i0, nrows, row_base, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
 }
 
 hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
@@ -517,8 +535,10 @@ hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
   if (!off) {
     const long waves = (long)a.nseq_cap * a.H;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-    if (a.L <= 32) hipLaunchKernelGGL(tail_self_attn_mfma_kernel<1>, grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
-    else hipLaunchKernelGGL(tail_self_attn_mfma_kernel<2>, grid, blk, 4 * (64 * 64 + 64) * sizeof(float), s, a);
+    static const int occ = [] { const char* e = getenv("RPR_TAIL_ATTN_OCC"); return e ? atoi(e) : 2; }();
+    if (a.L <= 32 && occ == 3) hipLaunchKernelGGL((tail_self_attn_mfma_kernel<1, 3>), grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
+    else if (a.L <= 32) hipLaunchKernelGGL(tail_self_attn_mfma_kernel<1>, grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
+    else hipLaunchKernelGGL(tail_self_attn_mfma_kernel<2>, grid, blk, 4 * (64 * 64 + 64 + 32 * 64) * sizeof(float), s, a);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(tail_self_attn_kernel, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L), s, a);
@@ -668,7 +688,7 @@ hipError_t init_tail_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_cross_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return e;
