@@ -744,7 +744,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
   }
   if (getenv("RPR_GEMM_TRACE")) {
     void* p = nullptr;
-    if (hipMalloc(&p, 1 << 20) == hipSuccess) { (void)hipMemset(p, 0, 1 << 20); c->trace_buf = (unsigned long long*)p; }
+    if (hipMalloc(&p, 2 << 20) == hipSuccess) { (void)hipMemset(p, 0, 2 << 20); c->trace_buf = (unsigned long long*)p; }
   }
   std::memset(c->done, 0, sizeof(c->done));
   hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
@@ -1443,6 +1443,14 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
       for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", hbuf[i], (i % tw == tw - 1) ? '\n' : ' ');
       fclose(f);
     }
+    // per-tile wall-clock stamps of block 0 (persistent kernel): start, first K-tile landed, K-loop done, epilogue issued
+    std::vector<unsigned long long> tb(4 * 4096);
+    RPR_HIP(hipMemcpy(tb.data(), c->trace_buf + 100000, tb.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen((std::string(getenv("RPR_GEMM_TRACE")) + ".tiles").c_str(), "w")) {
+      for (size_t i = 0; i + 3 < tb.size() && tb[i]; i += 4) fprintf(f, "%llu %llu %llu %llu\n", tb[i], tb[i + 1], tb[i + 2], tb[i + 3]);
+      fclose(f);
+    }
+    RPR_HIP(hipMemset(c->trace_buf + 100000, 0, tb.size() * 8));
   }
   return Ln.err;
 }

@@ -480,6 +480,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   const int bid = chunk0 + ti;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int bm = tm * BM, bn = tn * BN;
+  // TRACE: wall-clock stamps (100 MHz) of block 0 per tile: start, first K-tile landed, K-loop done, epilogue issued
+  const bool tl = TRACE && g.trace != nullptr && blockIdx.x == 0 && tid == 0 && round < 4096;
+#define PP_TILE_STAMP(k) if (TRACE) { if (tl) g.trace[100000 + round * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); }
+  PP_TILE_STAMP(0);
   if (g.row_ssq && tid < BM) {   // one dependent load + rsqrt per row, hidden behind the first K-tile's DMA; the epilogue
     const int m = bm + tid;      // (after the K-loop's barriers) reads the scales from LDS instead of global memory
     rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __builtin_amdgcn_s_waitcnt(WAIT_ALL);
   __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
   __builtin_amdgcn_sched_barrier(0);
+  PP_TILE_STAMP(1);
   if (wm == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();         // group 0 catches the extra barrier of group 1
   __builtin_amdgcn_sched_barrier(0);
+  PP_TILE_STAMP(2);
 #undef PP_PIECE
 #undef PP_LOAD_W
 #undef PP_LOAD_A
@@ -650,6 +656,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   asm volatile("" : "+v"(lane_e));
   h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
   __syncthreads();   // the staging strips alias the operand buffers the next tile's LDS-DMA writes; rs_tile is rewritten
+  PP_TILE_STAMP(3);
+#undef PP_TILE_STAMP
   }
 }
 
