@@ -388,7 +388,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
       const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
       const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
-      float* outp = g.out[oi];
+      float* outp = g.out[oi] + (size_t)blockIdx.y * g.part_stride;   // split-K: this block's partial result
       const int ldo = g.ldo[oi];
       float4 res[NK];
       if (g.resid) {
@@ -489,6 +489,15 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
   }
 
+  // split-K (weight gradients of the training step: few output tiles, K = thousands of rows): blockIdx.y walks its own
+  // range of K-tiles and stores a partial result at out + blockIdx.y * part_stride (splitk_reduce_kernel adds them in order)
+  constexpr int KSTEP = BF16 ? 2 * HBK : HBK;
+  int nkt = g.K / KSTEP, kbeg = 0;
+  if (g.ksplit > 1) {
+    const int per = (nkt + g.ksplit - 1) / g.ksplit;
+    kbeg = blockIdx.y * per;
+    nkt = min(per, nkt - kbeg);
+  }
   // (the lane index is laundered per tile: otherwise the compiler hoists the eight per-piece row / segment terms out of
   // the tile loop and the 256-register kernel spills)
   int lane_t = lane;
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
     else { base = g.W + (BF16 ? (size_t)HBK : g.w_ps); trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
     if (!FULL && trow >= limit) trow = limit - 1;
-    src[j] = base + (size_t)trow * ld + seg * 8;
+    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;
   }
 #define PP_PIECE(buf, k0, j)                                                                                   \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (k0)),             \
@@ -593,7 +602,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __builtin_amdgcn_sched_barrier(0)
   constexpr int WAIT_LGKM = 0xc07f, WAIT_ALL = 0x0070;   // lgkmcnt(0) | vmcnt(0) lgkmcnt(0)
 
-  const int nkt = g.K / (BF16 ? 2 * HBK : HBK);
   // TRACE: block 0 stamps s_memtime (shader cycles) at the 4 segment edges of each phase -> 16 per (K-tile, wave),
   // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
   const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;
-    const int k1 = (kt + 1) * (BF16 ? 2 * HBK : HBK);
+    const int k1 = (kt + 1) * KSTEP;
     // phase 0: chunk 0, A rows 0..63
     if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + 16] = __builtin_amdgcn_s_memrealtime(); }
     PP_STAMP(0);
@@ -826,7 +834,8 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int grid = (persist && nt > cus) ? cus : nt;
   // skew only pays when a block walks several tiles (the late blocks idle for up to 3/4 of a tile time once per launch)
   const int skew_ticks = (grid < nt && nt >= 4 * cus) ? (int)((long)skew * a.K / 768) : 0;
-  const dim3 gr(grid), bl(512);
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  const dim3 gr(ks > 1 ? nt : grid, ks), bl(512);      // split-K launches are not persistent: one block per (tile, K range)
   GemmH2Args ab = a;
   static const int xsync = [] { const char* e = getenv("RPR_GEMM_XCD_SYNC"); return e ? atoi(e) : 0; }();
   if (!(xsync && a.xcd_sync && grid < nt && nt >= 2 * cus)) ab.xcd_sync = nullptr;
@@ -898,6 +907,34 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmH2Args g, cons
   }
 }
 
+// Split-K through the 256x256 ping-pong kernel (weight gradients of the training step: dW[N, K] = dY^T X reduces over the
+// 8192 rows of the batch into 9 .. 36 output tiles): blockIdx.y = K range, partial tiles to the caller's scratch,
+// splitk_reduce_kernel adds them in split order (bitwise reproducible). Returns hipErrorNotSupported when the shape does
+// not qualify (the caller falls back to the 128x64 split-K route).
+static hipError_t launch_256_splitk(const GemmH2Args& a, hipStream_t s) {
+  static const int on = [] { const char* e = getenv("RPR_GEMM_PP_SPLITK"); return e ? atoi(e) : 1; }();
+  const int kstep = a.bf16 ? 2 * HBK : HBK;
+  if (!on || !a.part || (a.M & 255) || (a.N & 255) || (a.K % kstep) || a.relu || a.out_h || a.row_ssq || a.ssq_out || a.resid_h ||
+      a.m_dev || a.rm_B || a.split_n < a.N || (a.ldo[0] & 3) || (a.resid && (a.ldr & 3)))
+    return hipErrorNotSupported;
+  const long tiles = (long)(a.M / 256) * (a.N / 256);
+  const int cus = a.cus > 0 ? a.cus : 256, nkt = a.K / kstep;
+  long ks = cus / tiles;                                        // one round of (tile, K range) blocks on the chip
+  ks = std::min<long>(ks, nkt / 4);                             // at least 4 K-tiles per block
+  ks = std::min<long>(ks, (long)(a.part_cap / ((size_t)a.M * a.N)));
+  while (ks > 1 && (ks - 1) * ((nkt + ks - 1) / ks) >= nkt) --ks;
+  if (tiles > 64 || ks < 2) return hipErrorNotSupported;
+  GemmH2Args p = a;
+  p.ksplit = (int)ks; p.part_stride = (size_t)a.M * a.N;
+  p.out[0] = p.out[1] = p.out[2] = a.part; p.ldo[0] = p.ldo[1] = p.ldo[2] = a.N; p.split_n = a.N; p.resid = nullptr;
+  hipError_t e = launch_256(p, s);
+  if (e != hipSuccess) return e;
+  const size_t n4 = (size_t)a.M * (a.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.part, (int)ks, p.part_stride, a.M, a.N,
+                     a.out[0], a.ldo[0], a.resid, a.ldr);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   GemmH2Args a = a_in;
   if (a.acc_scale == 0.f) a.acc_scale = 1.f;      // zero-initialised args mean "no scaling"
@@ -922,6 +959,10 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // long reductions into few tiles (weight gradients); K-tiles of 64 columns
     if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63)) return hipErrorInvalidValue;
     const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.K >= 2048) {
+      const hipError_t e = launch_256_splitk(a, s);
+      if (e != hipErrorNotSupported) { if (e == hipSuccess) a_in.kernel_cls = RPR_K_GEMM; return e; }
+    }
     if (a.part && a.K >= 2048 && t128b * 2 < 640 && !a.relu && a.split_n >= a.N && (a.N & 3) == 0 && (a.ldo[0] & 3) == 0 &&
         (!a.resid || (a.ldr & 3) == 0)) {
       const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
@@ -942,8 +983,8 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
       }
     }
     const long t256b = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    static const int bf_pp = [] { const char* e = getenv("RPR_BF16_PP"); return e ? atoi(e) : 1; }();
-    if (bf_pp && t256b >= 200) return launch_256(a, s);     // ping-pong 256x256 tiles when they fill the chip
+    static const int bf_pp = [] { const char* e = getenv("RPR_BF16_PP"); return e ? atoi(e) : 200; }();   // min tiles of 256^2 (0 = never)
+    if (bf_pp > 0 && t256b >= bf_pp) return launch_256(a, s);     // ping-pong 256x256 tiles when they fill the chip
     return t128b < 256 ? launch_cfg<128, 64, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, true>(a, s);
   }
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
@@ -994,6 +1035,10 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   }
   // split-K: the caller lent scratch for partial results and the launch is a long reduction into few tiles
   static const int split_target = [] { const char* e = getenv("RPR_GEMM_SPLITK"); return e ? atoi(e) : 640; }();
+  if (a.part && split_target > 0 && a.K >= 2048 && t128 * 2 < split_target && !a.mid_split) {
+    const hipError_t e = launch_256_splitk(a, s);
+    if (e != hipErrorNotSupported) { if (e == hipSuccess) a_in.kernel_cls = RPR_K_GEMM; return e; }
+  }
   if (a.part && split_target > 0 && a.K >= 2048 && t128 * 2 < split_target && !a.out_h && !a.ssq_out && !a.row_ssq && !a.relu && !a.resid_h &&
       !a.m_dev && a.split_n >= a.N && (a.N & 3) == 0 && (a.ldo[0] & 3) == 0 && (!a.resid || (a.ldr & 3) == 0)) {
     const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
