@@ -157,6 +157,10 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
   const size_t depth0 = forks.empty() ? (size_t)L : (size_t)forks[0];   // stage 0 stops at the first fork
   E(w.kcache, nd * depth0 * R * inner * f); E(w.vcache, nd * depth0 * R * inner * f);
   E(w.lb, R * (size_t)d.V * 4);
+  {
+    const int G = select_groups(Q, B, d.V, 256);
+    if (G > 1) E(w.sel_part, R * (size_t)G * 20);
+  }
   for (int i = 0; i < 2; ++i) {
     E(w.score[i], R * 8); E(w.lo[i], R * 4); E(w.hi[i], R * 4);
     E(w.tokens[i], R * (size_t)L * 2); E(w.anc[i], R * (size_t)L * 2);
@@ -415,6 +419,22 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
       sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
     }
     if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
+    // few queries x many beams: G blocks per query + a merge, on the steps whose candidate sets are large — about
+    // B * min(V, docs per depth-t node) valid candidates; narrow steps go through the single block's compact path
+    const int G = taps ? 1 : select_groups(sd.Q, B, V, 256);
+    if (G > 1 && w.sel_part.p) {
+      double per_node = (double)tr->N;
+      for (int i = 0; i < t && per_node > 1.0; ++i) per_node /= (double)V;
+      const char* fa = getenv("RPR_SELECT_GROUPS_ALL");    // tests: grouped selection on every step
+      const int force_all = fa ? atoi(fa) : 0;
+      if (force_all || (double)B * std::min((double)V, per_node) > 4096.0) {
+        const size_t n = (size_t)sd.Q * B * G;
+        sa.G = G;
+        sa.p_score = P<double>(w.sel_part);
+        sa.p_item = reinterpret_cast<int32_t*>(sa.p_score + n);
+        sa.p_lo = sa.p_item + n; sa.p_hi = sa.p_lo + n;
+      }
+    }
     Ln.run(RPR_K_SELECT, 0, (double)Ma * V * 4 + (double)Ma * 40, [&] { return launch_select(sa, s); });
   }
 }
@@ -1211,7 +1231,11 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     enqueue_search(Ln, c, m, tr, Q, Lq, B, L, flags, taps, forks, drop_last);
     if (Ln.err) return Ln.err;
   } else {
-    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16), lane, pack_forks(forks, drop_last)};
+    // the per-call debug switches of the selection / ranking kernels are part of the key (tests flip them between calls)
+    auto env_int = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    const unsigned dbg = ((unsigned)(env_int("RPR_SELECT_GROUPS", -1) + 1) & 0x3fu) | (env_int("RPR_SELECT_GROUPS_ALL", 0) ? 0x40u : 0u) |
+                         (env_int("RPR_TAIL_RANK_REPLAY", 0) ? 0x80u : 0u);
+    GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16) | (dbg << 20), lane, pack_forks(forks, drop_last)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;

@@ -261,9 +261,15 @@ struct SelectArgs {
   unsigned long long* tap_valid;                                   // [Q, B*V/64] phase-A child bitmap (bit = beam*V + token)
   unsigned long long* clk;   // debug (RPR_SELECT_CLOCK=1, eager mode): 8 wall-clock stamps of block 0 at the phase boundaries
   const int* nq_dev;         // nullable: live query count on the device; blocks past it exit
+  // grouped launch (few queries x many beams): G blocks per query select among B / G beams each, select_merge_kernel
+  // merges their rank-ordered partial lists [Q, G, B]. G <= 1: one block per query writes the next state itself.
+  int G;
+  double* p_score; int32_t* p_item; int32_t* p_lo; int32_t* p_hi;
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
+// number of blocks per query a grouped launch would use for Q queries of B beams (1 = not worth it / not possible)
+int select_groups(int Q, int B, int V, int cus);
 
 struct FinalizeArgs {
   BeamState st;
@@ -359,6 +365,7 @@ struct TailRankArgs {
   const float* gold;         // [., B, L-T]
   int Qcap, B, T, L;
   int32_t* out_tokens; float* out_scores; int64_t* out_lo; int64_t* out_hi;
+  int replay = 0;            // 1: always replay the L - T steps (RPR_TAIL_RANK_REPLAY=1; the tie path, for tests)
 };
 hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s);
 // max over the rows of |E[r] (*) w|_2 (w nullable): bound of the logits after the final RMSNorm (model load)

@@ -599,55 +599,85 @@ hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_em
 // candidates. Per step the B winners are the beams' single valid children; new slot order = (cumulative score desc,
 // parent slot asc) — the sort order of the sequential select_kernel restricted to those candidates. Then
 // finalize_kernel's rule: rank by float64 sum/(L+1) desc, exact ties in reverse slot order, float32 store.
-__global__ __launch_bounds__(256) void tail_rank_kernel(TailRankArgs a) {
+// The slot order of the intermediate steps only ever decides exact ties, so the kernel first sums the scores (same
+// additions in the same order), ranks the final values once and replays the L - T steps only if two of them are equal
+// (B = 1000: the replay was 28 x B^2 comparisons = 9 ms for one query; the single ranking pass is 30 us).
+__global__ __launch_bounds__(1024) void tail_rank_kernel(TailRankArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int i = blockIdx.x, tid = threadIdx.x;
+  const int i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   if (i >= *a.nf_dev) return;
   const int B = a.B, T = a.T, L = a.L, Lt = L - T;
   double* S = reinterpret_cast<double*>(smem_raw);       // [B] cumulative score of the beam that started in slot b
   int* pos = reinterpret_cast<int*>(S + B);              // [B] its current slot
   int* npos = pos + B;                                   // [B]
+  __shared__ int tie;
   const int q = a.flist[i];
   const size_t r0 = (size_t)q * B;
-  for (int b = tid; b < B; b += 256) { S[b] = a.st.score[r0 + b]; pos[b] = b; }
+  if (tid == 0) tie = a.replay;
+  for (int b = tid; b < B; b += nt) {
+    double s = a.st.score[r0 + b];
+    const float* g = a.gold + ((size_t)i * B + b) * Lt;
+    for (int t = 0; t < Lt; ++t) s = ((double)g[t] + 0.0) + s;
+    S[b] = s / (double)(L + 1);
+    pos[b] = b;
+  }
   __syncthreads();
-  for (int t = 0; t < Lt; ++t) {
-    for (int b = tid; b < B; b += 256) S[b] = ((double)a.gold[((size_t)i * B + b) * Lt + t] + 0.0) + S[b];
+  for (int b = tid; b < B; b += nt) {
+    const double s = S[b];
+    int gt = 0, eq = 0;
+    for (int k = 0; k < B; ++k) { const double o = S[k]; gt += o > s; eq += o == s; }
+    npos[b] = gt;
+    if (eq > 1) tie = 1;                                 // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (tie) {                                             // block-uniform: exact ties -> the full replay decides them
+    for (int b = tid; b < B; b += nt) S[b] = a.st.score[r0 + b];
     __syncthreads();
-    for (int b = tid; b < B; b += 256) {
+    for (int t = 0; t < Lt; ++t) {
+      for (int b = tid; b < B; b += nt) S[b] = ((double)a.gold[((size_t)i * B + b) * Lt + t] + 0.0) + S[b];
+      __syncthreads();
+      for (int b = tid; b < B; b += nt) {
+        const double s = S[b];
+        const int pb = pos[b];
+        int rk = 0;
+        for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] < pb);
+        npos[b] = rk;
+      }
+      __syncthreads();
+      for (int b = tid; b < B; b += nt) pos[b] = npos[b];
+      __syncthreads();
+    }
+    for (int b = tid; b < B; b += nt) S[b] = S[b] / (double)(L + 1);
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) {
       const double s = S[b];
       const int pb = pos[b];
       int rk = 0;
-      for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] < pb);
+      for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] > pb);
       npos[b] = rk;
     }
     __syncthreads();
-    for (int b = tid; b < B; b += 256) pos[b] = npos[b];
-    __syncthreads();
   }
-  for (int b = tid; b < B; b += 256) S[b] = S[b] / (double)(L + 1);
-  __syncthreads();
   const size_t o0 = (size_t)a.qmap[i] * B;
-  for (int b = tid; b < B; b += 256) {
-    const double s = S[b];
-    const int pb = pos[b];
-    int rk = 0;
-    for (int k = 0; k < B; ++k) rk += (S[k] > s) || (S[k] == s && pos[k] > pb);
-    npos[b] = rk;
-    a.out_scores[o0 + rk] = (float)s;
+  for (int b = tid; b < B; b += nt) {
+    const int rk = npos[b];
+    a.out_scores[o0 + rk] = (float)S[b];
     a.out_lo[o0 + rk] = a.st.lo[r0 + b];
     a.out_hi[o0 + rk] = a.st.hi[r0 + b];
   }
-  __syncthreads();
-  for (int k = tid; k < B * L; k += 256) {
+  for (int k = tid; k < B * L; k += nt) {
     const int b = k / L, p = k - b * L;
     a.out_tokens[(o0 + npos[b]) * L + p] = (int32_t)a.tokens[((size_t)i * B + b) * L + p];
   }
 }
 
-hipError_t launch_tail_rank(const TailRankArgs& a, hipStream_t s) {
+hipError_t launch_tail_rank(const TailRankArgs& a_in, hipStream_t s) {
+  const char* rp = getenv("RPR_TAIL_RANK_REPLAY");          // tests: always take the tie path (read per call)
+  const int replay = rp ? atoi(rp) : 0;
+  TailRankArgs a = a_in;
+  if (replay) a.replay = 1;
   const size_t smem = (size_t)a.B * (sizeof(double) + 2 * sizeof(int)) + 16;
-  hipLaunchKernelGGL(tail_rank_kernel, dim3(a.Qcap), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(tail_rank_kernel, dim3(a.Qcap), dim3(a.B > 256 ? 1024 : 256), smem, s, a);
   return hipGetLastError();
 }
 

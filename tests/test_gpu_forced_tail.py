@@ -257,3 +257,53 @@ def test_optimistic_mode_flags_leftovers_and_the_guard_repeats(E):
     finally:
         ctx.set_fork_depths(None)
         ctx.set_forced_tail(True)
+
+
+def test_rank_replay_path_equals_single_ranking_pass(E, monkeypatch):
+    """tail_rank_kernel ranks the summed scores once and replays the L - T selection steps only when two final scores
+    are exactly equal; RPR_TAIL_RANK_REPLAY=1 forces the replay: both must give the same bits (beams 10 and 300; the
+    1024-thread launch of large beams included)."""
+    from ripor_amd.utils import synth
+    L, V, N = 12, 256, 40_000
+    codes = synth.make_codes(N, L, V, seed=5)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=6)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ctx.set_forced_tail(True)
+    for B in (10, 300):
+        monkeypatch.setenv("RPR_TAIL_RANK_REPLAY", "0")
+        a = E.search(model, trie, ti, tm, B, L)
+        stats = ctx.last_fork_stats()
+        assert stats and stats[0]["forced"] > 0, stats
+        monkeypatch.setenv("RPR_TAIL_RANK_REPLAY", "1")
+        b = E.search(model, trie, ti, tm, B, L)
+        torch.cuda.synchronize()
+        assert torch.equal(a.tokens, b.tokens) and torch.equal(a.scores, b.scores)
+        assert torch.equal(a.row_lo, b.row_lo) and torch.equal(a.row_hi, b.row_hi)
+
+
+def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
+    """Beam 512 / 1000 with 2 queries: the automatic grouped selection (16 / 8 blocks per query on the wide steps, the
+    single block's compact path on the narrow ones) returns the bits of the single-block kernel, with and without the
+    forced tail; so does grouping forced onto every step."""
+    from ripor_amd.utils import synth
+    L, V, N = 12, 256, 300_000
+    codes = synth.make_codes(N, L, V, seed=9)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=2)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    try:
+        for B in (512, 1000):
+            for ft in (False, True):
+                ctx.set_forced_tail(ft)
+                monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
+                monkeypatch.delenv("RPR_SELECT_GROUPS_ALL", raising=False)
+                ref = E.search(model, trie, ti, tm, B, L)
+                monkeypatch.delenv("RPR_SELECT_GROUPS")
+                auto = E.search(model, trie, ti, tm, B, L)
+                monkeypatch.setenv("RPR_SELECT_GROUPS_ALL", "1")
+                every = E.search(model, trie, ti, tm, B, L)
+                torch.cuda.synchronize()
+                for r, lab in ((auto, "auto"), (every, "every step")):
+                    assert torch.equal(r.tokens, ref.tokens) and torch.equal(r.scores, ref.scores), (B, ft, lab)
+                    assert torch.equal(r.row_lo, ref.row_lo) and torch.equal(r.row_hi, ref.row_hi), (B, ft, lab)
+    finally:
+        ctx.set_forced_tail(True)

@@ -313,3 +313,31 @@ def test_gemm_kernels_are_repeatable_bitwise(engine, M, N, K):
     assert (first.double() - ref).abs().max().item() < 5e-5
     for _ in range(8):
         assert torch.equal(ctx.linear(A, W, R), first)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "b100" in n])
+def test_grouped_selection_matches_golden(engine, golden_cache, name, monkeypatch):
+    """Few queries x many beams launch select_kernel as G blocks per query + select_merge_kernel (beam_kernels.hip). The
+    beam-100 goldens run it forced on every step (4 and 5 groups of 25 / 20 beams) with and without the forced tail:
+    same bar as the single block, and bit-identical to it (same candidates, same float64 arithmetic, same order)."""
+    g = golden_cache(name)
+    ctx, model, trie = _build(engine, g)
+    monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
+    ref = {}
+    for ft in (False, True):
+        ctx.set_forced_tail(ft)
+        ref[ft] = _run(engine, g, model, trie)
+    try:
+        for G in (4, 5):
+            monkeypatch.setenv("RPR_SELECT_GROUPS", str(G))
+            monkeypatch.setenv("RPR_SELECT_GROUPS_ALL", "1")
+            for ft in (False, True):
+                ctx.set_forced_tail(ft)
+                r = _run(engine, g, model, trie)
+                compare_ranked(g, r.tokens.cpu().numpy(), r.scores.cpu().numpy(), label=f" (select groups {G}, forced tail {ft})")
+                assert torch.equal(r.tokens, ref[ft].tokens) and torch.equal(r.scores, ref[ft].scores)
+                assert torch.equal(r.row_lo, ref[ft].row_lo) and torch.equal(r.row_hi, ref[ft].row_hi)
+            r = _run(engine, g, model, trie, use_graph=False)
+            assert torch.equal(r.tokens, ref[True].tokens) and torch.equal(r.scores, ref[True].scores)
+    finally:
+        ctx.set_forced_tail(True)
