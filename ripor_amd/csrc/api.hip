@@ -920,6 +920,7 @@ void rpr_free_model(rpr_model* m) {
   for (auto it = m->ctx->graphs.begin(); it != m->ctx->graphs.end();) {
     if (it->first.m == m) { (void)hipGraphExecDestroy(it->second); it = m->ctx->graphs.erase(it); } else ++it;
   }
+  train_forget_model(m->ctx, m);
   delete m;
 }
 

@@ -126,6 +126,8 @@ struct GemmH2Args {
   // hipGraph is static, the number of queries a fork leaves over is not).
   int live_lo, live_hi, small_live;
   int bf16;                                // 1: A and W are single bf16 planes (training GEMMs, RPR_PREC_BF16); fp32 output only
+  int prefer_pp;                           // 1: the 256x256 ping-pong kernel whatever the tile count, one K-loop per tile (weight gradients:
+                                           // few tiles, thousands of K rows, several launches side by side on separate streams)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 
@@ -396,6 +398,10 @@ hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, _
 // out_t[C][Rpad] (columns r >= R zero); RPR_PREC_BF16 training GEMMs
 hipError_t launch_to_bf16(const float* x, int R, int C, int ldi, void* out, hipStream_t s);
 hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s);
+// all GEMM weights at once: segs[i] = fp32 tensor [R][C] (R % 2 == 0, C % 4 == 0), off = element offset of its copies in
+// `plain` ([R][C]) and `tr` ([C][R]); pref = exclusive prefix sums of ceil(R/64) * ceil(C/64)
+struct WSeg { const float* src; int R, C; unsigned long long off; };
+hipError_t launch_weights_bf16(const WSeg* segs, const int* pref, int nseg, int ntiles, void* plain, void* tr, hipStream_t s);
 hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
 hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,

@@ -959,6 +959,13 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // long reductions into few tiles (weight gradients); K-tiles of 64 columns
     if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63)) return hipErrorInvalidValue;
     const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.prefer_pp) {
+      static const int dwk = [] { const char* e = getenv("RPR_TRAIN_DW_TILE"); return e ? atoi(e) : 256; }();   // experiment: 128 / 64
+      if (dwk == 128) return launch_cfg<128, 128, 2, 2, true>(a, s);
+      if (dwk == 64) return launch_cfg<128, 64, 2, 2, true>(a, s);
+      a_in.kernel_cls = RPR_K_GEMM;
+      return launch_256(a, s);
+    }
     if (a.K >= 2048) {
       const hipError_t e = launch_256_splitk(a, s);
       if (e != hipErrorNotSupported) { if (e == hipSuccess) a_in.kernel_cls = RPR_K_GEMM; return e; }
@@ -993,7 +1000,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   // chip idle in its last round; the 128-tile kernels quantise finer (measured M = 8192, N = 2304: 135 vs 151 us)
   const int cus = a.cus > 0 ? a.cus : 256;         // a lane stream owns part of the chip: thresholds scale with it
   const double round_eff = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);
-  if (force == 256 || (force == 0 && t256 >= 112L * cus / 256 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
+  if (force == 256 || a.prefer_pp || (force == 0 && t256 >= 112L * cus / 256 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
     a_in.kernel_cls = RPR_K_GEMM;
     return launch_256(a, s);
   }

@@ -183,6 +183,7 @@ inline int ensure_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
   return e;
 }
 void free_train_ws(rpr_ctx* c);   // train_api.hip
+void train_forget_model(rpr_ctx* c, const rpr_model* m);   // train_api.hip: drop the per-model weight cache table
 
 inline int ensure(rpr_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return 0;

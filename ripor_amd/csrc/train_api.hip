@@ -23,14 +23,27 @@ struct TrainWs {
   // saved forward activations
   DevBuf enc_act, dec_act, enc_out, xkv, x_last, scores, margins, dscores, in_idx, out_idx, tok_idx;
   // scratch
-  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, tB, tC, wT, w_part, bias_part, fix, gn_part, gn_out, amax, part, tB2, tC2, part2;
-  // the weight-gradient GEMMs run on a side stream beside the input-gradient GEMMs (each alone leaves CUs idle at
-  // M = 8192): two sets of transposed-plane scratch so that a dW product may still be running two dxdw calls later
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-  bool done_pending[2] = {false, false};
+  DevBuf h, dxa, dxb, dbig, dattn, dxkv, denc, tA, wT, w_part, bias_part, fix, gn_part, gn_out, amax, part, part2;
+  // The weight-gradient GEMMs run on side streams beside the input-gradient chain. dW[N, K] = dY^T X reduces over all
+  // rows of the batch into 9 .. 36 tiles of 256 x 256: one launch cannot fill the chip, so the launches of consecutive
+  // sites go round-robin to NSIDE streams and run next to each other, each walking the whole reduction in one K-loop
+  // (no split-K partials, no reduce pass). One set of transposed-operand scratch per stream: a set is reused NSIDE
+  // dxdw calls later, after its product has finished (ev_done).
+  static constexpr int NSIDE = 4;
+  DevBuf tB[NSIDE], tC[NSIDE];
+  hipStream_t side[NSIDE] = {};
+  hipEvent_t ev_fork[NSIDE] = {}, ev_done[NSIDE] = {};
+  bool done_pending[NSIDE] = {};
   int flip = 0;
   std::vector<hipEvent_t> bucket_ev;   // gradient buckets handed to the caller's communication stream (2 events each)
+  // bf16 mode: the GEMM weights are converted once per step (plain + transposed copies at the tensors' offsets of the flat
+  // parameter layout) instead of once per GEMM call, and the forward pass leaves the transposed bf16 copy of every
+  // linear layer's input behind — the X^T operand of its weight-gradient product — so the backward pass neither converts
+  // X again nor recomputes the normalised inputs it would only need for that
+  DevBuf wc, wcT, wseg, wpref, xT;
+  const rpr_model* wc_model = nullptr;
+  int wc_nseg = 0, wc_tiles = 0;
+  std::unordered_map<const float*, size_t> wc_off;
   int amax_next = 0;
   // forward GEMM site (keyed by its weight tensor) -> {amax of its input activations, amax of the weight}: the backward
   // multiplies the same two tensors again (dW = dY^T X, dX = dY W) and reuses both maxima
@@ -90,6 +103,7 @@ int tensure(rpr_ctx* c, DevBuf& b, size_t bytes) {   // like ensure(), without t
 }
 
 inline int pad32(int n) { return (n + 31) & ~31; }
+inline int pad64(int n) { return (n + 63) & ~63; }
 
 struct Dims {
   int bz, Lq, L, S, R, T, dm, inner, dff, H, ne, nd, V, xld, buckets;
@@ -116,7 +130,7 @@ void amax_reset(Launcher& Ln) {
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.amax), AMAX_SLOTS / 2, Ln.s); });
 }
 void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int ldc, int M, int N, int K, const float* resid, int relu,
-                 DevBuf* part = nullptr) {
+                 DevBuf* part = nullptr, bool whole_k = false) {
   GemmH2Args g{};
   g.A = A.p; g.a_ps = A.ps; g.lda = A.ld; g.W = B.p; g.w_ps = B.ps; g.ldw = B.ld;
   g.resid = resid; g.ldr = ldc;
@@ -124,7 +138,8 @@ void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int l
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.sat = Ln.c->status;
   g.dyn_a = A.amax; g.dyn_b = B.amax;
   if (!part) part = &Ln.c->tws->part;
-  g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float);
+  if (whole_k) g.prefer_pp = 1;        // one K-loop per tile on the 256 x 256 kernel, no split-K (weight gradients)
+  else { g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float); }
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm_h2(g, Ln.s); },
          &g.kernel_cls);
 }
@@ -132,29 +147,35 @@ void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int l
 // C[M, N] = act(A[M, K] B[N, K]^T) (+ resid): exact fp32 MFMA, or (split-precision mode) f16x2 planes with dynamic scales
 // one bf16 plane per operand, one MFMA per product (RPR_PREC_BF16)
 void gemm_bf16(Launcher& Ln, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const float* resid,
-               int relu, DevBuf* part = nullptr) {
+               int relu, DevBuf* part = nullptr, bool whole_k = false) {
   GemmH2Args g{};
   g.A = reinterpret_cast<const __half*>(A); g.lda = lda; g.W = reinterpret_cast<const __half*>(B); g.ldw = ldb;
   g.resid = resid; g.ldr = ldc;
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.bf16 = 1;
   if (!part) part = &Ln.c->tws->part;
-  g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float);
+  if (whole_k) g.prefer_pp = 1;
+  else { g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float); }
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, [&] { return launch_gemm_h2(g, Ln.s); },
          &g.kernel_cls);
 }
 
+// save_xt (bf16 mode): where to leave the transposed copy [K][pad64(M)] of A for the weight-gradient product
 void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-          const float* resid = nullptr, int relu = 0) {
+          const float* resid = nullptr, int relu = 0, void* save_xt = nullptr) {
   if (Ln.c->precision == RPR_PREC_BF16) {
     // the reference's bf16 autocast (main.py:152 bf16=args.use_fp16; tasks/trainer.py:229): operands rounded to bf16, fp32
     // accumulation. One conversion pass per operand, no maxima, no second plane.
     TrainWs& w = *Ln.c->tws;
     if (lda != K || ldb != K) { Ln.err = RPR_ERR_INVALID; return; }
     hipStream_t s = Ln.s;
-    Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16(A, M, K, lda, w.tA.p, s); });
-    Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16(B, N, K, ldb, w.wT.p, s); });
-    gemm_bf16(Ln, w.tA.p, K, w.wT.p, K, C, ldc, M, N, K, resid, relu);
+    if (save_xt) Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_to_bf16_T(A, M, K, lda, pad64(M), save_xt, w.tA.p, s); });
+    else Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16(A, M, K, lda, w.tA.p, s); });
+    const void* wb = w.wT.p;
+    auto it = w.wc_off.find(B);
+    if (it != w.wc_off.end() && w.wc.p) wb = reinterpret_cast<const __half*>(w.wc.p) + it->second;   // converted once per step
+    else Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16(B, N, K, ldb, w.wT.p, s); });
+    gemm_bf16(Ln, w.tA.p, K, wb, K, C, ldc, M, N, K, resid, relu);
     return;
   }
   if (Ln.c->precision == RPR_PREC_F16X2) {
@@ -177,34 +198,133 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
   Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), [&] { return launch_gemm(g, Ln.s); });
 }
 
+// Saved X^T operands (bf16 mode): encoder layer i holds [qkv | o | wi | wo], then the cross K/V projection, then decoder
+// layer i [qkv | o | xq | xo | wi | wo]; a slot is [K][pad64(rows)] bf16.
+enum XtSite { XT_QKV, XT_O, XT_XQ, XT_XO, XT_WI, XT_WO };
+struct XtLayout {
+  size_t Tp, Rp, enc_layer, dec_layer, xkv_off, dec_off, total;
+  int dm, inner, dff;
+  explicit XtLayout(const Dims& D) : Tp(pad64(D.T)), Rp(pad64(D.R)), dm(D.dm), inner(D.inner), dff(D.dff) {
+    enc_layer = Tp * (size_t)(2 * dm + inner + dff);
+    dec_layer = Rp * (size_t)(3 * dm + 2 * inner + dff);
+    xkv_off = enc_layer * D.ne;
+    dec_off = xkv_off + Tp * (size_t)dm;
+    total = dec_off + dec_layer * D.nd;
+  }
+  size_t enc(int layer, XtSite st) const {
+    const size_t o = enc_layer * layer;
+    switch (st) {
+      case XT_QKV: return o;
+      case XT_O: return o + Tp * dm;
+      case XT_WI: return o + Tp * (size_t)(dm + inner);
+      default: return o + Tp * (size_t)(2 * dm + inner);   // XT_WO
+    }
+  }
+  size_t dec(int layer, XtSite st) const {
+    const size_t o = dec_off + dec_layer * layer;
+    switch (st) {
+      case XT_QKV: return o;
+      case XT_O: return o + Rp * dm;
+      case XT_XQ: return o + Rp * (size_t)(dm + inner);
+      case XT_XO: return o + Rp * (size_t)(2 * dm + inner);
+      case XT_WI: return o + Rp * (size_t)(2 * dm + 2 * inner);
+      default: return o + Rp * (size_t)(3 * dm + 2 * inner);   // XT_WO
+    }
+  }
+};
+struct XtSlots {     // null base: nothing is saved (every mode but bf16)
+  __half* base; XtLayout lay;
+  void* enc(int l, XtSite st) const { return base ? base + lay.enc(l, st) : nullptr; }
+  void* dec(int l, XtSite st) const { return base ? base + lay.dec(l, st) : nullptr; }
+  void* xkv() const { return base ? base + lay.xkv_off : nullptr; }
+};
+
+// bf16 copies of every GEMM weight, refreshed at the start of each pass (the weights change between passes: AdamW, or the
+// caller writing through rpr_param_info's pointers). The table of tensors is built once per model.
+int refresh_weight_cache(Launcher& Ln, rpr_ctx* c, rpr_model* m) {
+  TrainWs& w = *c->tws;
+  if (w.wc_model != m) {
+    std::vector<WSeg> segs;
+    std::vector<int> pref;
+    w.wc_off.clear();
+    int tiles = 0;
+    const auto& d = m->d;
+    const int dm = d.d_model, inner = m->inner(), dff = d.d_ff, nd = d.num_decoder_layers;
+    auto add = [&](const float* p, int R, int C) {
+      size_t off = (size_t)-1;
+      for (const auto& pr : m->params) if (pr.ptr == p) off = pr.offset;
+      if (off == (size_t)-1 || (R & 1) || (C & 3)) return;
+      segs.push_back(WSeg{p, R, C, (unsigned long long)off});
+      pref.push_back(tiles);
+      tiles += ((R + 63) / 64) * ((C + 63) / 64);
+      w.wc_off[p] = off;
+    };
+    for (int i = 0; i < d.num_layers; ++i) {
+      add(m->enc_qkv[i], 3 * inner, dm); add(m->enc_o[i], dm, inner); add(m->enc_wi[i], dff, dm); add(m->enc_wo[i], dm, dff);
+    }
+    add(d.dec_xkv, nd * 2 * inner, dm);
+    for (int i = 0; i < nd; ++i) {
+      add(m->dec_qkv[i], 3 * inner, dm); add(m->dec_o[i], dm, inner); add(m->dec_xq[i], inner, dm); add(m->dec_xo[i], dm, inner);
+      add(m->dec_wi[i], dff, dm); add(m->dec_wo[i], dm, dff);
+    }
+    int e = tensure(c, w.wseg, segs.size() * sizeof(WSeg));
+    if (!e) e = tensure(c, w.wpref, pref.size() * sizeof(int));
+    if (!e) e = tensure(c, w.wc, m->params_total * sizeof(__half));
+    if (!e) e = tensure(c, w.wcT, m->params_total * sizeof(__half));
+    if (e) { w.wc_off.clear(); return e; }
+    RPR_HIP(hipMemcpyAsync(w.wseg.p, segs.data(), segs.size() * sizeof(WSeg), hipMemcpyHostToDevice, Ln.s));
+    RPR_HIP(hipMemcpyAsync(w.wpref.p, pref.data(), pref.size() * sizeof(int), hipMemcpyHostToDevice, Ln.s));
+    RPR_HIP(hipStreamSynchronize(Ln.s));              // the host vectors go out of scope
+    w.wc_model = m; w.wc_nseg = (int)segs.size(); w.wc_tiles = tiles;
+  }
+  Ln.run(RPR_K_OTHER, 0, 8.0 * (double)m->params_total, [&] {
+    return launch_weights_bf16(P<WSeg>(w.wseg), P<int>(w.wpref), w.wc_nseg, w.wc_tiles, w.wc.p, w.wcT.p, Ln.s);
+  });
+  return Ln.err;
+}
+
 struct Bwd {
   Launcher& Ln; rpr_ctx* c; TrainWs& w; const Dims& D;
+  // RPR_TRAIN_DW_SPLITK=1: one side stream, split-K over the rows + a reduce pass per weight gradient; =0: NSIDE streams,
+  // one K-loop per tile
+  // (measured, t5-base bz 128: bf16 32.4 ms whole-K vs 32.7 split-K; f16x2 56.3 vs 52.3 — a lone 256 x 256 block walks
+  // 256 K-tiles of the two-plane operands in 670 us and the four streams fall behind the main chain — so the split-precision
+  // mode keeps the split-K route by default)
+  bool whole_k() const {
+    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_SPLITK"); return e ? atoi(e) : -1; }();
+    return v < 0 ? c->precision == RPR_PREC_BF16 : v == 0;
+  }
   // dX[M, K] = dY[M, N] W[N, K]  and  dW[N, K] = dY[M, N]^T X[M, K]  (dX may alias X: X is consumed first)
-  void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K) {
+  void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K, const void* saved_xt = nullptr) {
     const int Mp = pad32(M);
     hipStream_t s = Ln.s;
     if (c->precision == RPR_PREC_BF16) {
       // bf16 operands (see gemm()): one read of dY gives its plain and its transposed copy; dW on the side stream.
       // The bf16 kernel walks K in tiles of 64: the reduction length of the dW product (the rows) is padded to 64.
       const int Mp = (M + 63) & ~63;
-      const int f = w.flip; w.flip ^= 1;
-      void *py = w.tA.p, *pyt = f ? w.tC2.p : w.tC.p, *pxt = f ? w.tB2.p : w.tB.p, *pwt = w.wT.p;
+      const int f = w.flip; w.flip = (w.flip + 1) % TrainWs::NSIDE;
+      hipStream_t side = whole_k() ? w.side[f] : w.side[0];
+      void *py = w.tA.p, *pyt = w.tC[f].p;
+      const void *pxt = w.tB[f].p, *pwt = w.wT.p;
       if (w.done_pending[f]) {
         if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = false;
       }
       Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s); });
-      Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16_T(X, M, K, K, Mp, pxt, nullptr, s); });
-      Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16_T(W, N, K, K, N, pwt, nullptr, s); });
-      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(w.side, w.ev_fork[f], 0) != hipSuccess) {
+      if (saved_xt) pxt = saved_xt;                       // left behind by the forward pass
+      else Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16_T(X, M, K, K, Mp, w.tB[f].p, nullptr, s); });
+      auto wit = w.wc_off.find(W);
+      if (wit != w.wc_off.end() && w.wcT.p) pwt = reinterpret_cast<const __half*>(w.wcT.p) + wit->second;   // once per step
+      else Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16_T(W, N, K, K, N, w.wT.p, nullptr, s); });
+      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_fork[f], 0) != hipSuccess) {
         Ln.err = RPR_ERR_HIP; return;
       }
       static const bool side_on_b = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
       {
-        Launcher L2{c, side_on_b ? w.side : s};
-        gemm_bf16(L2, pyt, Mp, pxt, Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2);
+        Launcher L2{c, side_on_b ? side : s};
+        gemm_bf16(L2, pyt, Mp, pxt, Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
         if (L2.err) { Ln.err = L2.err; return; }
-        if (hipEventRecord(w.ev_done[f], side_on_b ? w.side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        if (hipEventRecord(w.ev_done[f], side_on_b ? side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = true;
       }
       gemm_bf16(Ln, py, N, pwt, N, dX, K, M, K, N, nullptr, 0);
@@ -215,9 +335,10 @@ struct Bwd {
       // from the fp32 weight
       float* am = amax_slots(c, 3);
       if (!am) { Ln.err = RPR_ERR_INVALID; return; }
-      const int f = w.flip; w.flip ^= 1;
-      __half *py = P<__half>(w.tA), *pyt = P<__half>(f ? w.tC2 : w.tC), *pxt = P<__half>(f ? w.tB2 : w.tB), *pwt = P<__half>(w.wT);
-      if (w.done_pending[f]) {   // the dW product that last read this scratch set (two calls ago) must be over
+      const int f = w.flip; w.flip = (w.flip + 1) % TrainWs::NSIDE;
+      hipStream_t side = whole_k() ? w.side[f] : w.side[0];
+      __half *py = P<__half>(w.tA), *pyt = P<__half>(w.tC[f]), *pxt = P<__half>(w.tB[f]), *pwt = P<__half>(w.wT);
+      if (w.done_pending[f]) {   // the dW product that last read this scratch set (NSIDE calls ago) must be over
         if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = false;
       }
@@ -234,23 +355,23 @@ struct Bwd {
       Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_split_dyn_T(X, M, K, K, Mp, pxt, nullptr, am_x, s); });
       Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_split_dyn_T(W, N, K, K, N, pwt, nullptr, am_w, s); });
       // dW on the side stream, dX on the main one
-      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(w.side, w.ev_fork[f], 0) != hipSuccess) {
+      if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_fork[f], 0) != hipSuccess) {
         Ln.err = RPR_ERR_HIP; return;
       }
       static const bool side_on = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
       {
-        Launcher L2{c, side_on ? w.side : s};
-        gemm_planes(L2, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0, &w.part2);
+        Launcher L2{c, side_on ? side : s};
+        gemm_planes(L2, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
         if (L2.err) { Ln.err = L2.err; return; }
-        if (hipEventRecord(w.ev_done[f], side_on ? w.side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+        if (hipEventRecord(w.ev_done[f], side_on ? side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = true;
       }
       gemm_planes(Ln, {py, (size_t)M * N, N, am}, {pwt, (size_t)K * N, N, am_w}, dX, K, M, K, N, nullptr, 0);
       return;
     }
     Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_transpose_pad(dY, P<float>(w.tA), M, N, N, Mp, s); });
-    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB), M, K, K, Mp, s); });
-    gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB), Mp, dW, K, N, K, Mp);
+    Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_transpose_pad(X, P<float>(w.tB[0]), M, K, K, Mp, s); });
+    gemm(Ln, P<float>(w.tA), Mp, P<float>(w.tB[0]), Mp, dW, K, N, K, Mp);
     Ln.run(RPR_K_OTHER, 0, 8.0 * N * K, [&] { return launch_transpose_pad(W, P<float>(w.wT), N, K, K, N, s); });
     gemm(Ln, dY, N, P<float>(w.wT), N, dX, K, M, K, N);
   }
@@ -280,15 +401,18 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.in_idx, R * 4); E(w.out_idx, R * 4); E(w.tok_idx, T * 4);
   E(w.h, rows * dm * f); E(w.dxa, rows * dm * f); E(w.dxb, rows * dm * f); E(w.dbig, rows * wide * f);
   E(w.dattn, rows * inner * f); E(w.dxkv, T * (size_t)D.xld * f); E(w.denc, T * dm * f);
-  E(w.tA, wide * rp * f); E(w.tB, wide * rp * f); E(w.tC, wide * rp * f); E(w.tB2, wide * rp * f); E(w.tC2, wide * rp * f);
+  E(w.tA, wide * rp * f);
+  // the transposed operands of a weight-gradient product (fp32, two f16 planes or bf16), one set per side stream
+  for (int i = 0; i < TrainWs::NSIDE; ++i) { E(w.tB[i], wide * rp * f); E(w.tC[i], wide * rp * f); }
+  if (c->precision == RPR_PREC_BF16) E(w.xT, XtLayout(D).total * sizeof(__half));
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
   E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2); E(w.part2, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats per stream
-  if (!e && !w.side) {
-    RPR_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+  if (!e && !w.side[0]) {
+    for (int i = 0; i < TrainWs::NSIDE; ++i) {
+      RPR_HIP(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking));
       RPR_HIP(hipEventCreateWithFlags(&w.ev_fork[i], hipEventDisableTiming));
       RPR_HIP(hipEventCreateWithFlags(&w.ev_done[i], hipEventDisableTiming));
     }
@@ -323,6 +447,7 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   auto norm = [&](const float* x, const float* ln, float* out, int rows, float post = 1.0f) {
     Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * dm, [&] { return launch_rmsnorm(x, ln, out, rows, dm, D.eps, s, post); });
   };
+  const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(mask, last, D.bz, D.Lq, s, c->status + 1); });
   // ---- encoder over the padded [bz, Lq] layout (padded positions get no gradient: nothing downstream reads them)
   float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
@@ -331,17 +456,17 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
     EncAct a = enc_act(w, D, i);
     float* xnext = i + 1 < D.ne ? enc_act(w, D, i + 1).x : xe_last;
     norm(a.x, m->enc_ln0[i], h, T);
-    gemm(Ln, h, dm, m->enc_qkv[i], dm, a.qkv, 3 * inner, T, 3 * inner, dm);
+    gemm(Ln, h, dm, m->enc_qkv[i], dm, a.qkv, 3 * inner, T, 3 * inner, dm, nullptr, 0, xt.enc(i, XT_QKV));
     EncAttnArgs ea{a.qkv, mask, d.enc_rel_bias, m->enc_bucket, a.attn, D.bz, D.Lq, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
                    nullptr, 0};
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(ea, s); });
-    gemm(Ln, a.attn, inner, m->enc_o[i], inner, a.xm, dm, T, dm, inner, a.x);
+    gemm(Ln, a.attn, inner, m->enc_o[i], inner, a.xm, dm, T, dm, inner, a.x, 0, xt.enc(i, XT_O));
     norm(a.xm, m->enc_ln1[i], h, T);
-    gemm(Ln, h, dm, m->enc_wi[i], dm, a.ff, dff, T, dff, dm, nullptr, 1);
-    gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm);
+    gemm(Ln, h, dm, m->enc_wi[i], dm, a.ff, dff, T, dff, dm, nullptr, 1, xt.enc(i, XT_WI));
+    gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm, 0, xt.enc(i, XT_WO));
   }
   norm(xe_last, d.enc_final_ln, P<float>(w.enc_out), T);
-  gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, dm, P<float>(w.xkv), D.xld, T, D.xld, dm);
+  gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, dm, P<float>(w.xkv), D.xld, T, D.xld, dm, nullptr, 0, xt.xkv());
   // ---- teacher-forced decoder over all positions of the positive and the negative smtid
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_train_indices(codes, P<int32_t>(w.in_idx), P<int32_t>(w.out_idx), D.S, D.L, D.V, s); });
   Ln.run(RPR_K_OTHER, 0, 8.0 * R * dm, [&] { return launch_train_dec_embed(d.start_embed, d.in_embeds, codes, dec_act(w, D, 0).x0, D.S, D.L, dm, D.V, s); });
@@ -349,20 +474,20 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
     DecAct a = dec_act(w, D, i);
     float* xnext = i + 1 < D.nd ? dec_act(w, D, i + 1).x0 : P<float>(w.x_last);
     norm(a.x0, m->dec_ln0[i], h, R);
-    gemm(Ln, h, dm, m->dec_qkv[i], dm, a.qkv, 3 * inner, R, 3 * inner, dm);
+    gemm(Ln, h, dm, m->dec_qkv[i], dm, a.qkv, 3 * inner, R, 3 * inner, dm, nullptr, 0, xt.dec(i, XT_QKV));
     EncAttnArgs sa{a.qkv, nullptr, d.dec_rel_bias, m->dec_bucket, a.a0, D.S, D.L, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
                    nullptr, 1};
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(sa, s); });
-    gemm(Ln, a.a0, inner, m->dec_o[i], inner, a.x1, dm, R, dm, inner, a.x0);
+    gemm(Ln, a.a0, inner, m->dec_o[i], inner, a.x1, dm, R, dm, inner, a.x0, 0, xt.dec(i, XT_O));
     norm(a.x1, m->dec_ln1[i], h, R);
-    gemm(Ln, h, dm, m->dec_xq[i], dm, a.qx, inner, R, inner, dm);
+    gemm(Ln, h, dm, m->dec_xq[i], dm, a.qx, inner, R, inner, dm, nullptr, 0, xt.dec(i, XT_XQ));
     const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
     DecCrossAttnArgs ca{a.qx, xk, xk + inner, D.xld, mask, a.a1, D.bz, 2 * D.L, D.H, D.Lq, nullptr, 0, last, nullptr, 0, nullptr};
     Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] { return launch_dec_cross_attn(ca, s); });
-    gemm(Ln, a.a1, inner, m->dec_xo[i], inner, a.x2, dm, R, dm, inner, a.x1);
+    gemm(Ln, a.a1, inner, m->dec_xo[i], inner, a.x2, dm, R, dm, inner, a.x1, 0, xt.dec(i, XT_XO));
     norm(a.x2, m->dec_ln2[i], h, R);
-    gemm(Ln, h, dm, m->dec_wi[i], dm, a.ff, dff, R, dff, dm, nullptr, 1);
-    gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2);
+    gemm(Ln, h, dm, m->dec_wi[i], dm, a.ff, dff, R, dff, dm, nullptr, 1, xt.dec(i, XT_WI));
+    gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2, 0, xt.dec(i, XT_WO));
   }
   Ln.run(RPR_K_OTHER, 0, 0, [&] {
     return launch_gold_scores(P<float>(w.x_last), d.dec_final_ln, d.out_embeds, codes, P<float>(w.scores), D.S, D.L, dm, D.V, D.eps,
@@ -395,8 +520,11 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     }
     hipEvent_t e0 = w.bucket_ev[(size_t)2 * hook->next], e1 = w.bucket_ev[(size_t)2 * hook->next + 1];
     ++hook->next;
-    if (hipEventRecord(e0, s) != hipSuccess || hipStreamWaitEvent(hook->comm, e0, 0) != hipSuccess ||
-        hipEventRecord(e1, w.side) != hipSuccess || hipStreamWaitEvent(hook->comm, e1, 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    (void)e1;
+    if (hipEventRecord(e0, s) != hipSuccess || hipStreamWaitEvent(hook->comm, e0, 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    // ... and for the weight gradients in flight: the last product of every side stream (stream order covers the earlier ones)
+    for (int i = 0; i < TrainWs::NSIDE; ++i)
+      if (w.done_pending[i] && hipStreamWaitEvent(hook->comm, w.ev_done[i], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
     hook->cb(hook->user, (int64_t)off, (int64_t)numel);
   };
   auto layer_numel = [&](int first_kind, int last_kind, int layer) {
@@ -406,6 +534,8 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   };
   const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff, H = D.H;
   Bwd B{Ln, c, w, D};
+  const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
+  const bool saved = xt.base != nullptr;   // the normalised inputs are only recomputed for their weight-gradient products
   auto g = [&](int kind, int layer = -1) { return G + param_offset(m, kind, layer); };
   float *dxa = P<float>(w.dxa), *dxb = P<float>(w.dxb), *dbig = P<float>(w.dbig), *dattn = P<float>(w.dattn), *h = P<float>(w.h);
   unsigned long long* fix = P<unsigned long long>(w.fix);
@@ -425,14 +555,14 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   for (int i = D.nd - 1; i >= 0; --i) {
     DecAct a = dec_act(w, D, i);
     // feed-forward: x3 = x2 + relu(norm(x2) Wi^T) Wo^T
-    B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff);
+    B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff, xt.dec(i, XT_WO));
     Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
-    B.norm(a.x2, m->dec_ln2[i], R);
-    B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm);                       // dh into the (now free) h buffer
+    if (!saved) B.norm(a.x2, m->dec_ln2[i], R);
+    B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm, xt.dec(i, XT_WI));     // dh into the (now free) h buffer
     B.norm_bwd(a.x2, m->dec_ln2[i], h, dx, dx2, g(K_DEC_LN2, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x2
     // cross-attention: x2 = x1 + CrossAttn(norm(x1) Wq^T, Kx, Vx) Wo^T
-    B.dxdw(dx, m->dec_xo[i], a.a1, dattn, g(K_DEC_XO, i), R, dm, inner);
+    B.dxdw(dx, m->dec_xo[i], a.a1, dattn, g(K_DEC_XO, i), R, dm, inner, xt.dec(i, XT_XO));
     {
       const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
       float* dxk = P<float>(w.dxkv) + (size_t)i * 2 * inner;
@@ -440,18 +570,18 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
         return launch_cross_attn_bwd(a.qx, xk, xk + inner, D.xld, mask, dattn, dbig, dxk, dxk + inner, D.bz, 2 * D.L, D.Lq, H, s);
       });
     }
-    B.norm(a.x1, m->dec_ln1[i], R);
-    B.dxdw(dbig, m->dec_xq[i], h, h, g(K_DEC_XQ, i), R, inner, dm);
+    if (!saved) B.norm(a.x1, m->dec_ln1[i], R);
+    B.dxdw(dbig, m->dec_xq[i], h, h, g(K_DEC_XQ, i), R, inner, dm, xt.dec(i, XT_XQ));
     B.norm_bwd(a.x1, m->dec_ln1[i], h, dx, dx2, g(K_DEC_LN1, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x1
     // self-attention: x1 = x0 + SelfAttn(norm(x0) Wqkv^T) Wo^T
-    B.dxdw(dx, m->dec_o[i], a.a0, dattn, g(K_DEC_O, i), R, dm, inner);
+    B.dxdw(dx, m->dec_o[i], a.a0, dattn, g(K_DEC_O, i), R, dm, inner, xt.dec(i, XT_O));
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
       return launch_self_attn_bwd(a.qkv, dattn, nullptr, d.dec_rel_bias, m->dec_bucket, dbig, P<float>(w.bias_part), g(K_DEC_REL), D.S,
                                   D.L, H, d.rel_buckets, 1, s);
     });
-    B.norm(a.x0, m->dec_ln0[i], R);
-    B.dxdw(dbig, m->dec_qkv[i], h, h, g(K_DEC_QKV, i), R, 3 * inner, dm);
+    if (!saved) B.norm(a.x0, m->dec_ln0[i], R);
+    B.dxdw(dbig, m->dec_qkv[i], h, h, g(K_DEC_QKV, i), R, 3 * inner, dm, xt.dec(i, XT_QKV));
     B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
     { const auto b = layer_numel(K_DEC_LN0, K_DEC_WO, i); bucket(b.first, b.second); }
@@ -462,25 +592,25 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_sum_selected_rows(dx, P<int32_t>(w.in_idx), g(K_START), R, dm, s); });
   // ---- cross K/V projection and the encoder's final norm
   float* denc = P<float>(w.denc);
-  B.dxdw(P<float>(w.dxkv), d.dec_xkv, P<float>(w.enc_out), denc, g(K_XKV), T, D.xld, dm);
+  B.dxdw(P<float>(w.dxkv), d.dec_xkv, P<float>(w.enc_out), denc, g(K_XKV), T, D.xld, dm, xt.xkv());
   float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
   B.norm_bwd(xe_last, d.enc_final_ln, denc, nullptr, dxa, g(K_ENC_FLN), T);
   dx = dxa; dx2 = dxb;
   for (int i = D.ne - 1; i >= 0; --i) {
     EncAct a = enc_act(w, D, i);
-    B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff);
+    B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff, xt.enc(i, XT_WO));
     Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
-    B.norm(a.xm, m->enc_ln1[i], T);
-    B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm);
+    if (!saved) B.norm(a.xm, m->enc_ln1[i], T);
+    B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm, xt.enc(i, XT_WI));
     B.norm_bwd(a.xm, m->enc_ln1[i], h, dx, dx2, g(K_ENC_LN1, i), T);
     std::swap(dx, dx2);
-    B.dxdw(dx, m->enc_o[i], a.attn, dattn, g(K_ENC_O, i), T, dm, inner);
+    B.dxdw(dx, m->enc_o[i], a.attn, dattn, g(K_ENC_O, i), T, dm, inner, xt.enc(i, XT_O));
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] {
       return launch_self_attn_bwd(a.qkv, dattn, mask, d.enc_rel_bias, m->enc_bucket, dbig, P<float>(w.bias_part), g(K_ENC_REL), D.bz,
                                   D.Lq, H, d.rel_buckets, 0, s);
     });
-    B.norm(a.x, m->enc_ln0[i], T);
-    B.dxdw(dbig, m->enc_qkv[i], h, h, g(K_ENC_QKV, i), T, 3 * inner, dm);
+    if (!saved) B.norm(a.x, m->enc_ln0[i], T);
+    B.dxdw(dbig, m->enc_qkv[i], h, h, g(K_ENC_QKV, i), T, 3 * inner, dm, xt.enc(i, XT_QKV));
     B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
     std::swap(dx, dx2);
     { const auto b = layer_numel(K_ENC_LN0, K_ENC_WO, i); bucket(b.first, b.second); }
@@ -489,7 +619,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_scatter_rows_fix(dx, ids, fix, T, dm, s); });
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_fix_flush(fix, g(K_SHARED), (size_t)d.vocab_size * dm, s); });
   // the weight gradients still in flight on the side stream belong to this pass: join
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TrainWs::NSIDE; ++i)
     if (w.done_pending[i]) {
       if (hipStreamWaitEvent(s, w.ev_done[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;
       w.done_pending[i] = false;
@@ -499,16 +629,25 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
 
 }  // namespace
 
+void rpr::train_forget_model(rpr_ctx* c, const rpr_model* m) {
+  if (c && c->tws && c->tws->wc_model == m) { c->tws->wc_model = nullptr; c->tws->wc_off.clear(); }
+}
+
 void rpr::free_train_ws(rpr_ctx* c) {
   if (!c->tws) return;
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
-                   &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.tB, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.tC, &w.part, &w.tB2, &w.tC2, &w.part2};
+                   &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.wT, &w.w_part, &w.bias_part,
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
-  for (int i = 0; i < 2; ++i) { if (w.ev_fork[i]) (void)hipEventDestroy(w.ev_fork[i]); if (w.ev_done[i]) (void)hipEventDestroy(w.ev_done[i]); }
+  for (int i = 0; i < TrainWs::NSIDE; ++i) {
+    if (w.tB[i].p) (void)hipFree(w.tB[i].p);
+    if (w.tC[i].p) (void)hipFree(w.tC[i].p);
+    if (w.ev_fork[i]) (void)hipEventDestroy(w.ev_fork[i]);
+    if (w.ev_done[i]) (void)hipEventDestroy(w.ev_done[i]);
+    if (w.side[i]) (void)hipStreamDestroy(w.side[i]);
+  }
   for (hipEvent_t e : w.bucket_ev) (void)hipEventDestroy(e);
-  if (w.side) (void)hipStreamDestroy(w.side);
   delete c->tws;
   c->tws = nullptr;
 }
@@ -567,6 +706,12 @@ int rpr_lngknp_backward_buckets(rpr_ctx* c, rpr_model* m, const int32_t* input_i
   RPR_HIP(hipMemsetAsync(w.fix.p, 0, w.fix.cap, s));
   Launcher Ln{c, s};
   amax_reset(Ln);
+  if (c->precision == RPR_PREC_BF16) {
+    e = refresh_weight_cache(Ln, c, m);
+    if (e) return e;
+  } else {
+    w.wc_off.clear(); w.wc_model = nullptr;   // the other modes convert per call
+  }
   forward(Ln, c, m, D, input_ids, attention_mask, doc_codes, P<int32_t>(c->ws.last));
   if (Ln.err) return Ln.err;
   RPR_HIP(launch_margin_mse(P<float>(w.scores), teacher_pos, teacher_neg, prefix_lens, n_prefix, bz, L, out_losses, P<float>(w.margins), s));

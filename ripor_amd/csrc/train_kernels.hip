@@ -900,6 +900,51 @@ hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, voi
   return hipGetLastError();
 }
 
+// Every GEMM weight of the model in one launch: plain bf16 copy [N][K] (forward operand) and transposed copy [K][N]
+// (operand of the input-gradient product), both at the tensor's offset in the flat parameter layout. Block -> tensor by
+// binary search over the prefix sums of the tensors' 64 x 64 tile counts.
+__global__ __launch_bounds__(256) void weights_bf16_kernel(const WSeg* __restrict__ segs, const int* __restrict__ pref, int nseg,
+                                                            __bf16* __restrict__ plain, __bf16* __restrict__ tr) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pref[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const WSeg sg = segs[lo];
+  const int t = b - pref[lo], tc = (sg.C + 63) >> 6;
+  const int c0 = (t % tc) * 64, r0 = (t / tc) * 64, R = sg.R, C = sg.C;
+  __bf16* out_p = plain + sg.off;
+  __bf16* out_t = tr + sg.off;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = (tid >> 4) + 16 * k, c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < R && c0 + c < C) {
+      v = *reinterpret_cast<const float4*>(sg.src + (size_t)(r0 + r) * C + c0 + c);
+      __bf16 q[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<uint2*>(out_p + (size_t)(r0 + r) * C + c0 + c) = *reinterpret_cast<uint2*>(q);
+    }
+    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = (tid >> 5) + 8 * k, r = (tid & 31) * 2;        // R % 2 == 0
+    if (c0 + c < C && r0 + r < R) {
+      __bf16 q[2] = {(__bf16)tile[r][c], (__bf16)tile[r + 1][c]};
+      *reinterpret_cast<unsigned int*>(out_t + (size_t)(c0 + c) * R + r0 + r) = *reinterpret_cast<unsigned int*>(q);
+    }
+  }
+}
+hipError_t launch_weights_bf16(const WSeg* segs, const int* pref, int nseg, int ntiles, void* plain, void* tr, hipStream_t s) {
+  if (nseg <= 0 || ntiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(weights_bf16_kernel, dim3(ntiles), dim3(256), 0, s, segs, pref, nseg, reinterpret_cast<__bf16*>(plain),
+                     reinterpret_cast<__bf16*>(tr));
+  return hipGetLastError();
+}
+
 hipError_t init_train_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(self_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;

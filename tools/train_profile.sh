@@ -22,4 +22,5 @@ for pat in ("absmax2", "split_dyn_T", "gemm_h2_dma_kernel<128, 64", "gemm_h2_dma
     for gx, gy, n, avg, tot in rows:
         print(f"   grid {gx:>8} x {gy:<4} n={n:5d} avg {avg/1e3:8.1f} us total {tot/1e6:8.2f} ms")
 PY
+python tools/train_streams.py "$f"
 rm -rf $out/prof
