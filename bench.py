@@ -171,6 +171,18 @@ def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=2):
     return out
 
 
+def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
+    """One query in flight: the headline beam (10) and the reference script's literal setting (full_evaluate_t5seq_aq_encoder.sh
+    runs evaluate.py with --batch_size 1 --topk 1000): ms per query, every search a hipGraph replay."""
+    out = {"workload": f"t5-base dims, {trie.N}-doc trie, len={L}, 1 query per search", "unit": "ms/query"}
+    batches = _query_batches(synth, dims, 1, 4, dev, seed=303)
+    for beams in (10, 1000):
+        (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, beams, L, steps, warmup=2))
+        out[f"beams{beams}"] = {"value": dt * 1e3, "forks_last_step": ctx.last_fork_stats(), "leftover_fallback_taken": fb,
+                                "valid_leaves": f"{int((r.row_hi > r.row_lo).sum().item())}/{beams}"}
+    return out
+
+
 def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=3):
     """the training-data generation callers (evaluate.py:134-178; full_evaluate_t5seq_aq_encoder.sh:117-147):
     the same search at max_new_token 4 / 8 / 16 with topk = 100."""
@@ -303,10 +315,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--secondary", default="train,config4,f2,skew",
+    ap.add_argument("--secondary", default="train,config4,f2,skew,latency",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
-                         "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie); '' = none. config4 / f2 / "
-                         "skew run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
+                         "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
+                         "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
     ap.add_argument("--no-lanes", action="store_true",
                     help="one stream for the whole batch instead of two half batches on two CU-masked streams")
     ap.add_argument("--forced-tail", type=int, default=2, choices=[0, 1, 2], dest="forced_tail",
@@ -662,7 +674,7 @@ def main():
             sec[name] = {"error": repr(e)}
         if rank == 0:
             log(f"[bench] secondary {name}: {time.time() - t0:.1f}s -> "
-                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8")}))
+                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000")}))
 
     if "train" in legs:
         leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank))
@@ -673,6 +685,8 @@ def main():
             leg("f2", lambda: secondary_f2(E, synth, ctx, model, trie, dims, dev))
         if "skew" in legs:
             leg("skew", lambda: secondary_skew(E, synth, ctx, model, dims, dev, args.docs, B, L, V, Q))
+        if "latency" in legs and args.model == "t5-base":
+            leg("latency", lambda: secondary_latency(E, synth, ctx, model, trie, dims, dev, L))
         if "config4" in legs and args.model == "t5-base":
             leg("config4", lambda: secondary_config4(E, synth, ctx, trie, dev, L))
     if rank == 0:

@@ -287,12 +287,19 @@ struct Bwd {
   Launcher& Ln; rpr_ctx* c; TrainWs& w; const Dims& D;
   // RPR_TRAIN_DW_SPLITK=1: one side stream, split-K over the rows + a reduce pass per weight gradient; =0: NSIDE streams,
   // one K-loop per tile
-  // (measured, t5-base bz 128: bf16 32.4 ms whole-K vs 32.7 split-K; f16x2 56.3 vs 52.3 — a lone 256 x 256 block walks
-  // 256 K-tiles of the two-plane operands in 670 us and the four streams fall behind the main chain — so the split-precision
-  // mode keeps the split-K route by default)
-  bool whole_k() const {
-    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_SPLITK"); return e ? atoi(e) : -1; }();
-    return v < 0 ? c->precision == RPR_PREC_BF16 : v == 0;
+  // Measured, t5-base bz 128: bf16 32.4 ms whole-K on 2-4 streams vs 32.7 split-K on one; f16x2 56.3 vs 52.3 (a lone
+  // 256 x 256 block walks 256 K-tiles of the two-plane operands in 670 us and the side streams fall behind the main chain).
+  // And once the search path's two CU-masked lane streams exist in the process, a second side stream lands on the main
+  // stream's hardware queue and the step serialises (bf16 50 ms). The split-K route on ONE side stream does not depend on
+  // how the runtime maps streams to queues: it is the default, RPR_TRAIN_DW_SPLITK=0 selects the whole-K route.
+  static bool whole_k() {
+    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_SPLITK"); return e ? atoi(e) : 1; }();
+    return v == 0;
+  }
+  static int side_streams() {   // streams the whole-K products rotate over (the scratch sets always rotate over NSIDE)
+    static const int v = [] { const char* e = getenv("RPR_TRAIN_SIDE_STREAMS"); const int n = e ? atoi(e) : 2;
+                              return n < 1 ? 1 : (n > TrainWs::NSIDE ? TrainWs::NSIDE : n); }();
+    return whole_k() ? v : 1;
   }
   // dX[M, K] = dY[M, N] W[N, K]  and  dW[N, K] = dY[M, N]^T X[M, K]  (dX may alias X: X is consumed first)
   void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K, const void* saved_xt = nullptr) {
@@ -303,7 +310,7 @@ struct Bwd {
       // The bf16 kernel walks K in tiles of 64: the reduction length of the dW product (the rows) is padded to 64.
       const int Mp = (M + 63) & ~63;
       const int f = w.flip; w.flip = (w.flip + 1) % TrainWs::NSIDE;
-      hipStream_t side = whole_k() ? w.side[f] : w.side[0];
+      hipStream_t side = whole_k() ? w.side[f % side_streams()] : w.side[0];
       void *py = w.tA.p, *pyt = w.tC[f].p;
       const void *pxt = w.tB[f].p, *pwt = w.wT.p;
       if (w.done_pending[f]) {
@@ -336,7 +343,7 @@ struct Bwd {
       float* am = amax_slots(c, 3);
       if (!am) { Ln.err = RPR_ERR_INVALID; return; }
       const int f = w.flip; w.flip = (w.flip + 1) % TrainWs::NSIDE;
-      hipStream_t side = whole_k() ? w.side[f] : w.side[0];
+      hipStream_t side = whole_k() ? w.side[f % side_streams()] : w.side[0];
       __half *py = P<__half>(w.tA), *pyt = P<__half>(w.tC[f]), *pxt = P<__half>(w.tB[f]), *pwt = P<__half>(w.wT);
       if (w.done_pending[f]) {   // the dW product that last read this scratch set (NSIDE calls ago) must be over
         if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
@@ -412,7 +419,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2); E(w.part2, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats per stream
   if (!e && !w.side[0]) {
     for (int i = 0; i < TrainWs::NSIDE; ++i) {
-      RPR_HIP(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking));
+      if (i < Bwd::side_streams()) RPR_HIP(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking));   // only the streams in use
       RPR_HIP(hipEventCreateWithFlags(&w.ev_fork[i], hipEventDisableTiming));
       RPR_HIP(hipEventCreateWithFlags(&w.ev_done[i], hipEventDisableTiming));
     }
