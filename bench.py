@@ -58,6 +58,32 @@ def algorithmic_bytes_per_query(dims, Q, B, L, Lq, s_w=4, s_kv=4):
     return weights + self_r + self_w + cross_r + cross_w + trie + out
 
 
+def algorithmic_forced_tail_per_query(dims, Q, B, L, Lq, T, s_w=4, s_act=4):
+    """The same accounting for the forced-tail algorithm with its (first) fork at depth T: T sequential KV-cached steps as in
+    §8(d), then ONE teacher-forced pass over the B * (L - T) remaining positions — decoder weights read once more per batch,
+    every tail row's q/k/v and attention output written once and read once, the query's cross K/V read once per layer for
+    the whole pass, one gold logit per position. Returns (bytes, flops)."""
+    d, inner, dff = dims.d_model, dims.inner, dims.d_ff
+    ne, nd, V = dims.num_layers, dims.num_decoder_layers, dims.decoder_vocab_sizes[0]
+    T = max(0, min(int(T), L))
+    w_enc = ne * (4 * d * inner + 2 * d * dff)
+    w_xkv = nd * 2 * d * inner
+    w_dec = nd * (6 * d * inner + 2 * d * dff)
+    kvrow = nd * 2 * inner
+    rows = B * (L - T)
+    weights = ((w_enc + w_xkv) * s_w + (T + (1 if rows else 0)) * w_dec * s_w + T * V * d * s_w) / Q
+    steps_kv = B * (T * (T + 1) / 2) * kvrow * s_act + B * T * kvrow * s_act + T * Lq * kvrow * s_act + Lq * kvrow * s_act
+    tail_act = rows * nd * (3 * inner + inner + inner + inner) * s_act * 2     # qkv, self out, cross q, cross out: write + read
+    tail_prefix_kv = B * T * kvrow * s_act                                      # the T cached positions, once per beam
+    tail_cross = (Lq * kvrow * s_act) if rows else 0
+    gold = rows * d * s_w                                                        # one codebook row per position
+    byts = weights + steps_kv + tail_act + tail_prefix_kv + tail_cross + gold + B * T * 40 + B * (4 * L + 4)
+    attn_self = 4 * inner * nd * B * (T * (T + 1) / 2 + (L - T) * T + (L - T) * (L - T + 1) / 2)
+    flops = (2 * w_enc * Lq + 2 * w_xkv * Lq + B * L * 2 * w_dec + B * T * 2 * V * d + rows * 2 * d
+             + 4 * Lq * Lq * inner * ne + attn_self + 4 * inner * nd * B * L * Lq)
+    return byts, flops
+
+
 def algorithmic_flops_per_query(dims, B, L, Lq):
     d, inner, dff = dims.d_model, dims.inner, dims.d_ff
     ne, nd, V = dims.num_layers, dims.num_decoder_layers, dims.decoder_vocab_sizes[0]
@@ -527,9 +553,22 @@ def main():
                        "lanes": ("2 half batches on 2 HIP streams confined to half of the CUs each (rpr_set_lane_split)"
                                  if lanes_on else "1 (whole batch on one stream)")},
             "algorithmic": {"bytes_per_query": abytes, "flops_per_query": aflops, "tokens_per_query": lq_alg,
+                            "formula": "SURVEY.md §8(d): the KV-cached step-by-step algorithm",
                             "hbm_frac_whole_step": abytes * Q / (ms_per_step * 1e-3) / (PEAK_HBM_TBS * 1e12),
-                            "mfma_f32_frac_whole_step": aflops * Q / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
+                            "tflops_whole_step": aflops * Q / (ms_per_step * 1e-3) / 1e12,
+                            "frac_of_f16x3_mfma_peak_whole_step": aflops * Q / (ms_per_step * 1e-3) / (PEAK_F16_MFMA_TFLOPS / 3.0 * 1e12),
+                            "vs_native_f32_mfma_peak": aflops * Q / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                            "note": "vs_native_f32_mfma_peak > 1: the 3-pass f16 split runs fp32-equivalent products faster than "
+                                    "v_mfma_f32_32x32x2_f32 could at its 157 TF/s peak"},
         }
+        fk = out["forced_tail"].get("forks_last_step") or []
+        if args.forced_tail and fk:
+            fb, ff = algorithmic_forced_tail_per_query(dims, Q, B, L, lq_alg, fk[0]["depth"])
+            out["algorithmic"]["forced_tail"] = {
+                "fork_depth": fk[0]["depth"], "bytes_per_query": fb, "flops_per_query": ff,
+                "hbm_frac_whole_step": fb * Q / (ms_per_step * 1e-3) / (PEAK_HBM_TBS * 1e12),
+                "note": "the algorithm the timed region runs (first fork only): fewer bytes than §8(d) — no per-step self-KV "
+                        "re-reads past the fork, the decoder weights streamed fork_depth + 1 times instead of len times"}
         log(f"[bench] timed region done: {value:.1f} queries/s, {ms_per_step:.1f} ms/step")
         if not args.no_roofline:
             def profiled_step():

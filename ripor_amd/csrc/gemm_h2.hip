@@ -287,41 +287,45 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 }
 
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
-template <bool FULL, int TM, int TN, int WM, int WN>
+// SH = rows a wave stages at a time. 64: the strips of the 8 waves fill both operand buffers (128 KB). 32: they fit the
+// SECOND operand buffer alone (stg_off = its offset), which leaves the first one free for the LDS-DMA of the block's next
+// tile while this tile is being stored (persistent ping-pong kernel).
+template <bool FULL, int TM, int TN, int WM, int WN, int SH = 64>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
                                                 int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
-                                                float acc_scale) {
+                                                float acc_scale, int stg_off = 0) {
   constexpr int BM = 256, BN = 256;
   // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
   // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
-  // K = 768. Here each wave stages 64x64 outputs at a time in its private 16 KB of the (now idle)
+  // K = 768. Here each wave stages SH x 64 outputs at a time in its private strip of the (now idle)
   // operand LDS and streams them out row-wise with 16-byte accesses. The epilogue is bound by the NUMBER of
   // memory instructions and by its VALU work, not by bytes (measured: two extra 8-byte plane stores per float4
   // tripled it; ~20 VALU ops per plane element cost ~5 us per tile; a global load of the fused-RMSNorm row scales
   // cost a full memory latency per half), so the f16-plane outputs give a lane 8 consecutive columns = one 16-byte
   // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
   // one max per element plus one compare per half.
-  __syncthreads();                                   // all waves are done reading operand tiles
+  if (SH == 64) __syncthreads();                     // all waves are done reading operand tiles (SH = 32: the caller did it)
   const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
-  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SW);
+  constexpr int NS = TM * 32 / SH;                    // strips per wave
+  float* stg = reinterpret_cast<float*>(smem) + stg_off + wave * (SH * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
-  for (int half = 0; half < TM / 2; ++half) {
+  for (int strip = 0; strip < NS; ++strip) {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < SH / 32; ++ii)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[half * 2 + ii][j][r];
+          stg[(ii * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[strip * (SH / 32) + ii][j][r];
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    const int mrow0 = bm + wm * (BM / WM) + half * 64;
+    const int mrow0 = bm + wm * (BM / WM) + strip * SH;
     if (g.out_h) {
       // ---- f16-plane output (FF intermediate, residual stream): 8 columns per lane, 8 rows per pass
-      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = 64 / RPI;
+      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = SH / RPI;
       const int rrow = lane / LPR, rc8 = (lane % LPR) * 8;
       const int n0 = bn + wn * (BN / WN) + rc8;
       const bool ncol_ok = FULL || (n0 < g.N);          // N % 32 == 0
@@ -336,12 +340,12 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
         }
       }
       const float ps = g.plane_scale;
-      float amax = 0.f;                                 // split_f16's range check: one max per element, one compare per half
+      float amax = 0.f;                                 // split_f16's range check: one max per element, one compare per strip
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         const bool ok = ncol_ok && (FULL || m < Mlim);
-        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : acc_scale;
+        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + strip * SH + rl] : acc_scale;
         // pairs of columns as 2-vectors: gfx950 multiplies / adds / fmas two fp32 per instruction (v_pk_*_f32) and
         // converts two floats to a packed f16 pair in one (v_cvt_pk_f16_f32, round to nearest) — about half the VALU
         // work of the element-by-element form, which also spent a shift + or per pair on packing
@@ -383,7 +387,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       if (amax > 65504.f && g.sat) *g.sat = 1u;
     } else {
       // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes)
-      constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = 64 / RPI;   // lanes per staged row, rows per read instruction
+      constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI;   // lanes per staged row, rows per read instruction
       const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
       const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
       const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
@@ -403,14 +407,14 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       for (int k = 0; k < NK; ++k) {
         const int rl = k * RPI + rrow, m = mrow0 + rl;
         float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + half * 64 + rl] : acc_scale;   // fused RMSNorm row scale
+        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + strip * SH + rl] : acc_scale;   // fused RMSNorm row scale
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
         if (ncol_ok && (FULL || m < Mlim)) *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
       }
     }
-    __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next half
+    __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
   }
 }
 
@@ -430,7 +434,11 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // BF16 = true (training GEMMs, RPR_PREC_BF16): one bf16 plane per operand; the LDS rows of the lo planes hold the NEXT
 // 32 columns of K instead, a K-tile is 64 deep and a phase issues 8 v_mfma_f32_32x32x16_bf16 (slice 0 x slice 0 and
 // slice 1 x slice 1) on the same fragment reads — see gemm_h2_dma_kernel.
-template <bool FULL, bool TRACE = false, bool BF16 = false>
+// PREFETCH = true (persistent launches): before a tile's epilogue the block issues the LDS-DMA of its NEXT tile's first
+// K-tile into operand buffer 0 — the epilogue stages in 32-row strips inside buffer 1 — so the next tile starts with its
+// operands already in LDS instead of waiting out one memory latency with the matrix pipe idle (~3 us of ~78 per tile at
+// K = 768).
+template <bool FULL, bool TRACE = false, bool BF16 = false, bool PREFETCH = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n, int skew_ticks) {
   // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
   // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
@@ -465,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   const int xq = nt >> 3, xr = nt & 7, xcd = blockIdx.x & 7, xk = blockIdx.x >> 3, xstep = ((int)gridDim.x - xcd + 7) >> 3;
   const int chunk0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, chunk_n = xcd < xr ? xq + 1 : xq;
   int round = 0;
+  bool prefetched = false;           // this tile's first K-tile is already on its way into buffer 0 (block-uniform)
   for (int ti = xk; ti < chunk_n; ti += xstep, ++round) {
   if (g.xcd_sync && round > 0) {   // wait (bounded) until every block of this XCD has finished its previous tile
     if (tid == 0) {
@@ -503,20 +512,26 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   int lane_t = lane;
   asm volatile("" : "+v"(lane_t));
   const __half* src[PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int lrow = 16 * (wave + NW * j) + (lane_t >> 2);
-    const int seg = (lane_t & 3) ^ ((lrow >> 2) & 3);
-    const __half* base;
-    int trow, limit;
-    size_t ld;
-    if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM) { base = g.A + (BF16 ? (size_t)HBK : g.a_ps); trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
-    else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
-    else { base = g.W + (BF16 ? (size_t)HBK : g.w_ps); trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
-    if (!FULL && trow >= limit) trow = limit - 1;
-    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;
+#define PP_SRC_SETUP(dst, lane_x, bm_x, bn_x)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j) {                                                              \
+    const int lrow = 16 * (wave + NW * j) + ((lane_x) >> 2);                                                          \
+    const int seg = ((lane_x) & 3) ^ ((lrow >> 2) & 3);                                                               \
+    const __half* base;                                                                                               \
+    int trow, limit;                                                                                                  \
+    size_t ld;                                                                                                        \
+    if (lrow < BM) { base = g.A; trow = (bm_x) + lrow; limit = g.M; ld = g.lda; }                                     \
+    else if (lrow < 2 * BM) { base = g.A + (BF16 ? (size_t)HBK : g.a_ps); trow = (bm_x) + lrow - BM; limit = g.M; ld = g.lda; } \
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = (bn_x) + lrow - 2 * BM; limit = g.N; ld = g.ldw; }              \
+    else { base = g.W + (BF16 ? (size_t)HBK : g.w_ps); trow = (bn_x) + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; } \
+    if (!FULL && trow >= limit) trow = limit - 1;                                                                     \
+    dst[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;                                               \
   }
+  PP_SRC_SETUP(src, lane_t, bm, bn)
+#define PP_PIECE_OF(ptrs, buf, k0, j)                                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptrs[j] + (k0)),            \
+                                   (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
+                                                                             16 * (wave + NW * (j)) * HBK),     \
+                                   16, 0, 0)
 #define PP_PIECE(buf, k0, j)                                                                                   \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (k0)),             \
                                    (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
@@ -606,8 +621,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
   const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
 #define PP_STAMP(slot) if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + (slot)] = __builtin_readcyclecounter(); }
+  if (!PREFETCH || !prefetched) {
 #pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
+    for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
+  }
   __builtin_amdgcn_s_waitcnt(WAIT_ALL);
   __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
   __builtin_amdgcn_sched_barrier(0);
@@ -649,7 +666,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   if (wm == 0) __builtin_amdgcn_s_barrier();         // group 0 catches the extra barrier of group 1
   __builtin_amdgcn_sched_barrier(0);
   PP_TILE_STAMP(2);
-#undef PP_PIECE
 #undef PP_LOAD_W
 #undef PP_LOAD_A
 #undef PP_MFMA
@@ -662,10 +678,30 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 
   int lane_e = lane;   // laundered like lane_t: the epilogue's per-lane offsets must not live through the K-loop
   asm volatile("" : "+v"(lane_e));
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
+  if (PREFETCH) {
+    __syncthreads();                                 // every wave is done reading the operand buffers
+    const int tin = ti + xstep;
+    prefetched = tin < chunk_n && g.ksplit <= 1;
+    if (prefetched) {                                // block-uniform
+      const int nbid = chunk0 + tin, ntm = nbid / tiles_n, ntn = nbid - ntm * tiles_n;
+      int lane_n = lane;
+      asm volatile("" : "+v"(lane_n));
+      const __half* nsrc[PER_WAVE];
+      PP_SRC_SETUP(nsrc, lane_n, ntm * BM, ntn * BN)
+#pragma unroll
+      for (int j = 0; j < PER_WAVE; ++j) PP_PIECE_OF(nsrc, 0, 0, j);
+    }
+    h2_epilogue_256<FULL, TM, TN, WM, WN, 32>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale,
+                                              ROWS * HBK / 2);   // strips in operand buffer 1 (offset in floats)
+  } else {
+    h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
+  }
   __syncthreads();   // the staging strips alias the operand buffers the next tile's LDS-DMA writes; rs_tile is rewritten
   PP_TILE_STAMP(3);
 #undef PP_TILE_STAMP
+#undef PP_PIECE
+#undef PP_PIECE_OF
+#undef PP_SRC_SETUP
   }
 }
 
@@ -843,13 +879,28 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
     hipLaunchKernelGGL(zero_u32x8_kernel, dim3(1), dim3(64), 0, s, ab.xcd_sync);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
   }
+  // RPR_GEMM_PREFETCH=1: blocks that walk several tiles fetch the next tile's first K-tile under the current tile's
+  // epilogue. Measured on the headline (two runs each): 4656 / 4643 q/s with it, 4690 / 4667 without — hiding the ~3 us
+  // prologue does not pay for the 32-row epilogue strips it needs (and the kernel is power-bound: closing an idle gap
+  // mostly lowers the sustained clock). Off by default; parity-tested both ways.
+  static const int prefetch_on = [] { const char* e = getenv("RPR_GEMM_PREFETCH"); return e ? atoi(e) : 0; }();
+  const bool pf = prefetch_on && ks == 1 && grid < nt;
   if (a.bf16) {
-    if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-    else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+    if (pf) {
+      if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+      else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+    } else {
+      if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+      else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+    }
     return hipGetLastError();
   }
   if (full && a.trace)
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
+  else if (pf && full)
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, false, true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
+  else if (pf)
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, false, true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
   else if (full)
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
   else
