@@ -307,3 +307,67 @@ def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
                     assert torch.equal(r.row_lo, ref.row_lo) and torch.equal(r.row_hi, ref.row_hi), (B, ft, lab)
     finally:
         ctx.set_forced_tail(True)
+
+
+def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
+    """Exact float64 ties between candidates are decided by slot / candidate index (select_kernel: ascending flat index;
+    finalize: reverse slot order). Output codebooks with pairwise identical rows (tokens 2k and 2k+1 score the same at every
+    position: ties inside the steps) and, in a second model, all-zero codebooks from position 1 on (every candidate under the
+    best first token ties, up to the final ranking) force those rules
+    through every implementation of them: the step-by-step loop, the forced tail with its single ranking pass (which must
+    detect the ties and replay the steps), the forced replay, and the grouped selection — all must return the same bits."""
+    from ripor_amd.utils import synth
+    L, V, N, B = 12, 256, 40_000, 12
+    codes = synth.make_codes(N, L, V, seed=21)
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    ids, mask = synth.make_queries(6, vocab_size=dims.vocab_size, seed=4, max_len=14)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ctx = E.Context.get(0)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    for variant in ("paired rows", "zero codebooks"):
+        sd = synth.make_state_dict(dims, seed=6)
+        for p in range(L):
+            w = sd[f"list_output_embeds.{p}.weight"]
+            if variant == "paired rows":
+                w[1::2] = w[0::2]
+            elif p >= 1:
+                w[...] = 0.0
+        model = E.DeviceModel(ctx, sd, dims)
+        results = {}
+        try:
+            for name, ft, env in (("plain", False, {}), ("forced", True, {}), ("forced+replay", True, {"RPR_TAIL_RANK_REPLAY": "1"}),
+                                  ("grouped", False, {"RPR_SELECT_GROUPS": "4", "RPR_SELECT_GROUPS_ALL": "1"}),
+                                  ("grouped+forced", True, {"RPR_SELECT_GROUPS": "3", "RPR_SELECT_GROUPS_ALL": "1"})):
+                for k in ("RPR_TAIL_RANK_REPLAY", "RPR_SELECT_GROUPS", "RPR_SELECT_GROUPS_ALL"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                ctx.set_forced_tail(ft)
+                r = E.search(model, trie, ti, tm, B, L)
+                torch.cuda.synchronize()
+                if ft:
+                    st = ctx.last_fork_stats()
+                    assert st and st[0]["forced"] > 0, (variant, name, st)
+                results[name] = r
+        finally:
+            ctx.set_forced_tail(True)
+        ref = results["plain"]
+        live = ref.scores > -1e6
+        tied = int(((ref.scores[:, 1:] == ref.scores[:, :-1]) & live[:, 1:]).sum())
+        if variant == "zero codebooks":
+            assert tied > 0, "no exact ties among the returned scores — the test does not exercise the final tie rule"
+        # The step loop takes its logits from the split-precision GEMM, the tail pass from an exact fp32 dot product: with
+        # non-zero codebooks the two families agree to ~1e-5, not to the bit, so bits are compared inside a family; with the
+        # zero codebooks every tail logit is exactly 0 on both sides and all five paths must agree bit for bit.
+        families = ([("plain", "grouped"), ("forced", "forced+replay", "grouped+forced")] if variant == "paired rows"
+                    else [tuple(results)])
+        for fam in families:
+            base = results[fam[0]]
+            for name in fam[1:]:
+                r = results[name]
+                assert torch.equal(r.tokens[live], base.tokens[live]), (variant, name)
+                assert torch.equal(r.scores[live], base.scores[live]), (variant, name)
+                assert torch.equal(r.row_lo[live], base.row_lo[live]) and torch.equal(r.row_hi[live], base.row_hi[live]), (variant, name)
+        assert float((results["forced"].scores - ref.scores).abs().max()) <= 0.3 * SCORE_TOL
+        print(f"[ties] {variant}: {tied} exactly tied neighbours among {int(live.sum())} returned beams; "
+              f"families compared bit for bit: {families}")
