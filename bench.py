@@ -197,6 +197,52 @@ def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=2):
     return out
 
 
+def board_power_under(run, seconds=2.5):
+    """Board power and shader clock while `run()` keeps the GPU busy (outside every timed region): `rocm-smi --showpower
+    --showclocks --showuse` sampled from a thread. Best effort — None when rocm-smi is missing or prints something else."""
+    import re, shutil, subprocess, threading
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showuse"], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+                sc = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                use = re.search(r"GPU use \(%\): (\d+)", txt)
+                if pw and sc and use:
+                    samples.append((float(pw.group(1)), int(sc.group(1)), int(use.group(1))))
+            except Exception:
+                return
+
+    cap = None
+    try:
+        m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
+                      subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        run()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=6)
+    busy = [x for x in samples if x[2] >= 90]
+    if not busy:
+        return None
+    return {"samples_busy": len(busy), "power_w_mean": sum(b[0] for b in busy) / len(busy), "power_w_max": max(b[0] for b in busy),
+            "power_cap_w": cap, "sclk_mhz_mean": sum(b[1] for b in busy) / len(busy), "sclk_mhz_min": min(b[1] for b in busy),
+            "sclk_mhz_nominal": 2400,
+            "note": "rocm-smi sampled while the headline step repeats (outside the timed region; GPU use >= 90 % samples only): "
+                    "power_w_mean against power_cap_w and sclk_mhz_mean against the 2400 MHz nominal clock say how far DVFS throttles "
+                    "the GEMM-dominated step (default batch: ~1340 W of 1400 W at ~1.85 GHz, profiles/r03e_power_samples.txt)"}
+
+
 def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
     """One query in flight: the headline beam (10) and the reference script's literal setting (full_evaluate_t5seq_aq_encoder.sh
     runs evaluate.py with --batch_size 1 --topk 1000): ms per query, every search a hipGraph replay."""
@@ -681,6 +727,11 @@ def main():
                                                + ("; measured on the unsplit step (whole-chip launches); PMC traffic of "
                                                   "whole-chip launches: profiles/r02f_q2176_hbm_pmc.json" if lanes_on else "")}
                 out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
+        if world == 1 and not args.no_roofline:
+            try:
+                out["board_power"] = board_power_under(lambda: run_step(W))
+            except Exception as e:
+                out["board_power"] = {"error": repr(e)}
         if world == 1 and args.precision != "f32" and not args.no_exact_fp32:
             # secondary figure: the same step on the exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), 1 warm-up + 5 timed
             ctx.set_precision("f32")
