@@ -391,6 +391,8 @@ def main():
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
                          "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
+    ap.add_argument("--log-softmax", action="store_true", dest="log_softmax",
+                    help="apply_log_softmax_for_scores=True (reference generation.py:453-455; not the headline configuration)")
     ap.add_argument("--no-lanes", action="store_true",
                     help="one stream for the whole batch instead of two half batches on two CU-masked streams")
     ap.add_argument("--forced-tail", type=int, default=2, choices=[0, 1, 2], dest="forced_tail",
@@ -487,7 +489,7 @@ def main():
 
     def run_step(i):
         ids, mask, _ = batches[i]
-        return E.search(model, trie, ids, mask, B, L, use_graph=not args.no_graph)
+        return E.search(model, trie, ids, mask, B, L, use_graph=not args.no_graph, apply_log_softmax_for_scores=args.log_softmax)
 
     def timed_region():
         for i in range(W):
@@ -528,7 +530,7 @@ def main():
         for i in range(K):
             ids_d = host_in[i][0].to(dev, non_blocking=True)
             mask_d = host_in[i][1].to(dev, non_blocking=True)
-            r = E.search(model, trie, ids_d, mask_d, B, L, use_graph=not args.no_graph)
+            r = E.search(model, trie, ids_d, mask_d, B, L, use_graph=not args.no_graph, apply_log_softmax_for_scores=args.log_softmax)
             if host_out is None:
                 host_out = [torch.empty(x.shape, dtype=x.dtype).pin_memory() for x in (r.tokens, r.scores, r.row_lo, r.row_hi)]
             for dst, src in zip(host_out, (r.tokens, r.scores, r.row_lo, r.row_hi)):

@@ -237,7 +237,8 @@ int32_t rpr_lane_split(rpr_ctx* ctx);
  * Results are those of the step-by-step loop (generation.py:423-540: float64 cumulative scores, the slot order of every
  * step replayed, sum/(L+1) finalize with ties in reverse slot order); a fork only takes a query whose beams are all
  * live, single-sequence and close enough in score that no masked (-1e9) candidate could be selected (bound on |logit|
- * from the output codebooks, computed at rpr_load_model). Calls with debug taps or RPR_FLAG_LOG_SOFTMAX never fork.
+ * from the output codebooks, computed at rpr_load_model). Calls with debug taps never fork; RPR_FLAG_LOG_SOFTMAX
+ * forks too (the tail pass then computes the V logits of every forced position for the log-sum-exp).
  *   rpr_set_forced_tail(ctx, mode)           0 = off; 1 = exact (default): whoever is still unforced after the last fork
  *                                            walks on to L on the device; 2 = optimistic: when the trie statistics promise
  *                                            an (almost always) empty last stage, it is not enqueued at all (~100 launches

@@ -142,7 +142,7 @@ int flush_profile(rpr_ctx* c) {
 // forks: depths at which forced queries leave the sequential steps (ascending, each in [1, L-1]; empty = plain search)
 // drop_last: no stage after the last fork (optimistic mode, see choose_forks): its caches are not needed
 int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L, const std::vector<int>& forks = {},
-                    bool drop_last = false) {
+                    bool drop_last = false, bool log_softmax = false) {
   const auto& d = m->d;
   const size_t T = (size_t)Q * Lq, R = (size_t)Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff;
   const size_t nd = d.num_decoder_layers, ne = d.num_layers, f = sizeof(float);
@@ -198,6 +198,7 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
     } else {
       E(w.t_x, Rt * dm * f); E(w.t_h, Rt * dm * f); E(w.t_attn, Rt * inner * f); E(w.t_ff, Rt * dff * f);
     }
+    if (log_softmax) { E(w.t_h, Rt * dm * f); E(w.t_logits, Rt * (size_t)d.V * f); }   // normalised rows, V logits per row
   }
   return e;
 }
@@ -452,7 +453,9 @@ StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_t
   // No masked candidate may overtake a valid one during the remaining n = L - T steps. With |logit| <= bound
   // (rpr_model::logit_bound) the valid candidates of a step are >= smin - n*bound and the masked ones
   // <= smax + n*bound - 1e9, so forced requires (smax - smin) + 2*n*bound < 1e9; a tenth of that is demanded.
-  const double spread_max = 1e8 - 2.0 * (double)(L - T) * (double)m->logit_bound;
+  // Log-softmax scores: a step adds a log-probability in [-(2*bound + ln V), 0] instead of a logit in [-bound, bound].
+  const double per_step = (sd.flags & RPR_FLAG_LOG_SOFTMAX) ? 2.0 * (double)m->logit_bound + log((double)d.V) : 2.0 * (double)m->logit_bound;
+  const double spread_max = 1e8 - (double)(L - T) * per_step;
   ForkArgs fa{st, tr->codes, tr->L, Q, sv.nq_dev, B, T, L, spread_max, P<int32_t>(tb.flag)};
   Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_fork_classify(fa, s); });
   Ln.run(RPR_K_FORK, 0, 0, [&] {
@@ -550,10 +553,32 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
     linear(Ln, h2 ? xs.in(3 * i + 2) : in_h, {m->dec_wi[i], m->h_dec_wi[i], dff, dm}, R, o, nrows_dev, Ra);
     linear(Ln, in_ff, {m->dec_wo[i], m->h_dec_wo[i], dm, dff}, R, h2 ? xs.out(3 * i + 3) : out_f32(x, dm, dm, x), nrows_dev, Ra);
   }
-  Ln.run(RPR_K_OTHER, 2.0 * Ra * dm, 4.0 * 2 * Ra * dm, [&] {
-    return launch_tail_gold(x, d.dec_final_ln, d.out_embeds, P<uint16_t>(tb.tokens), P<float>(tb.gold), R, nrows_dev, T, L, dm, V, eps, post,
-                            s, h2 ? xs.x_h : nullptr, ps_d);
-  });
+  if (sd.flags & RPR_FLAG_LOG_SOFTMAX) {
+    // the score of a position is the log-probability of its token: final RMSNorm of every row, the V logits of the rows
+    // of one position per launch of the exact-fp32 GEMM (rows of a position are Lt apart; its codebook is out_embeds[p]),
+    // then log_softmax at the token (tail_logprob_kernel)
+    float* lg = P<float>(w.t_logits);
+    Ln.run(RPR_K_RMSNORM, 0, 2.0 * Ra * dm * 4, [&] {
+      return launch_rmsnorm(x, d.dec_final_ln, h, R, dm, eps, s, post, nullptr, 0, nrows_dev, nullptr, h2 ? xs.x_h : nullptr, ps_d);
+    });
+    for (int p = T; p < L; ++p) {
+      GemmArgs g{};
+      g.A = h + (size_t)(p - T) * dm; g.lda = Lt * dm;
+      g.W = d.out_embeds + (size_t)p * V * dm; g.ldw = dm;
+      for (int i = 0; i < 3; ++i) { g.out[i] = lg + (size_t)(p - T) * V; g.ldo[i] = Lt * V; }
+      g.split_n = V; g.M = S; g.N = V; g.K = dm; g.m_dev = nseq_dev;
+      Ln.run(RPR_K_GEMM_SMALL, 2.0 * (Ra / Lt) * (double)V * dm, 4.0 * ((double)(Ra / Lt) * (dm + V) + (double)V * dm),
+             [&] { return launch_gemm(g, s); });
+    }
+    Ln.run(RPR_K_OTHER, 0, 4.0 * Ra * V, [&] {
+      return launch_tail_logprob(lg, P<uint16_t>(tb.tokens), P<float>(tb.gold), R, nrows_dev, T, L, V, s);
+    });
+  } else {
+    Ln.run(RPR_K_OTHER, 2.0 * Ra * dm, 4.0 * 2 * Ra * dm, [&] {
+      return launch_tail_gold(x, d.dec_final_ln, d.out_embeds, P<uint16_t>(tb.tokens), P<float>(tb.gold), R, nrows_dev, T, L, dm, V, eps, post,
+                              s, h2 ? xs.x_h : nullptr, ps_d);
+    });
+  }
   TailRankArgs ra{sv.st[T & 1], P<int32_t>(tb.flist), P<int32_t>(tb.qmap), nf_dev, P<uint16_t>(tb.tokens), P<float>(tb.gold), Q, B, T, L,
                   P<int32_t>(w.o_tokens), P<float>(w.o_scores), P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
   Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_tail_rank(ra, s); });
@@ -1161,8 +1186,9 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
                               bool* drop_last) {
   std::vector<int> forks;
   *drop_last = false;
-  if (!c->forced_tail || taps || (flags & RPR_FLAG_LOG_SOFTMAX) || L < 3 || !std::isfinite(m->logit_bound)) return forks;
-  if (1e8 - 2.0 * L * (double)m->logit_bound <= 1e7) return forks;   // logits too large for the masked-candidate proof
+  if (!c->forced_tail || taps || L < 3 || !std::isfinite(m->logit_bound)) return forks;
+  const double per_step = 2.0 * (double)m->logit_bound + ((flags & RPR_FLAG_LOG_SOFTMAX) ? log((double)m->d.V) : 0.0);
+  if (1e8 - L * per_step <= 1e7) return forks;   // logits too large for the masked-candidate proof
   if (c->n_fork_override >= 0) {
     int prev = 0;
     for (int i = 0; i < c->n_fork_override; ++i) {
@@ -1217,7 +1243,7 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   if (m->f32_only) c->precision = RPR_PREC_F32;
   bool drop_last = false;
   const std::vector<int> forks = choose_forks(c, m, tr, Q, B, L, flags, taps != nullptr, &drop_last);
-  int e = alloc_workspace(c, m, Q, Lq, B, L, forks, drop_last);
+  int e = alloc_workspace(c, m, Q, Lq, B, L, forks, drop_last, (flags & RPR_FLAG_LOG_SOFTMAX) != 0);
   if (e) return e;
   c->last_forks = forks;
   c->last_ws_mask |= lane >= 0 ? (2 << lane) : 1;
@@ -1294,7 +1320,7 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
       if (m->f32_only) c->precision = RPR_PREC_F32;
       bool drop_last = false;
       const std::vector<int> forks = choose_forks(c, m, tr, Qh[i], B, L, flags, false, &drop_last);
-      const int e = alloc_workspace(c, m, Qh[i], Lq, B, L, forks, drop_last);
+      const int e = alloc_workspace(c, m, Qh[i], Lq, B, L, forks, drop_last, (flags & RPR_FLAG_LOG_SOFTMAX) != 0);
       c->precision = saved_prec;
       std::swap(c->ws, c->lanes[i].ws);
       if (e) return e;

@@ -360,6 +360,9 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_embeds, const uint16_t* tokens, float* gold, int rows,
                             const int* rows_dev, int T, int L, int d, int V, float eps, float post, hipStream_t s,
                             const __half* x_h = nullptr, size_t x_ps = 0);
+// log-softmax mode: gold[row] = log_softmax(logits[row, :])[token of the row]
+hipError_t launch_tail_logprob(const float* logits, const uint16_t* tokens, float* gold, int rows, const int* rows_dev, int T, int L,
+                               int V, hipStream_t s);
 struct TailRankArgs {
   BeamState st;              // the fork stage's beams (scores, ranges)
   const int32_t* flist; const int32_t* qmap; const int* nf_dev;   // qmap: tail query -> query of the call

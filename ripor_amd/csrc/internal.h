@@ -125,6 +125,7 @@ struct Workspace {
   StageBufs stage[MAX_FORKS];
   TailBufs tail[MAX_FORKS];
   DevBuf t_x, t_h, t_qkv, t_q, t_attn, t_ff, t_x_h, t_attn_h, t_ff_h, t_ssq;
+  DevBuf t_logits;        // log-softmax mode: the V logits of every tail row (fp32)
 };
 
 static_assert(sizeof(Workspace) % sizeof(DevBuf) == 0 && std::is_standard_layout<Workspace>::value,

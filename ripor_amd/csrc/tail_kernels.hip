@@ -595,6 +595,34 @@ hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_em
   return hipGetLastError();
 }
 
+// RPR_FLAG_LOG_SOFTMAX: the score of a position is the log-probability of its token (reference generation.py:453-455:
+// log_softmax over the V logits of the position in fp32). One wave per tail row: logits = the row's V exact-fp32 logits
+// (one GEMM per position, api.hip::enqueue_tail), arithmetic as select_kernel's: (x - max) - log(sum exp(x - max)).
+__global__ __launch_bounds__(256) void tail_logprob_kernel(const float* __restrict__ logits, const uint16_t* __restrict__ tokens,
+                                                            float* __restrict__ gold, int rows, const int* __restrict__ rows_dev, int T,
+                                                            int L, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows || row >= *rows_dev) return;
+  const int Lt = L - T, seq = row / Lt, p = T + (row - seq * Lt);
+  const int tok = tokens[(size_t)seq * L + p];
+  const float* lr = logits + (size_t)row * V;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  float sm = 0.f;
+  for (int c = lane; c < V; c += 64) sm += expf(lr[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);      // the reduction order of select_kernel
+  if (lane == 0) gold[row] = (lr[tok] - mx) - logf(sm);
+}
+
+hipError_t launch_tail_logprob(const float* logits, const uint16_t* tokens, float* gold, int rows, const int* rows_dev, int T, int L,
+                               int V, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tail_logprob_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, tokens, gold, rows, rows_dev, T, L, V);
+  return hipGetLastError();
+}
+
 // One block per forced query: replay of the remaining L - T selection steps and the finalize step on the B forced
 // candidates. Per step the B winners are the beams' single valid children; new slot order = (cumulative score desc,
 // parent slot asc) — the sort order of the sequential select_kernel restricted to those candidates. Then
