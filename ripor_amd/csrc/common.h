@@ -427,5 +427,11 @@ hipError_t launch_gold_score_bwd(const float* x, const float* ln, const float* o
 hipError_t launch_grad_norm(const float* g, size_t n, double* part, int nparts, float max_norm, float* out, hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* clip, float lr, float b1, float b2,
                         float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
+// every parameter tensor in one launch: segs[i] = {tensor, offset of its gradient / moments in the flat buffers, elements,
+// decays?}; pref = exclusive prefix sums of ceil(n / 4096)
+struct AdamSeg { float* p; unsigned long long off, n; int decay; };
+hipError_t launch_adamw_multi(const AdamSeg* segs, const int* pref, int nseg, int nchunks, const float* g, float* m, float* v,
+                              const float* clip, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                              hipStream_t s);
 
 }  // namespace rpr

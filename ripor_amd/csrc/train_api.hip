@@ -41,6 +41,9 @@ struct TrainWs {
   // linear layer's input behind — the X^T operand of its weight-gradient product — so the backward pass neither converts
   // X again nor recomputes the normalised inputs it would only need for that
   DevBuf wc, wcT, wseg, wpref, xT;
+  DevBuf aseg, apref;                  // rpr_adamw_step: one launch over all tensors (table built once per model)
+  const rpr_model* aw_model = nullptr;
+  int aw_nseg = 0, aw_chunks = 0;
   const rpr_model* wc_model = nullptr;
   int wc_nseg = 0, wc_tiles = 0;
   std::unordered_map<const float*, size_t> wc_off;
@@ -638,6 +641,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
 
 void rpr::train_forget_model(rpr_ctx* c, const rpr_model* m) {
   if (c && c->tws && c->tws->wc_model == m) { c->tws->wc_model = nullptr; c->tws->wc_off.clear(); }
+  if (c && c->tws && c->tws->aw_model == m) c->tws->aw_model = nullptr;
 }
 
 void rpr::free_train_ws(rpr_ctx* c) {
@@ -645,7 +649,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT, &w.aseg, &w.apref};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < TrainWs::NSIDE; ++i) {
     if (w.tB[i].p) (void)hipFree(w.tB[i].p);
@@ -750,10 +754,35 @@ int rpr_adamw_step(rpr_ctx* c, rpr_model* m, const float* flat_grads, float* exp
   // not an nn.LayerNorm in that version, so the T5 layer-norm weights DO decay; `relative_attention_bias.weight` is
   // excluded by its name. (Restated from memory of transformers 4.17 — its source is not available offline; the
   // reference's default weight_decay is 0, where the rule is moot.)
-  for (const auto& p : m->params) {
-    const float wd = (p.kind == K_ENC_REL || p.kind == K_DEC_REL) ? 0.0f : weight_decay;
-    RPR_HIP(launch_adamw(p.ptr, flat_grads + p.offset, exp_avg + p.offset, exp_avg_sq + p.offset, p.numel, P<float>(w.gn_out), lr, beta1,
-                         beta2, eps, wd, bc1, bc2s, s));
+  static const bool per_tensor = [] { const char* e = getenv("RPR_ADAMW_PER_TENSOR"); return e && atoi(e) != 0; }();
+  if (per_tensor) {
+    for (const auto& p : m->params) {
+      const float wd = (p.kind == K_ENC_REL || p.kind == K_DEC_REL) ? 0.0f : weight_decay;
+      RPR_HIP(launch_adamw(p.ptr, flat_grads + p.offset, exp_avg + p.offset, exp_avg_sq + p.offset, p.numel, P<float>(w.gn_out), lr, beta1,
+                           beta2, eps, wd, bc1, bc2s, s));
+    }
+  } else {
+    if (w.aw_model != m) {   // tensor table: pointer, offset in the flat buffers, elements, decays?
+      std::vector<AdamSeg> segs;
+      std::vector<int> pref;
+      int chunks = 0;
+      for (const auto& p : m->params) {
+        if (!p.numel) continue;
+        segs.push_back(AdamSeg{p.ptr, (unsigned long long)p.offset, (unsigned long long)p.numel,
+                               (p.kind == K_ENC_REL || p.kind == K_DEC_REL) ? 0 : 1});
+        pref.push_back(chunks);
+        chunks += (int)((p.numel + 4095) / 4096);
+      }
+      e = tensure(c, w.aseg, segs.size() * sizeof(AdamSeg));
+      if (!e) e = tensure(c, w.apref, pref.size() * sizeof(int));
+      if (e) return e;
+      RPR_HIP(hipMemcpyAsync(w.aseg.p, segs.data(), segs.size() * sizeof(AdamSeg), hipMemcpyHostToDevice, s));
+      RPR_HIP(hipMemcpyAsync(w.apref.p, pref.data(), pref.size() * sizeof(int), hipMemcpyHostToDevice, s));
+      RPR_HIP(hipStreamSynchronize(s));              // the host vectors go out of scope
+      w.aw_model = m; w.aw_nseg = (int)segs.size(); w.aw_chunks = chunks;
+    }
+    RPR_HIP(launch_adamw_multi(P<AdamSeg>(w.aseg), P<int>(w.apref), w.aw_nseg, w.aw_chunks, flat_grads, exp_avg, exp_avg_sq,
+                               P<float>(w.gn_out), lr, beta1, beta2, eps, weight_decay, bc1, bc2s, s));
   }
   if (out_grad_norm) RPR_HIP(hipMemcpyAsync(out_grad_norm, w.gn_out.p, 4, hipMemcpyDeviceToDevice, s));
   // the search / inference paths read the f16 planes of the weights: they are stale now and are re-split by the next call

@@ -737,6 +737,64 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
   return hipGetLastError();
 }
 
+// The same update for every parameter tensor in ONE launch (189 tensors of t5-base: 189 launches of 9 us before). A block
+// owns one chunk of 4096 consecutive elements of one tensor: block -> tensor by binary search over the prefix sums of the
+// tensors' chunk counts; gradients and moments live at the tensor's offset of the flat buffers.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamSeg* __restrict__ segs, const int* __restrict__ pref, int nseg,
+                                                           const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                           const float* __restrict__ clip, float lr, float b1, float b2, float eps,
+                                                           float wd, float bc1, float bc2_sqrt) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pref[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const AdamSeg sg = segs[lo];
+  const size_t c0 = (size_t)(b - pref[lo]) * 4096;
+  const float decay = 1.f - lr * (sg.decay ? wd : 0.f), cl = clip[1], step = lr / bc1;
+  float* p = sg.p;
+  const float* gs = g + sg.off;
+  float* ms = m + sg.off;
+  float* vs = v + sg.off;
+  auto upd = [&](float pi, float gi, float& mi, float& vi) {
+    gi *= cl;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    pi = pi * decay;
+    pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    return pi;
+  };
+  if (((sg.off | sg.n) & 3) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t i = c0 + ((size_t)k * 256 + threadIdx.x) * 4;
+      if (i >= sg.n) continue;
+      float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(ms + i), vv = *reinterpret_cast<float4*>(vs + i);
+      const float4 gv = *reinterpret_cast<const float4*>(gs + i);
+      pv.x = upd(pv.x, gv.x, mv.x, vv.x); pv.y = upd(pv.y, gv.y, mv.y, vv.y);
+      pv.z = upd(pv.z, gv.z, mv.z, vv.z); pv.w = upd(pv.w, gv.w, mv.w, vv.w);
+      *reinterpret_cast<float4*>(p + i) = pv; *reinterpret_cast<float4*>(ms + i) = mv; *reinterpret_cast<float4*>(vs + i) = vv;
+    }
+  } else {
+    for (int k = 0; k < 16; ++k) {
+      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
+      if (i >= sg.n) continue;
+      float mi = ms[i], vi = vs[i];
+      p[i] = upd(p[i], gs[i], mi, vi);
+      ms[i] = mi; vs[i] = vi;
+    }
+  }
+}
+hipError_t launch_adamw_multi(const AdamSeg* segs, const int* pref, int nseg, int nchunks, const float* g, float* m, float* v,
+                              const float* clip, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                              hipStream_t s) {
+  if (nseg <= 0 || nchunks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, s, segs, pref, nseg, g, m, v, clip, lr, b1, b2, eps, wd, bc1,
+                     bc2_sqrt);
+  return hipGetLastError();
+}
+
 // ---- per-tensor dynamic f16 planes for the training GEMMs ---------------------------------------------------------------
 // Absolute maxima of up to two tensors in one launch (blockIdx.y picks the tensor). The result is combined with an integer
 // atomicMax on the bit pattern (non-negative floats order like unsigned integers; a maximum does not depend on the order
