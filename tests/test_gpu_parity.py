@@ -272,7 +272,9 @@ def test_linear_kernel_against_torch_fp32(engine):
                                     # t5-large shapes (d = 1024, d_ff = 4096): 128-row, skinny and 256x256 kernels
                                     (300, 1024, 1024, False, True), (1000, 4096, 1024, True, False),
                                     (640, 1024, 4096, False, True), (12800, 3072, 1024, False, False),
-                                    (12800, 1024, 4096, False, True), (12800, 4096, 1024, True, False)]:
+                                    (12800, 1024, 4096, False, True), (12800, 4096, 1024, True, False),
+                                    # a little more than a whole number of rounds of 256x256 tiles (270 / 792 / 258 tiles)
+                                    (23040, 768, 768, False, True), (22500, 2304, 768, False, False), (22016, 768, 3072, True, True)]:
         A = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda") * K ** -0.5
         R = torch.randn(M, N, device="cuda") if resid else None
@@ -298,7 +300,7 @@ def test_rmsnorm_kernel_against_torch_fp32(engine):
 
 
 @pytest.mark.parametrize("M,N,K", [(20480, 768, 768), (5120, 2304, 768), (640, 768, 3072), (10, 768, 768), (2050, 832, 768),
-                                   (12800, 1024, 4096), (12800, 4096, 1024)])
+                                   (12800, 1024, 4096), (12800, 4096, 1024), (23040, 768, 768), (22016, 768, 3072)])
 def test_gemm_kernels_are_repeatable_bitwise(engine, M, N, K):
     """Race screen of the three split-precision GEMM kernels (ping-pong 256x256, LDS-DMA 128-row with deep prefetch,
     skinny): LDS-DMA ordering bugs show up as rare timing-dependent wrong tiles, so the same launch is repeated and
