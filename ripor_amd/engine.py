@@ -663,11 +663,23 @@ class GradExchange:
     ring on the point-to-point xGMI mesh wants; any torch.distributed backend works (the CPU tests use gloo).
     With one rank (or no process group) nothing is enqueued."""
 
-    def __init__(self, grads: torch.Tensor, dry_run: bool = False):
+    def __init__(self, grads: torch.Tensor, dry_run: bool = False, mode: Optional[str] = None):
         """``dry_run`` (tests, one rank): take the buckets and touch each slice on the communication stream instead of
-        all-reducing it — the hand-off (callback order, stream dependencies, coverage) without a process group."""
+        all-reducing it — the hand-off (callback order, stream dependencies, coverage) without a process group.
+
+        ``mode`` (default: ``RPR_GRAD_EXCHANGE`` or "allreduce"): "allreduce" = one ``all_reduce`` per bucket, the
+        algorithm is RCCL's choice; "mesh" = the exchange SURVEY §8 f4 asks for on the point-to-point xGMI mesh: every
+        rank owns 1/W of a bucket, receives that shard from all peers at once over the W-1 direct links
+        (``all_to_all_single``), sums the W copies in rank order (every rank adds in the same order: the reduced shard has
+        one value), and the shards are gathered back (``all_gather_into_tensor``) — reduce-scatter + all-gather in two
+        single-hop steps instead of a ring of 2(W-1) per-link-bound steps. Never timed on hardware (no multi-GPU box)."""
+        import os
         import torch.distributed as dist
         self.grads = grads
+        self.mode = (mode or os.environ.get("RPR_GRAD_EXCHANGE", "allreduce")).lower()
+        if self.mode not in ("allreduce", "mesh"):
+            raise ValueError(f"unknown gradient exchange mode {self.mode!r} (allreduce | mesh)")
+        self._scratch = {}                   # mesh mode: send / receive buffers per padded bucket size
         self.dry_run = bool(dry_run)
         self.active = self.dry_run or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.world = dist.get_world_size() if (self.active and not self.dry_run) else 1
@@ -693,9 +705,29 @@ class GradExchange:
             return
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+                self._exchange(sl)
         else:
+            self._exchange(sl)
+
+    def _exchange(self, sl: torch.Tensor):
+        import torch.distributed as dist
+        if self.mode == "allreduce":
             self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        W, n = self.world, sl.numel()
+        per = (n + W - 1) // W
+        if per not in self._scratch:         # a handful of distinct bucket sizes (decoder layer, encoder layer, the rest)
+            self._scratch[per] = (torch.zeros(W * per, dtype=sl.dtype, device=sl.device),
+                                  torch.empty(W * per, dtype=sl.dtype, device=sl.device),
+                                  torch.empty(W * per, dtype=sl.dtype, device=sl.device))
+        send, recv, full = self._scratch[per]
+        send[:n].copy_(sl)                   # the tail of the last shard stays zero
+        dist.all_to_all_single(recv, send, async_op=True).wait()     # recv[i] = rank i's copy of MY shard
+        shard = recv.view(W, per)[0].clone()
+        for i in range(1, W):                # fixed order: bitwise the same sum on every rank for its shard
+            shard += recv.view(W, per)[i]
+        dist.all_gather_into_tensor(full, shard, async_op=True).wait()
+        sl.copy_(full[:n])
 
     def comm_stream_ptr(self):
         return C.c_void_p(self.stream.cuda_stream) if self.stream is not None else None
@@ -768,7 +800,10 @@ def allreduce_grads(state: TrainState, bucket_elems: int = 64 << 20) -> None:
 
 def allreduce_mode() -> str:
     import os
-    return "serial" if os.environ.get("RPR_GRAD_OVERLAP", "1") == "0" else "bucketed, overlapped with the backward pass"
+    if os.environ.get("RPR_GRAD_OVERLAP", "1") == "0":
+        return "serial"
+    how = "all_to_all + all_gather per bucket (mesh)" if os.environ.get("RPR_GRAD_EXCHANGE", "allreduce").lower() == "mesh" else "all_reduce per bucket"
+    return f"bucketed, overlapped with the backward pass, {how}"
 
 
 def train_step(model: DeviceModel, state: TrainState, input_ids, attention_mask, doc_codes, teacher_pos, teacher_neg,

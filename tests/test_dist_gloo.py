@@ -3,6 +3,8 @@ the queries, one all_gather of the ranked results, merge by qid == the single-pr
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -211,15 +213,15 @@ def test_gradient_allreduce_averages_over_ranks():
     assert got == expect
 
 
-def _bucket_worker(rank, world, port, out):
+def _bucket_worker(rank, world, port, out, mode="allreduce"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ripor_amd import engine as E
         n = 1000
         grads = (torch.arange(n, dtype=torch.float32) + 1.0) * (rank + 1)
-        ex = E.GradExchange(grads)
-        assert ex.active and ex.world == 2 and ex.stream is None    # CPU tensors: no communication stream
+        ex = E.GradExchange(grads, mode=mode)
+        assert ex.active and ex.world == world and ex.stream is None    # CPU tensors: no communication stream
         # the order rpr_lngknp_backward_buckets hands the buckets over: layers last to first, then the front of the buffer
         for off, cnt in [(700, 300), (400, 300), (250, 150), (0, 250)]:
             ex.on_bucket(off, cnt)
@@ -239,15 +241,17 @@ def _bucket_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_bucketed_gradient_exchange_averages_over_ranks():
-    """engine.GradExchange (the overlapped exchange of the training step: one asynchronous all-reduce per bucket as the
-    backward hands it over, DDP's averaging at the end) on two gloo ranks."""
+@pytest.mark.parametrize("mode,world", [("allreduce", 2), ("mesh", 2), ("mesh", 3)])
+def test_bucketed_gradient_exchange_averages_over_ranks(mode, world):
+    """engine.GradExchange (the overlapped exchange of the training step: per bucket, as the backward hands it over, either
+    one asynchronous all-reduce or the mesh form — every rank receives its 1/W shard from all peers (all_to_all_single),
+    sums it, the shards are gathered back; buckets that do not divide by W are padded — then DDP's averaging) on gloo ranks."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, out, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = out.get(timeout=120)
@@ -255,5 +259,6 @@ def test_bucketed_gradient_exchange_averages_over_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got == ((torch.arange(1000, dtype=torch.float32) + 1.0) * 1.5).tolist()
+    mean_factor = sum(range(1, world + 1)) / world
+    assert got == ((torch.arange(1000, dtype=torch.float32) + 1.0) * mean_factor).tolist()
     assert refused
