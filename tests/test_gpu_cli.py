@@ -139,3 +139,15 @@ def test_bench_two_ranks_on_one_gpu_through_gloo():
     assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["gather_bytes_per_rank"] > 0
     assert d["value"] > 0 and d["config"]["queries_per_step_per_gpu"] == 64
     print("[bench x2 gloo]", d["value"], d["forced_tail"])
+
+
+@pytest.mark.gpu
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py, 16 seeded random cases (trie size, length, beams, V, skew, duplicates, log-softmax, explicit forks,
+    grouped selection; the small ones also against the CPU oracle): forced tail == step loop, grouped == single block."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_parity.py"), "16", "77"], capture_output=True, text=True,
+                       timeout=900, cwd=repo)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "16 cases passed" in r.stdout
