@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (diagnostic; `python tools/fuzz_parity.py [n_cases] [seed]`): mini-dims models over
-random tries (sizes 300 .. 300 k docs, uniform / skewed codes, duplicated smtids), lengths 4..16, beams 1..100, V 256 / 1024,
+random tries (sizes 300 .. 300 k docs, uniform / skewed codes, duplicated smtids), lengths 4..16, beams 1..1000 (a few cases
+with many beams and 1-2 queries, a few with enough rows for the lane split), V 256 / 1024,
 raw-logit and log-softmax scores. Every case compares
 
   * the forced tail (automatic depths, then random explicit forks, exact and optimistic mode) with the step-by-step loop:
@@ -84,6 +85,11 @@ for case in range(n_cases):                 # every random draw up front, so tha
     Q = rng.randint(1, 24)
     skew, dup, lsm = rng.random() < 0.4, rng.random() < 0.3, rng.random() < 0.3
     seed = rng.randint(1, 10_000)
+    shape = rng.random()
+    if shape < 0.08:        # few queries x many beams: automatic grouped selection, 1024-thread tail ranking
+        B, Q, N, V = rng.choice([256, 500, 1000]), rng.randint(1, 2), rng.choice([60_000, 300_000]), 256
+    elif shape < 0.12:      # >= 10 240 decoder rows: the call runs as two lanes
+        B, Q = 10, rng.randint(1030, 1300)
     d0 = rng.randint(1, max(1, L - 2))
     depths = [d0] + ([rng.randint(d0 + 1, L - 1)] if rng.random() < 0.6 and d0 + 1 <= L - 1 else [])
     params.append((N, L, V, B, Q, skew, dup, lsm, seed, depths))
