@@ -151,3 +151,15 @@ def test_randomised_parity_sweep():
                        timeout=900, cwd=repo)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "16 cases passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_randomised_training_shapes():
+    """tools/fuzz_train.py, 5 seeded random batch shapes (bz, smtid length, ragged query lengths, encoder depth, d_ff) in all
+    three GEMM arithmetics: gradients of rpr_lngknp_backward against torch autograd through the CPU oracle."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_train.py"), "5", "11"], capture_output=True, text=True,
+                       timeout=1200, cwd=repo)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "5 cases passed" in r.stdout
