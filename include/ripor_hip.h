@@ -51,7 +51,8 @@ typedef struct {
   int32_t num_layers, num_decoder_layers;
   int32_t rel_buckets, rel_max_distance;
   int32_t L;                     /* len(config.decoder_vocab_sizes) = max decoder positions      */
-  int32_t V;                     /* decoder_vocab_sizes[i], must be equal for all i (evaluate.py:433) */
+  int32_t V;                     /* decoder_vocab_sizes[i], must be equal for all i (evaluate.py:433); 2..65536 —
+                                  * sizes off the 64 grid are padded internally, only rpr_debug_taps need V % 64 == 0 */
   int32_t scaleup_output_hidden; /* config.scaleup_output_hidden (t5_generative_retriever.py:427)  */
   float layer_norm_eps;
   const float* shared;           /* [dev] shared.weight [vocab_size, d_model]                     */

@@ -51,7 +51,7 @@ int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
   unsigned int* probe = c->status + 8;
   RPR_HIP(hipMemsetAsync(probe, 0, 4, s));
   for (const auto& j : m->plane_jobs)
-    RPR_HIP(launch_split_planes(j.w, j.dst, j.n, j.n, s, W_PLANE_SCALE * j.pre, j.ln, m->d.d_model, probe));
+    RPR_HIP(launch_split_planes(j.w, j.dst, j.n, j.plane_stride ? j.plane_stride : j.n, s, W_PLANE_SCALE * j.pre, j.ln, m->d.d_model, probe));
   unsigned int sat = 0;
   RPR_HIP(hipMemcpyAsync(&sat, probe, 4, hipMemcpyDeviceToHost, s));
   RPR_HIP(hipStreamSynchronize(s));
@@ -153,12 +153,12 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
   E(w.ex, T * dm * f); E(w.eh, T * dm * f); E(w.eqkv, T * 3 * inner * f); E(w.eattn, T * inner * f);
   E(w.eff, T * dff * f); E(w.enc_out, T * dm * f); E(w.xkv, T * nd * 2 * inner * f);
   E(w.x, R * dm * f); E(w.h, R * dm * f); E(w.q, R * inner * f); E(w.attn, R * inner * f);
-  E(w.ff, R * dff * f); E(w.logits, R * (size_t)d.V * f);
+  E(w.ff, R * dff * f); E(w.logits, R * (size_t)m->Vp() * f);
   const size_t depth0 = forks.empty() ? (size_t)L : (size_t)forks[0];   // stage 0 stops at the first fork
   E(w.kcache, nd * depth0 * R * inner * f); E(w.vcache, nd * depth0 * R * inner * f);
-  E(w.lb, R * (size_t)d.V * 4);
+  E(w.lb, R * (size_t)m->Vp() * 4);
   {
-    const int G = select_groups(Q, B, d.V, 256);
+    const int G = select_groups(Q, B, m->Vp(), 256);
     if (G > 1) E(w.sel_part, R * (size_t)G * 20);
   }
   for (int i = 0; i < 2; ++i) {
@@ -325,7 +325,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
   const auto& d = m->d;
   Workspace& w = c->ws;
   const int Q = sv.Qcap, B = sd.B, L = sd.L, Lq = sd.Lq, R = Q * B, inner = m->inner(), dm = d.d_model, dff = d.d_ff, H = d.num_heads;
-  const int nd = d.num_decoder_layers, V = d.V, xld = sd.xld;
+  const int nd = d.num_decoder_layers, V = d.V, Vp = m->Vp(), xld = sd.xld;   // Vp: logits row / selection width (V padded to 64)
   const bool h2 = c->precision == RPR_PREC_F16X2;
   const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
@@ -342,6 +342,8 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
   };
   const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
   const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
+  if (Vp != V && !h2)   // exact-fp32 logits GEMM writes the V real columns of a row only: the padding must read as finite
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return hipMemsetAsync(logits, 0, (size_t)R * Vp * sizeof(float), s); });
   for (int t = t0; t < t1; ++t) {
     const BeamState cur = sv.st[t & 1], nxt = sv.st[(t + 1) & 1];
     Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
@@ -387,7 +389,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     }
     if (!h2) norm(d.dec_final_ln, post);
     // logits of position t only (the reference computes every position and keeps [-1])
-    float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;
+    float* lg = (taps && taps->step_logits) ? taps->step_logits + (size_t)t * R * V : logits;   // taps: V == Vp (rpr_search)
     {
       LinW wt{d.out_embeds + (size_t)t * V * dm, nullptr, V, dm};
       if (h2) {
@@ -396,20 +398,20 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         const LinIn a = xs.in(3 * nd);
         GemmH2Args g{};
         g.A = a.h; g.a_ps = a.ps; g.lda = dm;
-        g.W = m->h_out_embeds + (size_t)t * V * dm; g.w_ps = (size_t)d.L * V * dm; g.ldw = dm;
-        g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = V; g.split_n = V;
-        g.M = Rt; g.N = V; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
+        g.W = m->h_out_embeds + (size_t)t * Vp * dm; g.w_ps = (size_t)d.L * Vp * dm; g.ldw = dm;
+        g.out[0] = g.out[1] = g.out[2] = lg; g.ldo[0] = g.ldo[1] = g.ldo[2] = Vp; g.split_n = Vp;
+        g.M = Rt; g.N = Vp; g.K = dm; g.acc_scale = 1.0f / (W_PLANE_SCALE * a.scale);
         g.row_ssq = a.ssq; g.inv_d_fix = a.inv_d_fix; g.eps = a.eps; g.sat = c->status;
         g.m_dev = sv.nrows_dev; g.cus = c->cur_cus; g.small_live = sv.nrows_dev ? c->cur_small_live : 0;
         Ln.run(RPR_K_GEMM, 2.0 * Ma * (double)V * dm, 4.0 * ((double)Ma * dm + (double)V * dm + (double)Ma * V),
                [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
       } else {
-        linear(Ln, in_h, wt, Rt, out_f32(lg, V, V), sv.nrows_dev, Ma);
+        linear(Ln, in_h, wt, Rt, out_f32(lg, Vp, V), sv.nrows_dev, Ma);   // V real columns into rows of Vp (the pad stays 0)
       }
     }
     SelectArgs sa{};
     sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
-    sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = V; sa.t = t;
+    sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = Vp; sa.Vreal = V; sa.t = t;
     sa.log_softmax = (sd.flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
     sa.shared0 = (Bt != B) ? 1 : 0;
     sa.nq_dev = sv.nq_dev;
@@ -422,7 +424,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
     // few queries x many beams: G blocks per query + a merge, on the steps whose candidate sets are large — about
     // B * min(V, docs per depth-t node) valid candidates; narrow steps go through the single block's compact path
-    const int G = taps ? 1 : select_groups(sd.Q, B, V, 256);
+    const int G = taps ? 1 : select_groups(sd.Q, B, Vp, 256);
     if (G > 1 && w.sel_part.p) {
       double per_node = (double)tr->N;
       for (int i = 0; i < t && per_node > 1.0; ++i) per_node /= (double)V;
@@ -846,7 +848,7 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   RPR_REQUIRE(c && d && out, "NULL argument");
   RPR_REQUIRE(d->d_kv == DKV, "only d_kv == 64 is supported (t5-base / t5-large)");
   RPR_REQUIRE(d->d_model % 32 == 0 && d->d_ff % 32 == 0, "d_model and d_ff must be multiples of 32");
-  RPR_REQUIRE(d->V % 64 == 0 && d->V <= 65536, "decoder vocab size must be a multiple of 64 and <= 65536");
+  RPR_REQUIRE(d->V >= 2 && d->V <= 65536, "decoder vocab size out of range (2..65536)");
   RPR_REQUIRE(d->L >= 1 && d->L <= MAX_DEC_LEN, "decoder length out of range");
   RPR_REQUIRE(d->rel_buckets >= 2 && d->rel_buckets <= 64, "relative_attention_num_buckets out of range");
   RPR_REQUIRE(d->num_layers >= 1 && d->num_decoder_layers >= 1 && d->num_heads >= 1, "bad layer/head count");
@@ -896,7 +898,7 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
       hipError_t e = hipMalloc(&p, n * 2 * sizeof(__half));
       if (e == hipSuccess) {
         m->owned.push_back(p);
-        m->plane_jobs.push_back({wf, n, (__half*)p, ln, pre});
+        m->plane_jobs.push_back({wf, n, (__half*)p, ln, pre, 0});
         e = launch_split_planes(wf, (__half*)p, n, n, nullptr, W_PLANE_SCALE * pre, ln, (int)dm, probe);
       }
       if (e != hipSuccess) { err = hip_fail(e, "weight split", __FILE__, __LINE__); return; }
@@ -913,8 +915,20 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
     mkv(m->dec_xq, inner * dm, m->h_dec_xq, &m->dec_ln1); mkv(m->dec_xo, dm * inner, m->h_dec_xo);
     mkv(m->dec_wi, dff * dm, m->h_dec_wi, &m->dec_ln2); mkv(m->dec_wo, dm * dff, m->h_dec_wo);
     mk(d->dec_xkv, (size_t)nd * 2 * inner * dm, &m->h_dec_xkv);
-    mk(d->out_embeds, (size_t)d->L * d->V * dm, &m->h_out_embeds, d->dec_final_ln,
-       d->scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f);
+    if (!err) {   // the output codebooks, each padded to Vp rows (zero rows: their logits are 0 and never selectable)
+      const size_t Vp = (size_t)m->Vp(), ps = (size_t)d->L * Vp * dm, n = (size_t)d->V * dm;
+      const float pre = d->scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, ps * 2 * sizeof(__half));
+      if (e == hipSuccess) { m->owned.push_back(p); e = hipMemset(p, 0, ps * 2 * sizeof(__half)); }
+      for (int l = 0; l < d->L && e == hipSuccess; ++l) {
+        __half* dst = (__half*)p + (size_t)l * Vp * dm;
+        m->plane_jobs.push_back({d->out_embeds + (size_t)l * n, n, dst, d->dec_final_ln, pre, ps});
+        e = launch_split_planes(d->out_embeds + (size_t)l * n, dst, n, ps, nullptr, W_PLANE_SCALE * pre, d->dec_final_ln, (int)dm, probe);
+      }
+      if (e != hipSuccess) err = hip_fail(e, "codebook split", __FILE__, __LINE__);
+      m->h_out_embeds = (__half*)p;
+    }
     if (!err) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) err = hip_fail(e, "sync", __FILE__, __LINE__); }
     if (err) return err;
     // a weight (times its folded layer-norm weight, times 2^8) outside the f16 range cannot be carried by the planes:
@@ -1301,7 +1315,8 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
   RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
   RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
-  RPR_REQUIRE(select_fits(B, m->d.V), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
+  RPR_REQUIRE(select_fits(B, m->Vp()), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
+  RPR_REQUIRE(!taps || m->Vp() == m->d.V, "debug taps need a decoder vocab size that is a multiple of 64");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   { const int pe = ensure_weight_planes(c, m, s); if (pe) return pe; }   // after an optimizer step

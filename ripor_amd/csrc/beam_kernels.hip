@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   // writes the next beam state. Below, B is the number of source beams of this block and Bw the number of winners.
   const int G = a.G > 1 ? a.G : 1;
   const int Bw = a.B, B = a.B / G, V = a.V, t = a.t, Lc = a.Lc;
+  const int Vr = a.Vreal > 0 ? a.Vreal : V;   // real vocab; columns Vr..V-1 of a logits row are padding (zero logits)
   const int q = blockIdx.x / G, grp = blockIdx.x - q * G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.nq_dev && q >= *a.nq_dev) return;   // compacted stage: block-uniform
@@ -200,11 +201,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     for (int b = wave; b < B; b += 4) {
       const float* row = a.shared0 ? lg_q : lg_q + (size_t)b * V;
       float mx = -INFINITY;
-      for (int c = lane; c < V; c += 64) mx = fmaxf(mx, row[c]);
+      for (int c = lane; c < Vr; c += 64) mx = fmaxf(mx, row[c]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
       float sm = 0.f;
-      for (int c = lane; c < V; c += 64) sm += expf(row[c] - mx);
+      for (int c = lane; c < Vr; c += 64) sm += expf(row[c] - mx);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
       if (lane == 0) { lmax[b] = mx; lsum[b] = logf(sm); }
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   };
   auto cand_score = [&](int item, float lg) -> double {
     const int b = item / V;
+    if (Vr != V && item - b * V >= Vr) return -INFINITY;   // padding column: behind every candidate of the reference
     if (a.log_softmax) lg = (lg - lmax[b]) - lsum[b];
     const bool ok = (valid[item >> 6] >> (item & 63)) & 1ull;
     return ((double)lg + (ok ? 0.0 : -1e9)) + bscore[b];

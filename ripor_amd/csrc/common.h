@@ -253,7 +253,8 @@ struct SelectArgs {
   int Lc;                    // row stride of codes (trie depth)
   BeamState cur, nxt;
   int32_t* lb_scratch;       // [R, V] lower bounds found by the mask phase
-  int Q, B, V, t;
+  int Q, B, V, t;            // V: width of the token axis = the model's vocab rounded up to 64 (logits row stride)
+  int Vreal;                 // the model's decoder vocab size (0 = V): tokens >= Vreal are padding and never selectable
   int log_softmax;
   int lds_logits;            // set by the launcher: stage the query's B*V logits in LDS
   int sort_lds, sort_off;    // set by the launcher: B > 256 -> bitonic sort of the candidate lists; byte offset of its LDS buffer

@@ -33,7 +33,8 @@ struct rpr_model {
   std::vector<__half*> h_enc_qkv, h_enc_o, h_enc_wi, h_enc_wo;
   std::vector<__half*> h_dec_qkv, h_dec_o, h_dec_xq, h_dec_xo, h_dec_wi, h_dec_wo;
   __half* h_dec_xkv = nullptr;
-  __half* h_out_embeds = nullptr;  // [2][L*V][d]
+  __half* h_out_embeds = nullptr;  // [2][L*Vp][d]: every codebook padded to Vp = V rounded up to 64 rows (zero rows)
+  int Vp() const { return (d.V + 63) & ~63; }   // width of the selection kernel's token axis and of a logits row
   // Fused RMSNorm: the planes of every projection that consumes a normalised input hold W * diag(ln_weight)
   // (enc_qkv: ln0, enc_wi: ln1, dec_qkv: ln0, dec_xq: ln1, dec_wi: ln2, out_embeds: final ln * scaleup factor);
   // the fp32 weights of the caller stay untouched and serve the exact-fp32 mode.
@@ -41,7 +42,7 @@ struct rpr_model {
   bool planes_dirty = false;       // the fp32 weights changed (rpr_adamw_step) since the planes were split
   std::vector<void*> owned;
   // how every plane buffer was produced (replayed by refresh_weight_planes after an optimizer step changed the weights)
-  struct PlaneJob { const float* w; size_t n; __half* dst; const float* ln; float pre; };
+  struct PlaneJob { const float* w; size_t n; __half* dst; const float* ln; float pre; size_t plane_stride; };   // plane_stride 0 = n
   std::vector<PlaneJob> plane_jobs;
   // trainable tensors in the order of the flat gradient / optimizer-state buffers (train_api.hip)
   struct ParamRef { int kind; int layer; float* ptr; size_t numel; size_t offset; };

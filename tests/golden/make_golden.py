@@ -382,6 +382,9 @@ CASES = {
     "g1_mini_b10_l8_tiny_trie": dict(kind="mini", N=7, Q=3, B=10, L=8, V=256, seed=104),  # < B leaves
     "g1_mini_b4_l8_logsoftmax": dict(kind="mini", N=1000, Q=4, B=4, L=8, V=256, seed=105, log_softmax=True),
     "g1_mini_b4_l8_shared": dict(kind="mini", N=500, Q=4, B=4, L=8, V=256, seed=106, shared=True),
+    # decoder vocab sizes that are not multiples of 64 (the library pads the token axis internally)
+    "g1_mini_b4_l8_v100": dict(kind="mini", N=1000, Q=4, B=4, L=8, V=100, seed=107),
+    "g1_mini_b4_l6_v200_logsoftmax": dict(kind="mini", N=800, Q=3, B=4, L=6, V=200, seed=108, log_softmax=True),
     "g2_base_b10_l32": dict(kind="base", N=1000, Q=4, B=10, L=32, V=256, seed=201),
     # t5-large decoder shape (24 layers, 16 heads, d=1024 are forced by the reference ctor), B=100 top-k stress
     "g3_large_b100_l16": dict(kind="large", N=3000, Q=4, B=100, L=16, V=256, seed=301),
