@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (diagnostic; `python tools/fuzz_parity.py [n_cases] [seed]`): mini-dims models over
 random tries (sizes 300 .. 300 k docs, uniform / skewed codes, duplicated smtids), lengths 4..16, beams 1..1000 (a few cases
-with many beams and 1-2 queries, a few with enough rows for the lane split), V 256 / 1024,
+with many beams and 1-2 queries, a few with enough rows for the lane split), V 256 / 1024 / 100 / 200,
 raw-logit and log-softmax scores. Every case compares
 
   * the forced tail (automatic depths, then random explicit forks, exact and optimistic mode) with the step-by-step loop:
@@ -80,7 +80,7 @@ params = []
 for case in range(n_cases):                 # every random draw up front, so that a single case can be replayed
     N = rng.choice([300, 3000, 20_000, 60_000, 300_000])
     L = rng.choice([4, 6, 8, 10, 12, 16])
-    V = rng.choice([256, 256, 256, 1024])
+    V = rng.choice([256, 256, 256, 1024, 100, 200])
     B = rng.choice([1, 2, 4, 10, 10, 32, 100])
     Q = rng.randint(1, 24)
     skew, dup, lsm = rng.random() < 0.4, rng.random() < 0.3, rng.random() < 0.3
