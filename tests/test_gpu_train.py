@@ -459,3 +459,36 @@ def test_gradient_buckets_are_handed_over_during_the_backward(precision):
     assert len({n for _, n in hist[:nd]}) == 1 and len({n for _, n in hist[nd:nd + ne]}) == 1   # whole layers
     spans = sorted((o, o + n) for o, n in hist)
     assert spans[0][0] == 0 and spans[-1][1] == st.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [256, 100])
+def test_search_after_a_training_step_sees_the_new_weights(V):
+    """rpr_adamw_step marks the f16 weight planes of the search path stale; the next search re-splits them from the updated
+    fp32 weights — including the output codebooks, which live in a padded layout of their own when V is not a multiple of 64.
+    A search after one optimisation step must return the bits of a search on a fresh model loaded with the updated weights."""
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    L, bz = 8, 4
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    sd = synth.make_state_dict(dims, seed=31 + V)
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, sd, dims)
+    state = E.TrainState(model)
+    codes_trie = synth.make_codes(2000, L, V, seed=5)
+    trie = E.DeviceTrie.from_codes(ctx, codes_trie, V)
+    ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=9, max_len=12)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    before = E.search(model, trie, ti, tm, 4, L)
+    doc = torch.from_numpy(synth.make_codes(2 * bz, L, V, seed=6).astype(np.int64).reshape(2, bz, L).transpose(1, 0, 2).copy())
+    prefix = [L, 4]
+    tp = torch.from_numpy(np.stack([synth.uniform_f32(f"sa/p{k}", (bz,), 30.0) for k in prefix]))
+    tn = torch.from_numpy(np.stack([synth.uniform_f32(f"sa/n{k}", (bz,), 30.0) for k in prefix]))
+    E.train_step(model, state, ti.cuda(), tm.cuda(), doc.cuda(), tp, tn, prefix, lr=3e-3)     # a large step: results must move
+    after = E.search(model, trie, ti, tm, 4, L)
+    torch.cuda.synchronize()
+    fresh_model = E.DeviceModel(ctx, {k: v.cpu().numpy() for k, v in model.export_state_dict().items()}, dims)
+    fresh = E.search(fresh_model, trie, ti, tm, 4, L)
+    torch.cuda.synchronize()
+    assert torch.equal(after.tokens, fresh.tokens) and torch.equal(after.scores, fresh.scores)
+    assert not torch.equal(after.scores, before.scores), "the step did not change the scores: the test checks nothing"
