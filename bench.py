@@ -11,8 +11,11 @@ on its own shard, model + trie replicated, one RCCL all_gather of the ranked res
   python bench.py [--gpus N --steps K --warmup W --batch Q --beams B --len L --docs N_DOCS]
 
 Extra legs on rank 0 (outside the timed region):
-  roofline     one eager step with hipEvents around every launch on the launch stream (the library's
-               profile mode); the dominant kernel is the fp32-MFMA linear layer (gemm_f32_kernel).
+  roofline     one eager step of the TIMED configuration with hipEvents around every launch on the stream it is
+               launched on (the library's profile mode; nothing synchronises while the step is enqueued, so the two
+               lanes run side by side as in the timed region); the dominant kernel is the split-precision 256x256
+               ping-pong GEMM (gemm_h2_pp_kernel). The rocprofv3 average of the same kernel in the same configuration
+               is read from profiles/latest_kernel_stats.csv and reported beside it (roofline.source_profile).
   cpu_baseline the oracle "port" of the reference loop (no KV cache, dict+CSR float64 mask, top-2B,
                Python scorer) on the host cores, on a bounded sample.
 """
@@ -675,8 +678,28 @@ def main():
                                 traffic = None
                     except Exception:
                         pass
+                src = None
+                csv_path = os.path.join(REPO, "profiles", "latest_kernel_stats.csv")
+                if cu_fraction != 1.0 or not lanes_on:
+                    try:   # rocprofv3 --kernel-trace --stats of `bench.py --no-roofline --secondary ""` (tools/profile_round.sh)
+                        import csv as _csv
+                        want = kname.split("::")[-1].split(" ")[0]
+                        rows = [r for r in _csv.DictReader(open(csv_path)) if want in r["Name"]]
+                        rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+                        if rows:
+                            us = float(rows[0]["AverageNs"]) / 1e3
+                            mine = g["total_ms"] * 1e3 / max(1, g["launches"])
+                            src = {"file": "profiles/latest_kernel_stats.csv", "row": rows[0]["Name"].split("(")[0],
+                                   "calls": int(rows[0]["Calls"]), "rocprof_avg_launch_us": us,
+                                   "this_run_over_rocprof": mine / us,
+                                   "note": "rocprofv3 --kernel-trace --stats of the graph-replayed timed region of an earlier run of "
+                                           "the same build (bench.py --no-roofline --secondary ''); the eager event-timed average "
+                                           "above should agree within a few percent (boxes differ by +-2 %)"}
+                    except Exception:
+                        pass
                 return {"kernel": kname, "bound": "mfma", "achieved": ach,
                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "cu_fraction": cu_fraction,
+                        "source_profile": src,
                         "peak_whole_chip": full_peak, "note": note,
                         "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
@@ -690,6 +713,16 @@ def main():
             log("[bench] roofline leg done")
             out["roofline"] = gemm_roofline(stats, 0.5 if lanes_on else 1.0)
             out["lanes"] = 2 if lanes_on else 1
+            # consistency of the event-timed pass with the timed region: a lane executes its launches back to back, so the
+            # event durations of everything it ran must add up to about one step of wall clock
+            busy = sum(v["total_ms"] for v in stats.values()) / (2 if lanes_on else 1)
+            out["roofline"]["lane_time_check"] = {
+                "sum_of_event_durations_per_lane_ms": busy, "ms_per_step_timed_region": ms_per_step,
+                "ratio": busy / ms_per_step,
+                "dominant_kernel_ms_per_lane": stats["gemm"]["total_ms"] / (2 if lanes_on else 1),
+                "note": "eager profile pass (hipEvents around every launch, no synchronisation while enqueuing) vs the "
+                        "graph-replayed timed region; ratio ~1 means the launches were timed under the same contention as in "
+                        "the timed region"}
             if lanes_on:
                 # the same step on one stream with every launch on the whole chip: the kernel's own quality, comparable with
                 # earlier rounds; the per-kernel breakdown and the HBM roofline below come from this step (in lane mode two

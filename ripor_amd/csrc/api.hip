@@ -45,6 +45,21 @@ int rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
   return bucket + large;
 }
 
+// |logit| <= sqrt(d_model) * max_row |E_out[r] * ln_final| * scaleup factor for ANY decoder state (Cauchy-Schwarz on the
+// RMS-normalised hidden state): the bound behind the forced-tail fork's masked-candidate proof (enqueue_fork).
+int compute_logit_bound(rpr_ctx* c, rpr_model* m, hipStream_t s, float* out) {
+  const auto& d = m->d;
+  float* slot = reinterpret_cast<float*>(c->status + 9);   // device word next to the weight-range probe
+  RPR_HIP(hipMemsetAsync(slot, 0, 4, s));
+  RPR_HIP(launch_max_row_norm(d.out_embeds, d.dec_final_ln, d.L * d.V, d.d_model, slot, s));
+  float mx = 0.f;
+  RPR_HIP(hipMemcpyAsync(&mx, slot, 4, hipMemcpyDeviceToHost, s));
+  RPR_HIP(hipStreamSynchronize(s));
+  const float post = d.scaleup_output_hidden ? (float)pow((double)d.d_model, -0.5) : 1.0f;
+  *out = 1.001f * mx * sqrtf((float)d.d_model) * post + 1.0f;   // slack for the split-precision arithmetic
+  return RPR_OK;
+}
+
 int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
   // the weight-range probe has its own device word (status[8]): the ctx's sticky flags (status[0..3]) may hold something
   // nobody has read yet — searches on another model, a forward enqueued before the optimizer step
@@ -56,6 +71,17 @@ int refresh_weight_planes(rpr_ctx* c, rpr_model* m, hipStream_t s) {
   RPR_HIP(hipMemcpyAsync(&sat, probe, 4, hipMemcpyDeviceToHost, s));
   RPR_HIP(hipStreamSynchronize(s));
   m->f32_only = sat != 0;
+  // the weights changed (optimizer step, or a caller writing through rpr_param_info's pointers): the logit bound of the
+  // forced-tail proof follows them, and so do the graphs that hold the spread limit derived from it by value
+  float lb = m->logit_bound;
+  const int e = compute_logit_bound(c, m, s, &lb);
+  if (e) return e;
+  if (lb != m->logit_bound) {
+    m->logit_bound = lb;
+    for (auto it = c->graphs.begin(); it != c->graphs.end();) {
+      if (it->first.m == m) { (void)hipGraphExecDestroy(it->second); it = c->graphs.erase(it); } else ++it;
+    }
+  }
   return RPR_OK;
 }
 
@@ -112,7 +138,6 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.sat = L.c->status;
     g.cus = L.c->cur_cus;
     g.small_live = m_dev ? L.c->cur_small_live : 0;
-    g.xcd_sync = L.c->status + 16 + 8 * (L.c->cur_lane + 1);   // 8 words per stream (ctx, lane 0, lane 1) behind the flags
     g.part = P<float>(L.c->ws.part); g.part_cap = L.c->ws.part.cap / sizeof(float); g.mid_split = 1;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
@@ -127,12 +152,23 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
 }
 
 int flush_profile(rpr_ctx* c) {
+  std::map<const int*, int> live;   // device counters of the pass, read once each after the events have completed
   for (auto& r : c->recs) {
     RPR_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     RPR_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    double scale = 1.0;
+    if (r.live_dev && r.live_static > 0) {
+      auto it = live.find(r.live_dev);
+      if (it == live.end()) {
+        int n = r.live_static;
+        RPR_HIP(hipMemcpy(&n, r.live_dev, sizeof(int), hipMemcpyDeviceToHost));
+        it = live.emplace(r.live_dev, n).first;
+      }
+      scale = (double)std::min(std::max(it->second, 0), r.live_static) / (double)r.live_static;
+    }
     auto& d = c->done[r.cls];
-    d.total_ms += ms; d.launches += 1; d.flops += r.flops; d.bytes += r.bytes;
+    d.total_ms += ms; d.launches += 1; d.flops += r.flops * scale; d.bytes += r.bytes * scale;
     c->pool.push_back(r.a); c->pool.push_back(r.b);
   }
   c->recs.clear();
@@ -247,11 +283,8 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
   int Ta = T;                                                  // rows accounted in the profile (flops / bytes)
   if (packed) {
     Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_pack_rows(P<int32_t>(w.last), P<int32_t>(w.offs), P<int32_t>(w.row_src), Q, Lq, s); });
-    if (c->profiling && !Ln.err) {   // eager diagnostic pass: read the live row count back so the accounting is exact
-      int n = T;
-      if (hipMemcpyAsync(&n, live, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) Ta = n;
-    }
   }
+  Ln.account_live(live, T);   // profile pass: flops / bytes below are stated for T rows and scaled by the live count at flush
   const XStream xs{P<__half>(w.ex_h), ps_d, P<unsigned long long>(w.ssq_e), (size_t)T, dm, eps};
   if (h2) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(P<unsigned long long>(w.ssq_e), (size_t)(2 * d.num_layers + 1) * T, s); });
   auto norm = [&](const float* wgt) {   // exact-fp32 mode only: the split mode folds the norms into the projections
@@ -308,12 +341,12 @@ struct StageView {
   size_t kv_layer(int B, int inner) const { return (size_t)Qcap * depth * B * inner; }
 };
 
-// live count of a device counter for the profile accounting of an eager diagnostic pass (synchronises)
-int live_count(Launcher& Ln, const int* dev, int fallback) {
-  if (!dev || !Ln.c->profiling || Ln.err) return fallback;
-  int n = fallback;
-  if (hipMemcpyAsync(&n, dev, sizeof(int), hipMemcpyDeviceToHost, Ln.s) != hipSuccess || hipStreamSynchronize(Ln.s) != hipSuccess) return fallback;
-  return n;
+// Profile accounting of a compacted stage / tail job: the launches that follow state their flops and bytes for the
+// static capacity `rows`; the record keeps the device counter and flush_profile scales by live / rows afterwards. Nothing
+// is read back while the step is being enqueued (a synchronisation here would run the two lanes one after the other).
+int live_count(Launcher& Ln, const int* dev, int rows) {
+  Ln.account_live(dev, rows);
+  return rows;
 }
 
 struct SearchDims { int Q, Lq, B, L, xld; bool packed; unsigned flags; };
@@ -343,7 +376,8 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
   const XStream xs{P<__half>(w.x_h), ps_d, P<unsigned long long>(w.ssq_d), (size_t)R, dm, eps};
   const LinIn in_h{h, nullptr, 0, dm}, in_attn{attn, attn_h, ps_i, inner}, in_ff{ff, ff_h, ps_f, dff, FF_PLANE_SCALE};
   if (Vp != V && !h2)   // exact-fp32 logits GEMM writes the V real columns of a row only: the padding must read as finite
-    Ln.run(RPR_K_OTHER, 0, 0, [&] { return hipMemsetAsync(logits, 0, (size_t)R * Vp * sizeof(float), s); });
+    // (a kernel node: memset nodes captured into the search graph did not re-execute reliably on replay, see launch_zero_u64)
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_zero_u64(reinterpret_cast<unsigned long long*>(logits), (size_t)R * Vp / 2, s); });
   for (int t = t0; t < t1; ++t) {
     const BeamState cur = sv.st[t & 1], nxt = sv.st[(t + 1) & 1];
     Bt = (t == 0 && shared0) ? 1 : B; Rt = Q * Bt;
@@ -615,8 +649,10 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // cross-attention K/V of every decoder layer in one GEMM (shared by the B beams of a query;
   // the reference recomputes them for every beam at every step)
   const int xld = nd * 2 * inner;
+  Ln.account_live(packed ? P<int>(w.offs) + Q : nullptr, T);
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
          out_f32(P<float>(w.xkv), xld, xld), packed ? P<int>(w.offs) + Q : nullptr, c->enc_rows_accounted);
+  Ln.account_live(nullptr, 0);
 
   const SearchDims sd{Q, Lq, B, L, xld, packed, flags};
   StageView sv{};
@@ -691,6 +727,7 @@ void enqueue_train_forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int bz,
   const int xld = nd * 2 * inner;
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
          out_f32(P<float>(w.xkv), xld, xld), P<int>(w.offs) + bz, c->enc_rows_accounted);
+  Ln.account_live(nullptr, 0);
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qkv = P<float>(w.tr_x), *qb = P<float>(w.q), *attn = P<float>(w.attn),
         *ff = P<float>(w.ff);
@@ -937,15 +974,9 @@ int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
     RPR_HIP(hipMemcpy(&sat, probe, 4, hipMemcpyDeviceToHost));
     if (sat) m->f32_only = true;
   }
-  {  // |logit| <= sqrt(d_model) * max_row |E_out[r] * ln_final| * scaleup factor (forced-tail fork, see internal.h)
-    DevTmp nb;
-    RPR_HIP(nb.alloc(4));
-    RPR_HIP(hipMemset(nb.p, 0, 4));
-    RPR_HIP(launch_max_row_norm(d->out_embeds, d->dec_final_ln, d->L * d->V, d->d_model, nb.as<float>(), nullptr));
-    float mx = 0.f;
-    RPR_HIP(hipMemcpy(&mx, nb.p, 4, hipMemcpyDeviceToHost));
-    const float post = d->scaleup_output_hidden ? (float)pow((double)d->d_model, -0.5) : 1.0f;
-    m->logit_bound = 1.001f * mx * sqrtf((float)d->d_model) * post + 1.0f;   // slack for the split-precision arithmetic
+  {  // bound of |logit| (forced-tail fork, see internal.h)
+    const int e = compute_logit_bound(c, m.get(), nullptr, &m->logit_bound);
+    if (e) return e;
   }
   *out = m.release();
   return RPR_OK;

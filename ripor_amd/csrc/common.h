@@ -91,12 +91,6 @@ struct GemmH2Args {
   int M, N, K;
   int relu;
   unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
-  // XCD round barrier of the persistent 256x256 kernel (nullable; 8 counters, zeroed before the launch): the blocks of an
-  // XCD start their j-th tiles together, so that the column tiles of a row panel sweep K side by side and the panel's
-  // K-slices are fetched from the fabric once per XCD instead of once per tile (rocprofv3 FETCH_SIZE: 10x the
-  // algorithmic bytes without it on the N = 2304 / 3072 projections). A bounded wait — a performance hint, never a
-  // correctness dependency.
-  unsigned int* xcd_sync;
   int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
   const int* m_dev;                        // nullable: live row count on the device (see GemmArgs)
   // Power-of-two scaling of the f16 planes (exact; see W_/A_/FF_PLANE_SCALE below): the accumulators are multiplied

@@ -287,14 +287,12 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 }
 
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
-// SH = rows a wave stages at a time. 64: the strips of the 8 waves fill both operand buffers (128 KB). 32: they fit the
-// SECOND operand buffer alone (stg_off = its offset), which leaves the first one free for the LDS-DMA of the block's next
-// tile while this tile is being stored (persistent ping-pong kernel).
-template <bool FULL, int TM, int TN, int WM, int WN, int SH = 64>
+// A wave stages 64 rows at a time: the strips of the 8 waves fill both operand buffers (128 KB).
+template <bool FULL, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
                                                 int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
-                                                float acc_scale, int stg_off = 0) {
-  constexpr int BM = 256, BN = 256;
+                                                float acc_scale) {
+  constexpr int BM = 256, BN = 256, SH = 64;
   // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
   // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
@@ -305,11 +303,11 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   // cost a full memory latency per half), so the f16-plane outputs give a lane 8 consecutive columns = one 16-byte
   // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
   // one max per element plus one compare per half.
-  if (SH == 64) __syncthreads();                     // all waves are done reading operand tiles (SH = 32: the caller did it)
+  __syncthreads();                                   // all waves are done reading operand tiles
   const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
   constexpr int NS = TM * 32 / SH;                    // strips per wave
-  float* stg = reinterpret_cast<float*>(smem) + stg_off + wave * (SH * SW);
+  float* stg = reinterpret_cast<float*>(smem) + wave * (SH * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
   for (int strip = 0; strip < NS; ++strip) {
@@ -434,12 +432,13 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // BF16 = true (training GEMMs, RPR_PREC_BF16): one bf16 plane per operand; the LDS rows of the lo planes hold the NEXT
 // 32 columns of K instead, a K-tile is 64 deep and a phase issues 8 v_mfma_f32_32x32x16_bf16 (slice 0 x slice 0 and
 // slice 1 x slice 1) on the same fragment reads — see gemm_h2_dma_kernel.
-// PREFETCH = true (persistent launches): before a tile's epilogue the block issues the LDS-DMA of its NEXT tile's first
-// K-tile into operand buffer 0 — the epilogue stages in 32-row strips inside buffer 1 — so the next tile starts with its
-// operands already in LDS instead of waiting out one memory latency with the matrix pipe idle (~3 us of ~78 per tile at
-// K = 768).
-template <bool FULL, bool TRACE = false, bool BF16 = false, bool PREFETCH = false>
-__global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n, int skew_ticks) {
+// TRACE = true: diagnostic instantiation (tools/gemm_trace_pp.py, tools/gemm_tile_timeline.py) that stamps cycle counters
+// of block 0 into g.trace; never launched by a search.
+// Schedules that were measured and removed (DESIGN.md "tried and rejected"; the code is in the history): a phase skew
+// between the persistent blocks, a per-round barrier between the blocks of an XCD, and the next tile's first K-tile
+// prefetched under the epilogue — all of them slower or equal on the power-capped headline step.
+template <bool FULL, bool TRACE = false, bool BF16 = false>
+__global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
   // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
   const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
@@ -448,10 +447,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
   __shared__ float rs_tile[BM];                      // fused RMSNorm: rsqrt(mean(x^2) + eps) of the tile's rows
 
-  // PERSISTENT: the grid is (at most) one block per CU and a block walks the tiles bid, bid + gridDim.x, ... — the
-  // stores of a tile's epilogue drain under the first K-tiles of the block's next tile instead of holding the CU until
-  // the block retires, and blocks started with different offsets (skew_ticks) stay out of phase for the whole launch:
-  // the HBM bursts of the epilogues of some CUs run under the power-bound K-loops of the others.
+  // PERSISTENT: the grid is (at most) one block per CU and a block walks the tiles of its XCD's chunk — the stores of a
+  // tile's epilogue drain under the first K-tiles of the block's next tile instead of holding the CU until the block
+  // retires.
   int nt = tiles_m * tiles_n;
   if (g.m_dev) {                                             // packed rows: only the tiles holding live rows
     if (g.live_hi > 0 && (*g.m_dev <= g.live_lo || *g.m_dev > g.live_hi)) return;   // the other kernel of the pair runs
@@ -460,32 +458,13 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  if (skew_ticks > 0 && (int)blockIdx.x < nt) {     // 100 MHz ticks; every other block of an XCD starts late
-    const int ph = (blockIdx.x >> 3) & 3;
-    if (ph) {
-      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(skew_ticks * ph);
-      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   // tile order: XCD x = block & 7 owns a contiguous chunk of the live tiles; its blocks walk the chunk side by side
   // (blocks of XCD x: those with index = x mod 8, (gridDim.x - x + 7) / 8 of them — with one block per tile that is the
   // chunk size and every block handles exactly one tile)
   const int xq = nt >> 3, xr = nt & 7, xcd = blockIdx.x & 7, xk = blockIdx.x >> 3, xstep = ((int)gridDim.x - xcd + 7) >> 3;
   const int chunk0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, chunk_n = xcd < xr ? xq + 1 : xq;
   int round = 0;
-  bool prefetched = false;           // this tile's first K-tile is already on its way into buffer 0 (block-uniform)
   for (int ti = xk; ti < chunk_n; ti += xstep, ++round) {
-  if (g.xcd_sync && round > 0) {   // wait (bounded) until every block of this XCD has finished its previous tile
-    if (tid == 0) {
-      __hip_atomic_fetch_add(g.xcd_sync + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int want = (unsigned int)(round * xstep);
-      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + 3000ull;   // 30 us at 100 MHz
-      while (__hip_atomic_load(g.xcd_sync + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
-             __builtin_amdgcn_s_memrealtime() < until)
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-  }
   const int bid = chunk0 + ti;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int bm = tm * BM, bn = tn * BN;
@@ -527,11 +506,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     dst[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;                                               \
   }
   PP_SRC_SETUP(src, lane_t, bm, bn)
-#define PP_PIECE_OF(ptrs, buf, k0, j)                                                                          \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptrs[j] + (k0)),            \
-                                   (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
-                                                                             16 * (wave + NW * (j)) * HBK),     \
-                                   16, 0, 0)
 #define PP_PIECE(buf, k0, j)                                                                                   \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (k0)),             \
                                    (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
@@ -621,10 +595,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
   const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
 #define PP_STAMP(slot) if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + (slot)] = __builtin_readcyclecounter(); }
-  if (!PREFETCH || !prefetched) {
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
-  }
+  for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
   __builtin_amdgcn_s_waitcnt(WAIT_ALL);
   __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
   __builtin_amdgcn_sched_barrier(0);
@@ -678,29 +650,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 
   int lane_e = lane;   // laundered like lane_t: the epilogue's per-lane offsets must not live through the K-loop
   asm volatile("" : "+v"(lane_e));
-  if (PREFETCH) {
-    __syncthreads();                                 // every wave is done reading the operand buffers
-    const int tin = ti + xstep;
-    prefetched = tin < chunk_n && g.ksplit <= 1;
-    if (prefetched) {                                // block-uniform
-      const int nbid = chunk0 + tin, ntm = nbid / tiles_n, ntn = nbid - ntm * tiles_n;
-      int lane_n = lane;
-      asm volatile("" : "+v"(lane_n));
-      const __half* nsrc[PER_WAVE];
-      PP_SRC_SETUP(nsrc, lane_n, ntm * BM, ntn * BN)
-#pragma unroll
-      for (int j = 0; j < PER_WAVE; ++j) PP_PIECE_OF(nsrc, 0, 0, j);
-    }
-    h2_epilogue_256<FULL, TM, TN, WM, WN, 32>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale,
-                                              ROWS * HBK / 2);   // strips in operand buffer 1 (offset in floats)
-  } else {
-    h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
-  }
+  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
   __syncthreads();   // the staging strips alias the operand buffers the next tile's LDS-DMA writes; rs_tile is rewritten
   PP_TILE_STAMP(3);
 #undef PP_TILE_STAMP
 #undef PP_PIECE
-#undef PP_PIECE_OF
 #undef PP_SRC_SETUP
   }
 }
@@ -855,56 +809,27 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-__global__ void zero_u32x8_kernel(unsigned int* p) { if (threadIdx.x < 8) p[threadIdx.x] = 0u; }
-
 // 256x256 tile, 8 waves (2x4) of 128x64, ping-pong schedule: half the staged bytes per MFMA of the 128x128 tile;
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
 static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-  static const int assume_full = [] { const char* e = getenv("RPR_GEMM_ASSUME_FULL"); return e ? atoi(e) : 0; }();   // diagnostic
-  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && (!a.m_dev || assume_full);
+  const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
   // persistent blocks: one per CU of the stream (a whole number per XCD), fewer when the launch has fewer tiles
-  static const int persist = [] { const char* e = getenv("RPR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  static const int skew = [] { const char* e = getenv("RPR_GEMM_SKEW"); return e ? atoi(e) : 0; }();   // 100 MHz ticks per K = 768
   const int cus = a.cus > 0 ? a.cus : 256, nt = tiles_m * tiles_n;
-  const int grid = (persist && nt > cus) ? cus : nt;
-  // skew only pays when a block walks several tiles (the late blocks idle for up to 3/4 of a tile time once per launch)
-  const int skew_ticks = (grid < nt && nt >= 4 * cus) ? (int)((long)skew * a.K / 768) : 0;
+  const int grid = nt > cus ? cus : nt;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const dim3 gr(ks > 1 ? nt : grid, ks), bl(512);      // split-K launches are not persistent: one block per (tile, K range)
-  GemmH2Args ab = a;
-  static const int xsync = [] { const char* e = getenv("RPR_GEMM_XCD_SYNC"); return e ? atoi(e) : 0; }();
-  if (!(xsync && a.xcd_sync && grid < nt && nt >= 2 * cus)) ab.xcd_sync = nullptr;
-  if (ab.xcd_sync) {
-    hipLaunchKernelGGL(zero_u32x8_kernel, dim3(1), dim3(64), 0, s, ab.xcd_sync);
-    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-  }
-  // RPR_GEMM_PREFETCH=1: blocks that walk several tiles fetch the next tile's first K-tile under the current tile's
-  // epilogue. Measured on the headline (two runs each): 4656 / 4643 q/s with it, 4690 / 4667 without — hiding the ~3 us
-  // prologue does not pay for the 32-row epilogue strips it needs (and the kernel is power-bound: closing an idle gap
-  // mostly lowers the sustained clock). Off by default; parity-tested both ways.
-  static const int prefetch_on = [] { const char* e = getenv("RPR_GEMM_PREFETCH"); return e ? atoi(e) : 0; }();
-  const bool pf = prefetch_on && ks == 1 && grid < nt;
   if (a.bf16) {
-    if (pf) {
-      if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-      else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-    } else {
-      if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-      else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-    }
+    if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
     return hipGetLastError();
   }
   if (full && a.trace)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n, 0);
-  else if (pf && full)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, false, true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
-  else if (pf)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, false, true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
   else if (full)
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, ab, tiles_m, tiles_n, skew_ticks);
+    hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n);
   return hipGetLastError();
 }
 

@@ -144,7 +144,7 @@ struct Lane {
 struct rpr_ctx {
   int device;
   int precision = RPR_PREC_F16X2;
-  unsigned int* status = nullptr;       // [dev, 64 words] [8] weight-range probe, [16..39] XCD round barriers of the persistent GEMM (8 per stream); sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing, [2] a query was left unforced by the last fork of an optimistic forced-tail search
+  unsigned int* status = nullptr;       // [dev, 64 words] [8] weight-range probe; sticky words: [0] a value left the f16 plane range, [1] a query attends to nothing, [2] a query was left unforced by the last fork of an optimistic forced-tail search
   unsigned int* status_host = nullptr;  // pinned mirror filled by rpr_get_status
   struct TrainWs* tws = nullptr;        // activations / scratch of the training step (train_api.hip), freed by free_train_ws
   unsigned long long* trace_buf = nullptr;  // diagnostic (RPR_GEMM_TRACE): cycle stamps of block 0 of the last f16x2 GEMM
@@ -168,7 +168,11 @@ struct rpr_ctx {
   std::map<GraphKey, hipGraphExec_t> graphs;
   // profiling
   bool profiling = false;
-  struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+  // one timed launch of the eager profile pass. live_dev (nullable): device word holding the live rows of a compacted /
+  // packed launch whose flops and bytes were accounted for live_static rows at enqueue time; read back when the
+  // records are flushed — no synchronisation while a step is being enqueued, so both lanes run side by side exactly as
+  // in the timed region
+  struct Rec { int cls; hipEvent_t a, b; double flops, bytes; const int* live_dev; int live_static; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   rpr_kernel_stats done[RPR_K_COUNT];
@@ -219,6 +223,9 @@ struct Launcher {
   rpr_ctx* c;
   hipStream_t s;
   int err = 0;
+  const int* live_dev = nullptr;   // profile accounting of the launches that follow (see rpr_ctx::Rec)
+  int live_static = 0;
+  void account_live(const int* dev, int rows_static) { live_dev = dev; live_static = rows_static; }
   hipEvent_t get_event() {
     if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -236,7 +243,7 @@ struct Launcher {
     if (e != hipSuccess) { err = hip_fail(e, "kernel launch", __FILE__, __LINE__); return; }
     if (c->profiling && ea && eb) {
       (void)hipEventRecord(eb, s);
-      c->recs.push_back({cls_after ? *cls_after : cls, ea, eb, flops, bytes});
+      c->recs.push_back({cls_after ? *cls_after : cls, ea, eb, flops, bytes, live_dev, live_static});
     }
   }
 };

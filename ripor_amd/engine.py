@@ -522,11 +522,22 @@ class GuardedSearch:
         self._res, self._ticket = res, ticket
         self.repeated = False
         self._done = False
+        self._error: Optional[BaseException] = None
 
     def result(self) -> SearchResult:
         if self._done:
             return self._res
+        if self._error is not None:   # the guard fired and the repeat failed: the first result is known to be invalid
+            raise self._error
+        try:
+            res = self._result()
+        except BaseException as e:
+            self._error = e
+            raise
         self._done = True
+        return res
+
+    def _result(self) -> SearchResult:
         st = self._ticket.flags()
         if st & _lib.STATUS_EMPTY_QUERY:
             raise ValueError("a query has an all-zero attention_mask (no token to attend to)")
@@ -687,27 +698,49 @@ class GradExchange:
         self.works: List = []
         self.buckets: List[tuple] = []
         self.history: List[tuple] = []       # buckets of the last finished exchange, in hand-over order
+        self.error: Optional[BaseException] = None   # first exception raised inside the ctypes callback
         self._cb = _lib.GRAD_BUCKET_CB(self._on_bucket_c)
 
     def _on_bucket_c(self, _user, offset, numel):
-        self.on_bucket(int(offset), int(numel))
+        # ctypes prints and swallows an exception raised inside a callback: the C side would carry on, finish()'s coverage
+        # check would pass and AdamW would run on a bucket that was never reduced. Keep the first error; lngknp_backward /
+        # finish() re-raise it, and nothing is enqueued after it.
+        if self.error is not None:
+            return
+        try:
+            self.on_bucket(int(offset), int(numel))
+        except BaseException as e:   # noqa: BLE001 - must not escape into ctypes
+            self.error = e
 
     def on_bucket(self, offset: int, numel: int):
-        import torch.distributed as dist
-        self.buckets.append((offset, numel))
         if not self.active or numel <= 0:
+            self.buckets.append((offset, numel))
             return
         sl = self.grads[offset:offset + numel]
         if self.dry_run:
             if self.stream is not None:
                 with torch.cuda.stream(self.stream):
                     sl.mul_(1.0)          # reads and rewrites the bucket on the communication stream
-            return
-        if self.stream is not None:
+        elif self.stream is not None:
             with torch.cuda.stream(self.stream):
                 self._exchange(sl)
         else:
             self._exchange(sl)
+        self.buckets.append((offset, numel))   # recorded only once its collective has been enqueued
+
+    def raise_pending(self):
+        """Re-raise an exception caught inside the bucket callback (and forget the half-done exchange)."""
+        if self.error is not None:
+            e, self.error = self.error, None
+            for w in self.works:   # collectives already in flight must not outlive the buffers they reduce
+                try:
+                    w.wait()
+                except Exception:
+                    pass
+            if self.stream is not None:
+                torch.cuda.current_stream(self.grads.device).wait_stream(self.stream)
+            self.works, self.buckets = [], []
+            raise RiporHipError(f"gradient exchange failed inside the bucket callback: {e!r}") from e
 
     def _exchange(self, sl: torch.Tensor):
         import torch.distributed as dist
@@ -737,6 +770,7 @@ class GradExchange:
 
     def finish(self):
         """Join the exchange (the current stream waits for every bucket) and average."""
+        self.raise_pending()
         for w in self.works:
             w.wait()
         if self.stream is not None:
@@ -776,6 +810,7 @@ def lngknp_backward(model: DeviceModel, state: TrainState, input_ids, attention_
                                                   losses.data_ptr(), state.grads.data_ptr(), _stream_ptr(dev),
                                                   exchange.comm_stream_ptr(), exchange.callback(), None),
               "rpr_lngknp_backward_buckets")
+        exchange.raise_pending()
     else:
         check(ctx.lib.rpr_lngknp_backward(ctx.handle, model.handle, ids.data_ptr(), mask.data_ptr(), bz, Lq, codes.data_ptr(), L,
                                           tp.data_ptr(), tn.data_ptr(), pl.data_ptr(), n_prefix, losses.data_ptr(),

@@ -280,12 +280,13 @@ class T5SeqAQEncoderForLngKnpMarginMSE(T5SeqAQEncoder):
             import warnings
             warnings.warn("activation outside the f16 plane range of the split-precision GEMMs: repeating this forward "
                           "with exact fp32 MFMA (RPR_PRECISION=f32 avoids the retry)")
+            saved = ctx.get_precision()   # "f16x2" or "bf16" (a training ctx): whatever it was comes back
             ctx.set_precision("f32")
             try:
                 losses, self.last_position_scores = E.lngknp_forward(*args)
                 ctx.status(clear=True)
             finally:
-                ctx.set_precision("f16x2")
+                ctx.set_precision(saved)
         return {n: losses[i] for i, n in enumerate(names)}
 
     __call__ = forward

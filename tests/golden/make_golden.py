@@ -585,6 +585,146 @@ def make_train_case(name, spec, gen, mod, utils, shim):
     print(f"[golden] {name}: {time.time() - t0:.1f}s losses {dict((k, float(v)) for k, v in losses.items())} -> {path}")
 
 
+# ----------------------------------------------------------------------------- caller fixtures
+# The reference's OWN caller functions — constrained_decode_doc (evaluate.py:87-132), constrained_decode (:45-85),
+# constrained_decode_smtid (:134-178) and the two merge steps t5seq_aq_retrieve_docids_2 (:489-526) /
+# t5seq_aq_get_qid_to_smtid_rankdata_2 (:600-655) — imported from /root/reference/t5_pretrainer/evaluate.py and run on CPU.
+# evaluate.py needs two modules that are not installed (`import faiss`, utils/metrics.py: `from pytrec_eval import
+# RelevanceEvaluator`): both are satisfied by EMPTY stub modules — neither is touched by the functions run here. The
+# module's `generate_for_constrained_prefix_beam_search` is pointed at the same shimmed wrapper every search fixture uses
+# (run_reference: encoder once, repeat_interleave(B), the reference's beam_search_for_constrained_prefix), `evaluate`
+# (metrics, pytrec_eval) is stubbed out and torch.cuda.device_count() is made to return the number of rank files the
+# merge asserts on (:505, :611). Query shards: torch's DistributedSampler(shuffle=False), as evaluate.py:468 builds it.
+CALLER_CASES = {
+    # 2 ranks, batch size 3 (a ragged last batch), duplicated smtids (several docids per smtid), one smtid removed from
+    # the lookup after the trie was built (the "smtid not in smtid_to_docid" branch), a prefix search at 4 of 8 positions
+    "c5_callers_mini": dict(kind="mini", N=600, Q=7, B=4, L=8, Lp=4, V=256, seed=601, world=2, batch_size=3, dup=150,
+                            clusters=24),
+}
+
+
+def load_reference_evaluate(gen):
+    import importlib
+    import importlib.machinery
+    try:
+        import transformers.trainer  # noqa: F401  (pulls `datasets`, which probes for faiss: must happen before the stub exists)
+    except Exception:
+        pass
+    for name in ("faiss", "pytrec_eval"):
+        if name not in sys.modules:
+            m_ = types.ModuleType(name)
+            m_.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            m_.RelevanceEvaluator = object
+            sys.modules[name] = m_
+    ev = importlib.import_module("t5_pretrainer.evaluate")
+    assert os.path.realpath(ev.__file__).startswith(REF + os.sep), ev.__file__
+    return ev
+
+
+def make_caller_case(name, spec, gen, mod, utils, shim):
+    import tempfile
+    from types import SimpleNamespace
+    from torch.utils.data.distributed import DistributedSampler
+    ev = load_reference_evaluate(gen)
+    N, Q, B, L, Lp, V, seed, W, bs = (spec[k] for k in ("N", "Q", "B", "L", "Lp", "V", "seed", "world", "batch_size"))
+    t0 = time.time()
+    dims = synth.mini_dims(L=L, V=V)
+    sd = synth.make_state_dict(dims, seed=seed)
+    model = build_reference_model(mod, dims, sd)
+    codes = synth.make_codes(N, L, V, seed=seed)
+    codes[:, :Lp] = codes[np.arange(N) % spec["clusters"], :Lp]   # few distinct prefixes: a prefix smtid holds many docids
+    codes[N - spec["dup"]:] = codes[: spec["dup"]]           # the last docs repeat the smtids of the first ones
+    d2s, lst = reference_trie(gen, codes)
+    processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
+    ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=20)
+    qids = np.arange(Q, dtype=np.int64) * 7 + 1000
+
+    class Out:
+        pass
+
+    def wrapper(model_, processor_, input_ids=None, attention_mask=None, max_new_tokens=None, num_beams=None,
+                num_return_sequences=None, apply_log_softmax_for_scores=False, **kw):
+        assert num_return_sequences == num_beams and kw.get("return_dict_in_generate")
+        _enc, seqs, scores, _strs, _steps = run_reference(gen, utils, shim, model_, processor_, input_ids, attention_mask,
+                                                          num_beams, max_new_tokens, apply_log_softmax_for_scores)
+        o = Out()
+        o.sequences, o.sequences_scores = torch.from_numpy(seqs), torch.from_numpy(scores)
+        return o
+
+    ev.generate_for_constrained_prefix_beam_search = wrapper
+    ev.evaluate = lambda args: None
+    ev.tqdm = lambda it, **kw: it
+    real_count = torch.cuda.device_count
+    torch.cuda.device_count = lambda: W
+
+    def smtid_lookup(n_tok):     # evaluate.py:439-446 (inside t5seq_aq_retrieve_docids: cannot be called on its own)
+        out = {}
+        for docid, smtids in d2s.items():
+            assert smtids[0] == -1
+            out.setdefault("_".join(str(x) for x in smtids[1:1 + n_tok]), []).append(docid)
+        return out
+
+    def loaders():
+        for r in range(W):
+            idx = list(DistributedSampler(list(range(Q)), num_replicas=W, rank=r, shuffle=False))
+            yield r, idx, [{"id": torch.from_numpy(qids[idx[i:i + bs]]), "input_ids": torch.from_numpy(ids[idx[i:i + bs]]),
+                            "attention_mask": torch.from_numpy(mask[idx[i:i + bs]])} for i in range(0, len(idx), bs)]
+
+    res = {}
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            full = smtid_lookup(L)
+            # first pass to learn what the model returns, then drop the best smtid of the first query from the lookup
+            probe = wrapper(model, processor, input_ids=torch.from_numpy(ids[:1]), attention_mask=torch.from_numpy(mask[:1]),
+                            max_new_tokens=L, num_beams=B, num_return_sequences=B, return_dict_in_generate=True)
+            dropped = utils.convert_ptsmtids_to_strsmtid(probe.sequences.view(-1, B, L + 1), L)[0][0]
+            lookup = {k: v for k, v in full.items() if k != dropped}
+            for variant, ls in (("doc", False), ("doc_logsoftmax", True)):
+                out_dir = os.path.join(tmp, variant, "msmarco_dev")   # get_dataset_name(...) -> "MSMARCO"
+                os.makedirs(os.path.join(tmp, variant, "MSMARCO"))
+                shards = {}
+                for r, idx, batches in loaders():
+                    ev.constrained_decode_doc(model, batches, processor, lookup, L, "cpu", os.path.join(tmp, variant, "MSMARCO"), r,
+                                              topk=B, apply_log_softmax_for_scores=ls)
+                    shards[r] = json.load(open(os.path.join(tmp, variant, "MSMARCO", f"run_{r}.json")))
+                    res.setdefault("shard_indices", {})[r] = idx
+                ev.t5seq_aq_retrieve_docids_2(SimpleNamespace(q_collection_paths=[json.dumps([out_dir])], out_dir=os.path.join(tmp, variant)))
+                res[variant] = dict(shards=shards, merged=json.load(open(os.path.join(tmp, variant, "MSMARCO", "run.json"))))
+            # smtid-level outputs of the full-length search (evaluate.py:45-85)
+            sm_dir = os.path.join(tmp, "smtid")
+            os.makedirs(sm_dir)
+            shards = {}
+            for r, idx, batches in loaders():
+                ev.constrained_decode(model, batches, processor, lookup, L, "cpu", sm_dir, r, topk=B)
+                shards[r] = json.load(open(os.path.join(sm_dir, f"qid_to_smtid_{r}.json")))
+            res["smtid"] = dict(shards=shards)
+            # training-data generation pass: prefix search over the first Lp positions, nested output, merge (:134-178, :600-655)
+            pdir = os.path.join(tmp, "prefix")
+            os.makedirs(pdir)
+            plookup = smtid_lookup(Lp)
+            shards = {}
+            for r, idx, batches in loaders():
+                ev.constrained_decode_smtid(model, batches, processor, plookup, Lp, "cpu", pdir, r, topk=B)
+                shards[r] = json.load(open(os.path.join(pdir, f"qid_smtid_rankdata_{r}.json")))
+            ev.t5seq_aq_get_qid_to_smtid_rankdata_2(SimpleNamespace(out_dir=pdir))
+            res["prefix"] = dict(shards=shards, merged=json.load(open(os.path.join(pdir, "qid_smtid_rankdata.json"))))
+    finally:
+        torch.cuda.device_count = real_count
+    # G6: the index lists of torch's DistributedSampler(shuffle=False) at MSMARCO-dev size
+    samp = {str(w): [list(DistributedSampler(list(range(6980)), num_replicas=w, rank=r, shuffle=False))[:4] +
+                     list(DistributedSampler(list(range(6980)), num_replicas=w, rank=r, shuffle=False))[-4:]
+                     + [len(list(DistributedSampler(list(range(6980)), num_replicas=w, rank=r, shuffle=False)))]
+                     for r in range(w)] for w in (1, 2, 3, 4, 8)}
+    out = dict(spec=json.dumps(dict(spec, name=name, dims=dims.__dict__)), input_ids=ids, attention_mask=mask, codes=codes,
+               qids=qids, dropped_smtid=np.array(dropped), results=np.array(json.dumps(res)),
+               sampler_head_tail_len=np.array(json.dumps(samp)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    n_doc = sum(len(v) for v in res["doc"]["merged"].values())
+    print(f"[golden] {name}: {time.time() - t0:.1f}s, merged run holds {len(res['doc']['merged'])} queries / {n_doc} docids, "
+          f"dropped smtid {dropped} -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -599,6 +739,10 @@ def main():
         if args.only and args.only not in (name, "train"):
             continue
         make_train_case(name, spec, gen, mod, utils, shim)
+    for name, spec in CALLER_CASES.items():
+        if args.only and args.only not in (name, "callers"):
+            continue
+        make_caller_case(name, spec, gen, mod, utils, shim)
 
 
 if __name__ == "__main__":

@@ -123,3 +123,63 @@ def test_prefix_search_shorter_than_model_length(golden_cache):
                 rows = trie.perm[lo[q, b]:hi[q, b]]
                 assert (codes[rows] == tok[q, b][None, :]).all()
                 assert len(rows) == int((codes == tok[q, b][None, :]).all(axis=1).sum())
+
+
+def test_callers_match_the_reference_run_files(tmp_path):
+    """a12 / f2 on the GPU against what the reference's own evaluate.py wrote (tests/golden/c5_callers_mini.npz, see
+    tests/test_callers_golden.py): per-rank run files of constrained_decode_doc (dict and sorted-row-range lookups, raw and
+    log-softmax scores), constrained_decode, the prefix search of constrained_decode_smtid, and both merges — with the HIP
+    search underneath. Scores within 1e-4 per position; docid / smtid sets identical."""
+    from test_callers_golden import CallerFixture
+    from ripor_amd import evaluate as EV
+    from ripor_amd.modeling.t5_generative_retriever import T5forDocIDConfig, T5ForDocIDGeneration
+    from ripor_amd.tasks.generation import PrefixConstrainLogitProcessorFastSparse
+    fx = CallerFixture()
+    model = T5ForDocIDGeneration(T5forDocIDConfig.from_dims(fx.dims), fx.state_dict).to(0)
+    proc = PrefixConstrainLogitProcessorFastSparse.from_codes(fx.codes, fx.V)
+    table = EV.DocidTable(fx.docids)
+    tol = 1e-4
+
+    def same_docs(got, ref, scale, what):
+        assert set(got) == set(ref), f"{what}: {sorted(set(got) ^ set(ref))[:6]}"
+        for k in ref:
+            assert abs(got[k] - ref[k]) <= tol * scale, (what, k, got[k], ref[k])
+
+    extra = set(fx.lookup(fx.L, drop=False)[fx.dropped])
+    for variant, ls in (("doc", False), ("doc_logsoftmax", True)):
+        d = tmp_path / variant
+        d.mkdir()
+        for rank in range(fx.world):
+            ref = fx.res[variant]["shards"][str(rank)]
+            run = EV.constrained_decode_doc(model, fx.batches(rank), proc, fx.lookup(fx.L), fx.L, 0, str(d), rank, topk=fx.B,
+                                            apply_log_softmax_for_scores=ls)
+            rng = EV.constrained_decode_doc(model, fx.batches(rank), proc, table, fx.L, 0, str(d), rank, topk=fx.B,
+                                            apply_log_softmax_for_scores=ls, write=False)
+            assert {str(q) for q in run} == set(ref)
+            for q in ref:
+                same_docs(run[int(q)], ref[q], fx.L, f"{variant} rank {rank} query {q}")
+                same_docs({k: v for k, v in rng[int(q)].items() if k not in extra}, ref[q], fx.L, f"{variant} range lookup, query {q}")
+        merged = EV.merge_runs(str(d), expected_files=fx.world)
+        assert set(merged) == set(fx.res[variant]["merged"])
+        for q, docs in fx.res[variant]["merged"].items():
+            same_docs(merged[q], docs, fx.L, f"{variant} merged query {q}")
+    for rank in range(fx.world):
+        out = EV.constrained_decode(model, fx.batches(rank), proc, fx.lookup(fx.L), fx.L, 0, str(tmp_path), rank, topk=fx.B)
+        for q, ref in fx.res["smtid"]["shards"][str(rank)].items():
+            same_docs(out[int(q)], ref, 1, f"qid_to_smtid rank {rank} query {q}")
+    d = tmp_path / "prefix"
+    d.mkdir()
+    for rank in range(fx.world):
+        ref = fx.res["prefix"]["shards"][str(rank)]
+        for lookup in (fx.lookup(fx.Lp, drop=False), table):
+            out = EV.constrained_decode_smtid(model, fx.batches(rank), proc, lookup, fx.Lp, 0, str(d), rank, topk=fx.B,
+                                              write=lookup is table)
+            for q in ref:
+                assert set(out[int(q)]) == set(ref[q])
+                for s in ref[q]:
+                    same_docs(out[int(q)][s], ref[q][s], fx.Lp, f"prefix search rank {rank} query {q} smtid {s}")
+    merged = EV.merge_qid_smtid_rankdata(str(d), expected_files=fx.world)
+    for q, by in fx.res["prefix"]["merged"].items():
+        assert set(merged[q]) == set(by)
+        for s in by:
+            same_docs(merged[q][s], by[s], fx.Lp, f"prefix merged query {q} smtid {s}")

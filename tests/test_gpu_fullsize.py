@@ -126,3 +126,89 @@ def test_split_precision_agrees_with_exact_fp32(world):
             if min(up, dn) > 2e-4:
                 assert (tt[q, r] == rt[q, r]).all(), f"query {q} rank {r}"
     assert diverged <= rt.shape[0] // 8, diverged
+
+
+# ---- the bench's own configuration --------------------------------------------------------------------------------------
+# bench.py times 2150 queries per step as two half batches on the CU-masked lanes, 256x256 ping-pong GEMMs with
+# ~300 000-row tail launches and the optimistic forced tail on the 8.8 M-doc trie (config 4: 162 queries, beam 100). The
+# pieces are tested separately at small sizes; here the composition at size is compared with the most conservative path
+# the library has: one stream, plain step-by-step loop (reference generation.py:423-540, one iteration per position),
+# exact fp32 MFMA GEMMs.
+
+def _compare_runs(ref, got, B, what, max_diverged_frac):
+    rt, rs = ref.tokens.cpu().numpy(), ref.scores.cpu().numpy().astype(np.float64)
+    tt, ts = got.tokens.cpu().numpy(), got.scores.cpu().numpy().astype(np.float64)
+    step_scores = ref.taps["step_scores"].cpu().numpy()      # [L, Q, B] float64, sorted desc per step (the kept B)
+    Q = rt.shape[0]
+    diverged, ranks_exact, ranks_tied, worst = 0, 0, 0, 0.0
+    for q in range(Q):
+        ref_set = {tuple(x): r for r, x in enumerate(rt[q].tolist())}
+        got_set = {tuple(x): r for r, x in enumerate(tt[q].tolist())}
+        assert len(got_set) == B, f"{what}: query {q} returns a duplicate smtid"
+        if ref_set.keys() != got_set.keys():
+            # only a pruning near-tie of the fp32 run itself may change WHICH sequences survive
+            gaps = -np.diff(step_scores[:, q, :], axis=1)
+            assert gaps.min() < 1e-3, f"{what}: query {q}: smtid sets differ although the fp32 run has no near-tie"
+            diverged += 1
+            continue
+        for k, r in ref_set.items():
+            err = abs(ts[q, got_set[k]] - rs[q, r])
+            worst = max(worst, err)
+            assert err <= 1e-4, f"{what}: query {q} ref rank {r}: score differs by {err:.3g}"
+        for r in range(B):
+            up = rs[q, r - 1] - rs[q, r] if r else np.inf
+            dn = rs[q, r] - rs[q, r + 1] if r + 1 < B else np.inf
+            if min(up, dn) > 2e-4:
+                ranks_exact += 1
+                assert (tt[q, r] == rt[q, r]).all(), f"{what}: query {q} rank {r} differs"
+            else:
+                ranks_tied += 1
+    print(f"[parity] {what}: {Q} queries, {ranks_exact} ranks identical, {ranks_tied} inside 2e-4 near-ties, "
+          f"{diverged} queries excused by a pruning near-tie of the fp32 run, worst score difference {worst:.3g}")
+    assert diverged <= max(1, int(max_diverged_frac * Q)), (what, diverged)
+    assert ranks_exact >= 0.9 * Q * B, (what, ranks_exact)
+
+
+def test_bench_configuration_matches_plain_fp32_loop(world):
+    """The timed configuration of bench.py (config 2: 2150 queries; config 4: 162 queries at beam 100) in its default
+    settings against one stream / no forced tail / exact fp32 on the same batch."""
+    E, ctx, model, trie, codes, _, _, B = world
+    from ripor_amd.utils import synth
+    nq = 2150 if B == 10 else 162
+    ids, mask = synth.make_queries(nq, vocab_size=model.cfg.vocab_size, seed=4242)
+    ids, mask = torch.from_numpy(ids), torch.from_numpy(mask)
+    saved_mode, saved_split = ctx.forced_tail(), ctx.lane_split()
+    try:
+        # the conservative path; taps give the per-step kept scores (they also switch the forks and the lanes off)
+        ctx.set_precision("f32")
+        ctx.set_forced_tail(0)
+        ctx.set_lane_split(0)
+        ref = E.search(model, trie, ids, mask, B, L, taps=True)
+        torch.cuda.synchronize()
+        assert ctx.last_fork_stats() == []
+        # the bench's settings
+        ctx.set_precision("f16x2")
+        ctx.set_forced_tail(2)
+        ctx.set_lane_split(saved_split if saved_split > 0 else 10240)
+        assert 0 < ctx.lane_split() <= nq * B, "the lane split must be active for this batch"
+        ctx.status(clear=True)
+        got = E.search(model, trie, ids, mask, B, L)
+        torch.cuda.synchronize()
+        st = ctx.status(clear=True)
+        forks = ctx.last_fork_stats()
+        assert forks and forks[0]["forced"] > 0.5 * nq, forks      # the forced tail did carry the batch
+        assert not (st & 1), "saturation flag raised in the bench configuration"
+        if st & 4:   # optimistic mode left a query unforced: the guard of bench.py / search_guarded repeats in mode 1
+            ctx.set_forced_tail(1)
+            got = E.search(model, trie, ids, mask, B, L)
+            torch.cuda.synchronize()
+        lo, hi = got.row_lo.cpu().numpy(), got.row_hi.cpu().numpy()
+        assert (hi > lo).all(), "a returned smtid is not a trie leaf"
+        tok = got.tokens.cpu().numpy()
+        first = trie.perm[lo.reshape(-1)]
+        assert (codes[first] == tok.reshape(-1, L)).all(), "returned tokens are not the code rows of their ranges"
+        _compare_runs(ref, got, B, f"bench configuration ({nq} queries, beam {B}) vs plain fp32 loop", 0.02)
+    finally:
+        ctx.set_precision("f16x2")
+        ctx.set_forced_tail(saved_mode)
+        ctx.set_lane_split(saved_split)
