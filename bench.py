@@ -183,7 +183,32 @@ def _leftover_guard(ctx, fn):
     return out
 
 
-def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=2):
+def _profiled(ctx, fn):
+    """One eager pass of fn() with hipEvents around every launch (the library's profile mode) -> per-class stats."""
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return ctx.profile_get()
+    finally:
+        ctx.profile_enable(False)
+
+
+def _gemm_roofline(stats, peak_tflops, cu_fraction, kernel, note):
+    """`roofline` object of a secondary leg: the GEMM launches of one profiled pass (dominant + small-tile kernels together:
+    these legs run mixed tile shapes) against the MFMA peak of the arithmetic they use."""
+    g, gs = stats["gemm"], stats["gemm_small"]
+    ms, fl, n = g["total_ms"] + gs["total_ms"], g["flops"] + gs["flops"], g["launches"] + gs["launches"]
+    tot = sum(v["total_ms"] for v in stats.values())
+    ach = fl / max(1e-9, ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak_tflops * cu_fraction, "unit": "TFLOP/s",
+            "frac": ach / (peak_tflops * cu_fraction), "cu_fraction": cu_fraction, "traffic": None,
+            "gemm_launches": n, "avg_launch_us": ms * 1e3 / max(1, n), "gemm_ms": ms, "all_kernels_ms": tot,
+            "gemm_share_of_kernel_time": ms / max(1e-9, tot), "note": note}
+
+
+def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=5):
     """BASELINE config 4: t5-large dims, the same 8.8M-doc trie, beam 100, len 32."""
     dims = synth.t5_large_dims(L=L)
     t0 = time.time()
@@ -192,8 +217,14 @@ def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=2):
     batches = _query_batches(synth, dims, queries, 2, dev, seed=404)
     (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, 100, L, steps))
     ok = int((r.row_hi > r.row_lo).sum().item())
+    lanes = 0 < ctx.lane_split() <= queries * 100
+    st = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], 100, L))
+    roof = _gemm_roofline(st, PEAK_F16_MFMA_TFLOPS / 3.0, 0.5 if lanes else 1.0, "rpr::gemm_h2_pp_kernel (+ small-tile kernels)",
+                          "algorithmic 2MNK flops of every projection launch of one step / their summed event durations; 3 f16 "
+                          "MFMAs per product -> peak 2500/3 TF/s, halved per launch when the step runs as two CU-masked lanes")
     out = {"workload": f"t5-large dims (d 1024, d_ff 4096, 24+24 layers), {trie.N}-doc trie, beams=100, len={L}, {queries} queries/step",
            "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps, "queries_per_step": queries,
+           "roofline": roof, "lanes": 2 if lanes else 1,
            "dtype": "f32 via f16x2-split MFMA (fp32 accumulate)", "valid_leaves": f"{ok}/{queries * 100}",
            "forks_last_step": ctx.last_fork_stats(), "leftover_fallback_taken": fb, "weights_s": round(t_w, 1)}
     del model
@@ -258,7 +289,7 @@ def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
     return out
 
 
-def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=3):
+def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=5):
     """the training-data generation callers (evaluate.py:134-178; full_evaluate_t5seq_aq_encoder.sh:117-147):
     the same search at max_new_token 4 / 8 / 16 with topk = 100."""
     out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams=100, {queries} queries/step, prefix search", "unit": "queries/s"}
@@ -270,15 +301,13 @@ def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=3):
     return out
 
 
-def secondary_skew(E, synth, ctx, model, dims, dev, docs, B, L, V, queries, steps=2):
-    """The clustered trie of SURVEY §8(d): residual-quantiser codes are imbalanced (aq_preprocess/
-    create_customized_smtid_file.py:33-59) — squared-uniform tokens on the first three levels plus 10 % of the docs
-    sharing their smtid with another doc. Beams stay on wide ranges longer, forks come later."""
+def secondary_skew(E, synth, ctx, model, dims, dev, docs, B, L, V, queries, steps=5):
+    """The skewed trie of SURVEY §8(d): Zipf s = 1.0 on levels 1-3 — residual-quantiser codes are imbalanced
+    (aq_preprocess/create_customized_smtid_file.py:33-59) — plus 10 % of the docs sharing their smtid with another doc
+    (evaluate.py:439-446 keeps every docid of an smtid). Popular prefixes stay dense for longer: the automatic forks move
+    from {4, 6} to {5, 7} and more queries walk on after the first one."""
     t0 = time.time()
-    codes = synth.make_codes_fast(docs, L, V, seed=synth.SEED + 1)
-    lv = min(3, L)
-    u = (synth.hash_u64(f"bench_skew/{docs}", docs * lv, synth.SEED).reshape(docs, lv) >> np.uint64(44)).astype(np.float64) / float(1 << 20)
-    codes[:, :lv] = np.minimum((u * u * V).astype(np.int64), V - 1).astype(codes.dtype)
+    codes = synth.make_codes_fast(docs, L, V, seed=synth.SEED + 1, zipf=1.0)
     ndup = docs // 10
     src = (synth.hash_u64(f"bench_dup/{docs}", ndup, synth.SEED) % np.uint64(docs)).astype(np.int64)
     codes[docs - ndup:] = codes[src]
@@ -296,7 +325,7 @@ def secondary_skew(E, synth, ctx, model, dims, dev, docs, B, L, V, queries, step
     tot = sum(v["total_ms"] for v in st.values())
     ok = int((r.row_hi > r.row_lo).sum().item())
     multi = int((r.row_hi - r.row_lo > 1).sum().item())
-    out = {"workload": f"t5-base dims, {docs}-doc SKEWED trie (squared-uniform codes on levels 1-3, 10 % duplicated smtids), "
+    out = {"workload": f"t5-base dims, {docs}-doc SKEWED trie (Zipf s=1.0 codes on levels 1-3 as SURVEY 8d asks, 10 % duplicated smtids), "
                        f"beams={B}, len={L}, {queries} queries/step",
            "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps,
            "forks_last_step": forks, "leftover_fallback_taken": fb,
@@ -305,6 +334,33 @@ def secondary_skew(E, synth, ctx, model, dims, dev, docs, B, L, V, queries, step
            "valid_leaves": f"{ok}/{queries * B}", "returned_smtids_with_several_docs": multi, "trie_build_s": round(t_trie, 1),
            "single_sequence_node_share_by_depth": [round(float(x), 4) for x in frac[:10]]}
     del trie
+    return out
+
+
+def secondary_v1024(E, synth, ctx, dev, docs, B, queries, steps=5):
+    """RIPOR's 16 x 1024 codebook variant (reference full_16_1024_scripts/full_evaluate_t5seq_aq_encoder.sh:19-22: M = 16,
+    nbits = 10): t5-base dims, smtids of 16 tokens over 1024-entry codebooks, the same number of docs and queries."""
+    L, V = 16, 1024
+    dims = synth.t5_base_dims(L=L, V=V)
+    t0 = time.time()
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+    codes = synth.make_codes_fast(docs, L, V, seed=synth.SEED + 2)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    del codes
+    t_setup = time.time() - t0
+    batches = _query_batches(synth, dims, queries, 2, dev, seed=505)
+    (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, B, L, steps))
+    forks = ctx.last_fork_stats()
+    ok = int((r.row_hi > r.row_lo).sum().item())
+    lanes = 0 < ctx.lane_split() <= queries * B
+    st = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], B, L))
+    out = {"workload": f"t5-base dims, {docs}-doc trie of 16 x 1024 codes, beams={B}, len={L}, {queries} queries/step",
+           "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps, "forks_last_step": forks,
+           "leftover_fallback_taken": fb, "valid_leaves": f"{ok}/{queries * B}", "setup_s": round(t_setup, 1),
+           "roofline": _gemm_roofline(st, PEAK_F16_MFMA_TFLOPS / 3.0, 0.5 if lanes else 1.0, "rpr::gemm_h2_pp_kernel (+ small-tile kernels)",
+                                      "2MNK flops of every projection launch of one step / summed event durations; 3 f16 MFMAs per product"),
+           "kernel_breakdown_ms": {k: round(v["total_ms"], 3) for k, v in st.items()}}
+    del model, trie
     return out
 
 
@@ -350,12 +406,19 @@ def secondary_train_step(E, synth, ctx, dev, world, rank, bz=128, L=32, steps=5,
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         prec = ctx.get_precision()
+        st = _profiled(ctx, step)
+        peak = {"bf16": PEAK_F16_MFMA_TFLOPS, "f16x2": PEAK_F16_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS}[prec]
+        roof = _gemm_roofline(st, peak, 1.0, "rpr::gemm_h2_pp_kernel / gemm_h2_dma_kernel" + (" <BF16>" if prec == "bf16" else ""),
+                              "2MNK flops of every GEMM launch of one optimisation step (forward with saved activations, input and "
+                              "weight gradients) / their summed event durations (side-stream launches overlap the main stream's, so "
+                              "the sum can exceed the step's wall clock); peak = dense MFMA peak of the arithmetic "
+                              "(bf16: one MFMA per product; f16x2: three)")
     finally:
         ctx.set_precision(saved)
     out = {"workload": f"lng_knp margin-MSE fine-tune step (forward + backward + gradient all-reduce + clip + AdamW), t5-base dims, "
                        f"bz={bz}/GPU, smtid len {L}, queries padded to {int(Lq)}",
            "value": world * bz / dt, "unit": "examples/s", "ms_per_step": dt * 1e3, "steps": steps, "n_gpus": world,
-           "gemm_arithmetic": prec, "loss_first": [float(x) for x in first], "loss_last": [float(x) for x in last],
+           "gemm_arithmetic": prec, "roofline": roof, "loss_first": [float(x) for x in first], "loss_last": [float(x) for x in last],
            "allreduce_bytes_per_step_per_rank": int(state.total * 4) if world > 1 else 0,
            "allreduce": E.allreduce_mode() if world > 1 else "none (1 rank)", "params": int(state.total)}
     del model, state
@@ -390,7 +453,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--secondary", default="train,config4,f2,skew,latency",
+    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,v1024",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
                          "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
@@ -810,6 +873,8 @@ def main():
             leg("f2", lambda: secondary_f2(E, synth, ctx, model, trie, dims, dev))
         if "skew" in legs:
             leg("skew", lambda: secondary_skew(E, synth, ctx, model, dims, dev, args.docs, B, L, V, Q))
+        if "v1024" in legs and args.model == "t5-base":
+            leg("v1024", lambda: secondary_v1024(E, synth, ctx, dev, args.docs, B, Q))
         if "latency" in legs and args.model == "t5-base":
             leg("latency", lambda: secondary_latency(E, synth, ctx, model, trie, dims, dev, L))
         if "config4" in legs and args.model == "t5-base":

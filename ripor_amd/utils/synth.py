@@ -181,14 +181,34 @@ def make_state_dict(dims: ModelDims, seed: int = SEED, logit_scale: float = 0.35
 # --------------------------------------------------------------------------- docid codes
 
 
-def make_codes(N: int, L: int, V: int, seed: int = SEED, skew: bool = False) -> np.ndarray:
+def zipf_tokens(name: str, shape, V: int, s: float = 1.0, seed: int = SEED) -> np.ndarray:
+    """Tokens in [0, V) with P(token = k) proportional to (k + 1)^-s (Zipf over the V symbols; token 0 the most frequent):
+    inverse-CDF sampling of 40-bit uniform variates from the counter hash. s = 1.0 on the first three levels is SURVEY.md
+    §8(d)'s stand-in for the imbalance of residual-quantiser codes (reference
+    aq_preprocess/create_customized_smtid_file.py:33-59 writes whatever the RQ index assigned)."""
+    w = 1.0 / np.power(np.arange(1, V + 1, dtype=np.float64), float(s))
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.int64)
+    chunk = 1 << 23
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        u = (hash_u64(name, b - a, seed, offset=a) >> np.uint64(24)).astype(np.float64) / float(1 << 40)
+        out[a:b] = np.minimum(np.searchsorted(cdf, u, side="right"), V - 1)
+    return out.reshape(shape)
+
+
+def make_codes(N: int, L: int, V: int, seed: int = SEED, skew: bool = False, zipf: Optional[float] = None) -> np.ndarray:
     """Synthetic ``docid_to_smtid`` code matrix ``[N, L]`` (docid = row index), i.i.d. uniform
-    tokens. ``skew`` squares the uniform variate on the first three levels to
-    mimic residual-quantiser code imbalance."""
+    tokens (SURVEY.md §8d). ``zipf`` = s draws the first three levels from Zipf(s) (§8d's skewed variant, s = 1.0);
+    ``skew`` (older, milder) squares the uniform variate on those levels."""
     dt = np.uint8 if V <= 256 else np.uint16
     codes = randint(f"codes/{N}x{L}x{V}", (N, L), 0, V, seed)
-    if skew:
-        lv = min(3, L)
+    lv = min(3, L)
+    if zipf is not None:
+        codes[:, :lv] = zipf_tokens(f"codes_zipf/{N}x{V}", (N, lv), V, zipf, seed)
+    elif skew:
         u = randint(f"codes_skew/{N}", (N, lv), 0, 1 << 20, seed).astype(np.float64) / float(1 << 20)
         codes[:, :lv] = np.minimum((u * u * V).astype(np.int64), V - 1)
     return codes.astype(dt)
@@ -227,9 +247,10 @@ def make_queries(Q: int, vocab_size: int = 32128, seed: int = SEED, mean_len: fl
     return ids, mask
 
 
-def make_codes_fast(N: int, L: int, V: int, seed: int = SEED) -> np.ndarray:
+def make_codes_fast(N: int, L: int, V: int, seed: int = SEED, zipf: Optional[float] = None) -> np.ndarray:
     """Large-trie variant of :func:`make_codes` (8.8 M x 32): one hash yields four codes
-    (16 bits each, reduced mod V), ~4x fewer hash evaluations. Distribution: i.i.d. uniform."""
+    (16 bits each, reduced mod V), ~4x fewer hash evaluations. Distribution: i.i.d. uniform; ``zipf`` = s
+    redraws the first three levels from Zipf(s) (SURVEY.md §8d's skewed trie)."""
     n = N * L
     n4 = (n + 3) // 4
     out = np.empty(n4 * 4, dtype=np.uint16)
@@ -240,4 +261,8 @@ def make_codes_fast(N: int, L: int, V: int, seed: int = SEED) -> np.ndarray:
         out[4 * s:4 * e] = h.view(np.uint16)
     if V < 65536:
         out %= np.uint16(V)
-    return out[:n].reshape(N, L)
+    out = out[:n].reshape(N, L)
+    if zipf is not None:
+        lv = min(3, L)
+        out[:, :lv] = zipf_tokens(f"codes_fast_zipf/{N}x{V}", (N, lv), V, zipf, seed).astype(np.uint16)
+    return out

@@ -399,6 +399,10 @@ CASES = {
     # fixtures shrink d_ff and the encoder): beam 100, short smtids so that the reference's full-prefix recompute stays
     # within minutes on the build container's 8 cores. Pins the K = 4096 FF path inside a 24-layer decoder end to end.
     "g5_largefull_b100_l8": dict(kind="large_full", N=3000, Q=2, B=100, L=8, V=256, seed=501),
+    # RIPOR's 16 x 1024 codebook variant (reference full_16_1024_scripts/full_evaluate_t5seq_aq_encoder.sh:19-22: M=16,
+    # nbits=10) at the real t5-base dimensions, at the headline beam and at the training-data beam
+    "g6_base_v1024_b10_l16": dict(kind="base", N=3000, Q=4, B=10, L=16, V=1024, seed=601),
+    "g6_base_v1024_b100_l16": dict(kind="base", N=3000, Q=2, B=100, L=16, V=1024, seed=602),
 }
 
 # SURVEY §8 row f4 (BASELINE config 5): T5SeqAQEncoderForLngKnpMarginMSE.forward on a seeded batch

@@ -401,3 +401,52 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
         assert float((results["forced"].scores - ref.scores).abs().max()) <= 0.3 * SCORE_TOL
         print(f"[ties] {variant}: {tied} exactly tied neighbours among {int(live.sum())} returned beams; "
               f"families compared bit for bit: {families}")
+
+
+def test_zipf_codes_of_survey_8d(E):
+    """SURVEY.md §8(d)'s skewed trie: Zipf s = 1.0 on the first three levels (the imbalance of residual-quantiser codes,
+    reference aq_preprocess/create_customized_smtid_file.py:33-59). Popular prefixes are dense, so the automatic forks
+    come later than on uniform codes and a share of the queries walks on after the first one."""
+    from ripor_amd.utils import synth
+    L, V, B, N = 16, 256, 10, 400_000
+    codes = synth.make_codes(N, L, V, seed=71, zipf=1.0)
+    uni = synth.make_codes(N, L, V, seed=71)
+    f_z, f_u = E.trie_single_frac(codes, L), E.trie_single_frac(uni, L)
+    # the popular prefixes stay dense for longer (the many rare prefixes are single-sequence nodes early on, which is why
+    # depth 2 goes the other way): the depth at which nearly every node holds one sequence moves from 3 to 4-5
+    assert f_z[3] < f_u[3] and f_z[4] < f_u[4], (f_z[:6], f_u[:6])
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=64)
+    d_z = ctx.fork_depths(model, trie, 64, B, L)
+    trie_u = E.DeviceTrie.from_codes(ctx, uni, V)
+    d_u = ctx.fork_depths(model, trie_u, 64, B, L)
+    assert d_z and d_u and d_z[0] >= d_u[0], (d_z, d_u)
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"zipf 400k, forks {d_z} (uniform: {d_u})")
+    assert stats[0]["forced"] > 0
+    for mode in (2,):   # optimistic mode with its guard
+        ctx.set_forced_tail(mode)
+        try:
+            g = E.search_guarded(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L).result()
+        finally:
+            ctx.set_forced_tail(True)
+        assert torch.equal(g.tokens, res.tokens)
+
+
+def test_late_first_fork(E):
+    """A trie whose first automatic fork is >= 8: nine levels over a 3-symbol alphabet (19 683 prefixes holding ~6 docs
+    each), uniform codes below. Ten sequential steps with partly dead beams (3 and 9 live candidates at depths 1 and 2),
+    then the tail pass over the remaining 14 positions; also at an explicit later pair of forks."""
+    from ripor_amd.utils import synth
+    L, V, B, N = 24, 256, 6, 120_000
+    codes = synth.make_codes(N, L, V, seed=81)
+    codes[:, :9] = synth.randint("late_fork", (N, 9), 0, 3, seed=81).astype(codes.dtype)
+    f = E.trie_single_frac(codes, L)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=40)
+    depths = ctx.fork_depths(model, trie, 40, B, L)
+    assert depths and depths[0] >= 8, (depths, f[:14])
+    res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"late fork {depths}")
+    assert stats[0]["forced"] > 0, stats
+    ctx.set_fork_depths([depths[0] + 1, depths[0] + 3])
+    try:
+        _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"late fork, explicit {[depths[0] + 1, depths[0] + 3]}")
+    finally:
+        ctx.set_fork_depths(None)
