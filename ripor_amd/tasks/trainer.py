@@ -1,0 +1,151 @@
+"""The optimisation loop around the prefix-oriented ranking fine-tune step: what the reference gets
+from HF ``Trainer`` + ``CondDocID_DRTrainer`` (tasks/trainer.py:203-275, main.py:127-186) for the
+``t5seq_aq_encoder_lng_knp_margin_mse`` loss, restated for a model whose forward, backward and AdamW run in
+libripor_hip.so (``T5SeqAQEncoderForLngKnpMarginMSE.training_step``):
+
+* data-parallel sampling: ``DistributedSampler(shuffle=True, seed)`` re-seeded per epoch, ``per_device_train_batch_size``
+  examples per rank and step, incomplete last batches kept (HF default ``dataloader_drop_last=False``);
+* learning rate: linear warm-up over ``ceil(max_steps * warmup_ratio)`` steps to ``learning_rate``, then linear decay to 0 at
+  ``max_steps`` — HF ``get_linear_schedule_with_warmup`` as ``TrainingArguments(warmup_ratio=…, lr_scheduler_type=
+  "linear")`` instantiates it (main.py:135-137; full_lng_knp_train_pipline.sh:80-99: lr 1e-4, warmup_ratio 0.04);
+* every step: loss = sum of the task losses (``ln_to_weight`` 1 each), gradient all-reduce across the ranks overlapped with
+  the backward (RCCL, engine.GradExchange), ``clip_grad_norm_(1.0)``, AdamW(betas (0.9, 0.999), eps 1e-8, weight_decay 0);
+* checkpoints every ``save_steps`` under ``output_dir/checkpoint-<step>`` (at most ``save_total_limit``) and the final
+  model under ``output_dir/checkpoint`` in the layout ``T5SeqAQEncoder.from_pretrained`` reads (config.json +
+  pytorch_model.bin under the reference's tensor names + tokenizer files), like ``save_torch_model_and_tokenizer``.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import shutil
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+
+def get_warmup_steps(max_steps: int, warmup_ratio: float, warmup_steps: int = 0) -> int:
+    """HF ``TrainingArguments.get_warmup_steps``."""
+    return warmup_steps if warmup_steps > 0 else math.ceil(max_steps * warmup_ratio)
+
+
+def linear_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int) -> float:
+    """Multiplier of the base learning rate at optimizer step ``step`` (0-based): HF ``get_linear_schedule_with_warmup``."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+
+
+@dataclass
+class LngKnpTrainingArgs:
+    """The fields of the reference's ``CondDocID_TrainingArgs`` this loop uses (main.py:131-155)."""
+    output_dir: str
+    learning_rate: float = 1e-4
+    warmup_ratio: float = 0.04
+    per_device_train_batch_size: int = 96
+    num_train_epochs: float = 3
+    max_steps: int = -1
+    logging_steps: int = 50
+    save_steps: int = 15_000
+    save_total_limit: int = 5
+    seed: int = 2
+    max_grad_norm: float = 1.0
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    bf16: bool = True               # --use_fp16 in the reference's scripts means bf16 autocast (main.py:152)
+    task_names: Optional[List[str]] = None
+    ln_to_weight: Dict[str, float] = field(default_factory=dict)
+
+
+class LngKnpTrainer:
+    def __init__(self, model, train_dataset, data_collator, args: LngKnpTrainingArgs, log: Callable[[str], None] = print):
+        import torch.distributed as dist
+        self.model, self.dataset, self.collator, self.args, self.log = model, train_dataset, data_collator, args, log
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        for name, w in (args.ln_to_weight or {}).items():
+            if float(w) != 1.0:   # the device-side backward sums the task losses with unit weights (arguments.py:109-119 default)
+                raise NotImplementedError(f"ln_to_weight[{name!r}] = {w}: only unit task weights are built")
+        per_epoch = math.ceil(math.ceil(len(train_dataset) / self.world) / args.per_device_train_batch_size)
+        self.steps_per_epoch = max(1, per_epoch)
+        self.max_steps = args.max_steps if args.max_steps > 0 else math.ceil(args.num_train_epochs * self.steps_per_epoch)
+        self.warmup_steps = get_warmup_steps(self.max_steps, args.warmup_ratio)
+        self.global_step = 0
+        self.history: List[dict] = []
+
+    def lr_at(self, step: int) -> float:
+        return self.args.learning_rate * linear_schedule_with_warmup(step, self.warmup_steps, self.max_steps)
+
+    def _loader(self, epoch: int):
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(self.dataset, num_replicas=self.world, rank=self.rank, shuffle=True, seed=self.args.seed)
+        sampler.set_epoch(epoch)
+        return DataLoader(self.dataset, batch_size=self.args.per_device_train_batch_size, sampler=sampler,
+                          collate_fn=self.collator, drop_last=False)
+
+    def train(self):
+        import random
+        a = self.args
+        random.seed(a.seed)          # the dataset draws its negatives from Python's RNG (dataset.py:479-483)
+        torch.manual_seed(a.seed)
+        if a.bf16:                   # the reference's autocast: every GEMM operand of the step rounded to bf16, fp32 accumulation
+            self.model.base_model.engine_model().ctx.set_precision("bf16")
+        t0, epoch, window = time.time(), 0, []
+        while self.global_step < self.max_steps:
+            for batch in self._loader(epoch):
+                if self.global_step >= self.max_steps:
+                    break
+                lr = self.lr_at(self.global_step)
+                losses = self.model.training_step(lr=lr, max_grad_norm=a.max_grad_norm, betas=(a.adam_beta1, a.adam_beta2),
+                                                  eps=a.adam_epsilon, weight_decay=a.weight_decay, **batch)
+                self.global_step += 1
+                window.append(losses)
+                if self.global_step % a.logging_steps == 0 or self.global_step == self.max_steps:
+                    mean = {k: float(torch.stack([w[k] for w in window]).mean()) for k in window[0]}   # one sync per log line
+                    rec = dict(step=self.global_step, epoch=self.global_step / self.steps_per_epoch, learning_rate=lr,
+                               loss=sum(mean.values()), **mean, elapsed_s=time.time() - t0)
+                    self.history.append(rec)
+                    if self.rank == 0:
+                        self.log(json.dumps(rec))
+                    window = []
+                if a.save_steps > 0 and self.global_step % a.save_steps == 0 and self.rank == 0:
+                    self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
+                    self._rotate()
+            epoch += 1
+        return self.history
+
+    # ---- checkpoints ------------------------------------------------------------------------------------------------
+    def save_checkpoint(self, path: str, tokenizer=None):
+        """config.json + pytorch_model.bin under the reference checkpoint's tensor names (DeviceModel.export_state_dict:
+        the weights as the optimizer left them on the device) [+ tokenizer files]."""
+        from ..modeling.t5_generative_retriever import expected_keys
+        os.makedirs(path, exist_ok=True)
+        base = self.model.base_model
+        sd = {k: v.cpu() for k, v in base.engine_model().export_state_dict().items()}
+        base._sd = {k: sd[k] for k in expected_keys(base.config)}   # host copy follows the device (the binding stays)
+        base.save_pretrained(path)
+        if tokenizer is not None:
+            tokenizer.save_pretrained(path)
+        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+            json.dump(dict(global_step=self.global_step, max_steps=self.max_steps, warmup_steps=self.warmup_steps,
+                           learning_rate=self.args.learning_rate, log_history=self.history), f, indent=1)
+
+    def _rotate(self):
+        lim = self.args.save_total_limit
+        if not lim or lim <= 0:
+            return
+        cks = sorted((int(d.split("-")[1]), d) for d in os.listdir(self.args.output_dir)
+                     if d.startswith("checkpoint-") and d.split("-")[1].isdigit())
+        for _, d in cks[:-lim]:
+            shutil.rmtree(os.path.join(self.args.output_dir, d), ignore_errors=True)
+
+    def save_torch_model_and_tokenizer(self, tokenizer=None):
+        """reference tasks/trainer.py: the final model under ``output_dir/checkpoint``."""
+        if self.rank == 0:
+            self.save_checkpoint(os.path.join(self.args.output_dir, "checkpoint"), tokenizer)

@@ -729,6 +729,98 @@ def make_caller_case(name, spec, gen, mod, utils, shim):
           f"dropped smtid {dropped} -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)")
 
 
+# ----------------------------------------------------------------------------- data side of the fine-tune (row f4)
+class WordTokenizer:
+    """Whitespace tokenizer with the HF call signature the reference collator uses (no pretrained tokenizer offline): word ->
+    3 + crc32 % 97, ``</s>`` = 1 appended, padded with 0 to the longest of the batch, truncated to max_length."""
+
+    def __call__(self, texts, add_special_tokens=True, padding="longest", truncation="longest_first", max_length=64,
+                 return_attention_mask=True, return_tensors="pt"):
+        import zlib
+        assert padding == "longest" and truncation == "longest_first" and add_special_tokens and return_tensors == "pt"
+        ids = [[3 + zlib.crc32(w.encode()) % 97 for w in t.split()][: max_length - 1] + [1] for t in texts]
+        m = max(len(x) for x in ids)
+        return {"input_ids": torch.tensor([x + [0] * (m - len(x)) for x in ids]),
+                "attention_mask": torch.tensor([[1] * len(x) + [0] * (m - len(x)) for x in ids])}
+
+
+def lngknp_files(root, L, n_ex=5, n_cand=4, seed=0):
+    """The three inputs of LngKnpMarginMSEforT5SeqAQDataset: examples (jsonl), query collection, docid_to_smtid.json."""
+    rng = np.random.RandomState(1234 + L + seed)
+    os.makedirs(os.path.join(root, "queries"), exist_ok=True)
+    os.makedirs(os.path.join(root, "docs"), exist_ok=True)
+    with open(os.path.join(root, "queries", "raw.tsv"), "w") as f:
+        for q in range(n_ex):
+            f.write(f"{100 + q}\t" + " ".join(f"w{int(x)}" for x in rng.randint(0, 50, size=3 + q)) + " \n")
+    with open(os.path.join(root, "docs", "raw.tsv"), "w") as f:
+        f.write("0\tunused document text\n")
+    d2s, lines = {}, []
+    for q in range(n_ex):
+        docids = [str(1000 + q * 10 + j) for j in range(n_cand)]
+        smtids = []
+        for d in docids:
+            codes = [int(x) for x in rng.randint(0, 256, size=L)]
+            d2s[d] = [-1] + codes
+            smtids.append("_".join(str(c) for c in codes))
+        ex = {"qid": str(100 + q), "docids": docids, "smtids": smtids, "scores": [float(x) for x in rng.uniform(-5, 30, n_cand).round(3)]}
+        for k in (4, 8, 16):
+            if k < L:
+                ex[f"smtid_{k}_scores"] = [float(x) for x in rng.uniform(-5, 30, n_cand).round(3)]
+        lines.append(json.dumps(ex))
+    with open(os.path.join(root, "examples.jsonl"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(root, "docid_to_smtid.json"), "w") as f:
+        json.dump(d2s, f)
+    return dict(queries=open(os.path.join(root, "queries", "raw.tsv")).read(), docs=open(os.path.join(root, "docs", "raw.tsv")).read(),
+                examples=open(os.path.join(root, "examples.jsonl")).read(), docid_to_smtid=json.dumps(d2s))
+
+
+def make_lngknp_data_case(name="c6_lngknp_data"):
+    """The reference's OWN dataset and collator (dataset/dataset.py:418-525, dataset/data_collator.py:11-88) on small seeded
+    files: items for a fixed index order under random.seed(5) and the collated batch, for smtid lengths 8 / 16 / 32 in both
+    lookup modes. AutoTokenizer.from_pretrained is replaced by the whitespace tokenizer above (no tokenizer files offline)."""
+    import importlib
+    import random
+    import tempfile
+    ds_mod = importlib.import_module("t5_pretrainer.dataset.dataset")
+    dc_mod = importlib.import_module("t5_pretrainer.dataset.data_collator")
+    for m_ in (ds_mod, dc_mod):
+        assert os.path.realpath(m_.__file__).startswith(REF + os.sep), m_.__file__
+
+    class _AT:
+        @staticmethod
+        def from_pretrained(_path):
+            return WordTokenizer()
+
+    dc_mod.AutoTokenizer = _AT
+    cases = {}
+    for L in (8, 16, 32):
+        for as_docid in (True, False):
+            with tempfile.TemporaryDirectory() as root:
+                files = lngknp_files(root, L)
+                ds = ds_mod.LngKnpMarginMSEforT5SeqAQDataset(
+                    dataset_path=os.path.join(root, "examples.jsonl"), document_dir=os.path.join(root, "docs"),
+                    query_dir=os.path.join(root, "queries"), docid_to_smtid_path=None if as_docid else os.path.join(root, "docid_to_smtid.json"),
+                    smtid_as_docid=as_docid)
+                order = [3, 0, 4, 1, 2, 0]
+                random.seed(5)
+                items = [ds[i] for i in order]
+                coll = dc_mod.LngKnpMarginMSEforT5SeqAQCollator("unused", max_length=6)
+                batch = coll(items[:4])
+                flat = {}
+                for k, v in batch.items():
+                    if isinstance(v, dict):
+                        for kk, vv in v.items():
+                            flat[f"{k}.{kk}"] = vv.tolist()
+                    else:
+                        flat[k] = v.tolist()
+                cases[f"L{L}_{'smtid' if as_docid else 'docid'}"] = dict(
+                    files=files, order=order, items=[list(it) for it in items], batch=flat, length=len(ds), max_length=6)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, cases=np.array(json.dumps(cases)))
+    print(f"[golden] {name}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -747,6 +839,8 @@ def main():
         if args.only and args.only not in (name, "callers"):
             continue
         make_caller_case(name, spec, gen, mod, utils, shim)
+    if not args.only or args.only in ("c6_lngknp_data", "callers"):
+        make_lngknp_data_case()
 
 
 if __name__ == "__main__":

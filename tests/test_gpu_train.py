@@ -492,3 +492,44 @@ def test_search_after_a_training_step_sees_the_new_weights(V):
     torch.cuda.synchronize()
     assert torch.equal(after.tokens, fresh.tokens) and torch.equal(after.scores, fresh.scores)
     assert not torch.equal(after.scores, before.scores), "the step did not change the scores: the test checks nothing"
+
+
+def test_training_loop_schedule_and_checkpoint(tmp_path):
+    """The optimisation loop around the device step (ripor_amd/tasks/trainer.py; reference main.py:127-186 + HF Trainer):
+    dataset -> collator -> training_step with the linear warm-up / decay schedule -> checkpoint that from_pretrained reads
+    back with exactly the weights the optimizer left on the device."""
+    from test_trainer_plumbing import CASES, WordTokenizer, _write
+    from ripor_amd.dataset.lng_knp import LngKnpMarginMSEforT5SeqAQCollator, LngKnpMarginMSEforT5SeqAQDataset
+    from ripor_amd.modeling.t5_generative_retriever import T5SeqAQEncoderForLngKnpMarginMSE
+    from ripor_amd.tasks import trainer as T
+    from ripor_amd.utils import synth
+    _write(tmp_path, CASES["L8_smtid"]["files"])
+    ds = LngKnpMarginMSEforT5SeqAQDataset(str(tmp_path / "examples.jsonl"), None, str(tmp_path / "queries"), None, True)
+    coll = LngKnpMarginMSEforT5SeqAQCollator(WordTokenizer(), 16)
+    model = T5SeqAQEncoderForLngKnpMarginMSE.from_synthetic(synth.mini_dims(L=8, V=256, enc_layers=1, d_ff=128), seed=9)
+    model.to(0)
+    before = {k: v.clone() for k, v in model.base_model.engine_model().export_state_dict().items()}
+    args = T.LngKnpTrainingArgs(output_dir=str(tmp_path / "out"), learning_rate=2e-5, warmup_ratio=0.25, per_device_train_batch_size=5,
+                                max_steps=8, logging_steps=2, save_steps=4, bf16=False)
+    os.makedirs(args.output_dir)
+    ctx = model.base_model.engine_model().ctx
+    saved_prec = ctx.get_precision()
+    try:
+        tr = T.LngKnpTrainer(model, ds, coll, args, log=lambda s: None)
+        hist = tr.train()
+        tr.save_torch_model_and_tokenizer(coll.tokenizer)
+    finally:
+        ctx.set_precision(saved_prec)
+    assert [h["step"] for h in hist] == [2, 4, 6, 8]
+    assert hist[0]["learning_rate"] == 2e-5 * 0.5 and abs(hist[-1]["learning_rate"] - 2e-5 / 6) < 1e-12     # steps 1 and 7 of 8, warm-up 2
+    assert hist[-1]["loss"] < hist[0]["loss"], "eight steps on five examples must lower the loss"
+    assert sorted(os.listdir(args.output_dir)) == ["checkpoint", "checkpoint-4", "checkpoint-8"]
+    dev = model.base_model.engine_model().export_state_dict()
+    assert any(not torch.equal(dev[k].cpu(), before[k].cpu()) for k in dev), "the weights did not move"
+    back = T5SeqAQEncoderForLngKnpMarginMSE.from_pretrained(os.path.join(args.output_dir, "checkpoint"))
+    sd = back.base_model.state_dict()
+    for k, v in dev.items():
+        assert torch.equal(sd[k], v.cpu().reshape(sd[k].shape)), k
+    assert os.path.exists(os.path.join(args.output_dir, "checkpoint", "tokenizer.txt"))
+    st = json.load(open(os.path.join(args.output_dir, "checkpoint-4", "trainer_state.json")))
+    assert st["global_step"] == 4 and st["warmup_steps"] == 2
