@@ -1258,11 +1258,15 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   // beam 100, len 8: 1890 queries/s without forks, 1510 with)
   if (!t0 || L - t0 < 8) return forks;
   forks.push_back(t0);
-  for (int t = t0 + 1; t <= L - 2 && t <= t0 + 12; ++t)
-    if ((double)Q * (1.0 - p_forced(t)) <= 0.05) { forks.push_back(t); break; }
   // Optimistic mode (rpr_set_forced_tail(ctx, 2)): when the statistics promise an (almost always) empty last stage, that
   // stage is not enqueued at all — ~100 launches per step for nobody — and a query that is still unforced at the last
   // fork raises RPR_STATUS_TAIL_LEFTOVER instead; the caller then repeats the batch in the exact mode (1).
+  // A handful of queries in flight: the first fork already leaves fewer than 0.05 queries behind in expectation, so the
+  // second fork (a compacted stage, its steps and a second tail pass: ~300 launches that almost always work on nothing,
+  // 2 of the 9.8 ms of a single-query search) is not enqueued either.
+  if (c->forced_tail == 2 && (double)Q * (1.0 - p_forced(t0)) <= 0.05) { *drop_last = true; return forks; }
+  for (int t = t0 + 1; t <= L - 2 && t <= t0 + 12; ++t)
+    if ((double)Q * (1.0 - p_forced(t)) <= 0.05) { forks.push_back(t); break; }
   *drop_last = c->forced_tail == 2 && forks.size() == 2;
   return forks;
 }

@@ -6,7 +6,7 @@ TAG=${1:-rXX}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 -x -s "$@" > $OUT/pytest.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 -s "$@" > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/pytest.log
 grep -E "^\[parity\]|^\[select\]|passed|failed|error" $OUT/pytest.log | tail -40
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
