@@ -675,9 +675,38 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];             // 128 KB
   const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int bm = tm * BM, bn = tn * BN;
+  // compacted stage / tail job: M is the capacity, the live row count is on the device (and, for one kernel of a gated
+  // group, decides whether this kernel runs at all); row tiles past the live rows exit at once
+  int Mlive = g.M;
+  if (g.m_dev) {
+    const int md = *g.m_dev;
+    if (g.live_hi > 0 && (md <= g.live_lo || md > g.live_hi)) return;
+    Mlive = min(md, g.M);
+  }
+  if (bm >= Mlive) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
+  // Epilogue operands of wave 0, requested BEFORE the K walk so that their memory latency passes under it (a launch of
+  // this kernel is a chain of latencies: ~1.5 us each for the row scales and for the residual planes when they were
+  // loaded after the reduction): the fused-RMSNorm sums of squares of the lane's 16 rows and the residual of its 16
+  // outputs (column bn + lane % 32, rows 4 * (lane / 32) + (r & 3) + 8 * (r >> 2)).
+  unsigned long long e_ssq[16];
+  __half e_rh[16], e_rl[16];
+  float e_rf[16];
+  if (wave == 0) {
+    const int n = bn + (lane & 31), rsub = 4 * (lane >> 5);
+    const bool nok = FULL || n < g.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
+      const bool mok = m < Mlive;
+      e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
+      e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
+      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+    }
+  }
 
   const __half* src[PIECES];
 #pragma unroll
@@ -753,12 +782,12 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
-    const bool mok = FULL || m < g.M, ok = nok && mok;
+    const bool mok = m < Mlive, ok = nok && mok;
     float v = acc[r] * acc_scale;
-    if (g.row_ssq && mok) v *= ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps);
+    if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
-    if (g.resid && ok) v = g.resid[(size_t)m * g.ldr + n] + v;
-    if (g.resid_h && ok) v = x_from_planes(g.resid_h[(size_t)m * g.ldrh + n], g.resid_h[g.r_ps + (size_t)m * g.ldrh + n]) + v;
+    if (g.resid && ok) v = e_rf[r] + v;
+    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
     if (ok) {
       if (g.out_h) {
         __half hi, lo;
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
-        if (FULL || m < g.M) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
+        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
       }
     }
   }
@@ -918,17 +947,30 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   a_in.kernel_cls = RPR_K_GEMM_SMALL;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
+  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
+  auto launch_skinny = [&](const GemmH2Args& k) {
+    const int tiles_m = (k.M + 31) / 32, tiles_n = (k.N + 31) / 32;
+    const bool full = (k.M % 32 == 0) && (k.N % 32 == 0) && !k.m_dev;
+    if (full) hipLaunchKernelGGL((gemm_h2_skinny_kernel<true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, k, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_h2_skinny_kernel<false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, k, tiles_m, tiles_n);
+    return hipGetLastError();
+  };
   if (a.m_dev && a.small_live > 0 && a.M > a.small_live && !a.bf16) {
     // a compacted stage: capacity M rows, usually a handful alive. The large-tile kernel would walk all of K with the
-    // one or two blocks that hold live rows (60-250 us per launch); pair it with a 128x64 launch sized for small_live
-    // rows, each gated on the device-side live count.
-    GemmH2Args big = a, sm = a;
+    // one or two blocks that hold live rows (60-250 us per launch). The launch is enqueued as a group of three, each
+    // gated on the device-side live count (two of them exit at once): the large-tile kernel for more than small_live
+    // rows, a 128x64 launch sized for small_live rows, and the skinny kernel for at most `skinny` rows (a few leftover
+    // queries: 10 us instead of 17-20 for the 128x64 tile walking K alone).
+    GemmH2Args big = a, mid = a, sk = a;
+    const int sk_rows = std::min(skinny, a.small_live);
     big.small_live = 0; big.live_lo = a.small_live; big.live_hi = 0x7fffffff;
-    sm.small_live = 0; sm.live_lo = -1; sm.live_hi = a.small_live; sm.M = a.small_live;
+    mid.small_live = 0; mid.live_lo = sk_rows; mid.live_hi = a.small_live; mid.M = a.small_live;
+    sk.small_live = 0; sk.live_lo = -1; sk.live_hi = sk_rows; sk.M = (sk_rows + 31) / 32 * 32;
     hipError_t e = launch_gemm_h2(big, s);
     if (e != hipSuccess) return e;
     a_in.kernel_cls = big.kernel_cls;
-    return launch_cfg<128, 64>(sm, s);
+    if (sk_rows < a.small_live) { e = launch_cfg<128, 64>(mid, s); if (e != hipSuccess) return e; }
+    return launch_skinny(sk);
   }
   if (a.bf16) {
     // one bf16 plane per operand (training GEMMs, RPR_PREC_BF16): fp32 output, optional residual / ReLU, split-K for the
@@ -982,14 +1024,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
-  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
-  if (force == 0 && !a.m_dev && a.M <= skinny) {
-    const int tiles_m = (a.M + 31) / 32, tiles_n = (a.N + 31) / 32;
-    const bool full = (a.M % 32 == 0) && (a.N % 32 == 0);
-    if (full) hipLaunchKernelGGL((gemm_h2_skinny_kernel<true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm_h2_skinny_kernel<false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
-    return hipGetLastError();
-  }
+  if (force == 0 && a.M <= skinny) return launch_skinny(a);   // (with m_dev: row tiles past the live rows exit)
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   // A few hundred to a few thousand rows in flight (beam 1000 with one query, beam 100 with a dozen, beam 10 with
   // 40-400): the 128x64 launch has fewer blocks than CUs and each walks all of K alone (24-96 K-tiles at ~1 us).
