@@ -21,6 +21,7 @@
 // K-tiles with LDS-DMA into unpadded XOR-swizzled rows. Earlier variants (register staging, in-phase software
 // pipelining) are in the history and in DESIGN.md §5 / §8 with their measured numbers.
 #include <algorithm>
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
@@ -321,96 +322,143 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int mrow0 = bm + wm * (BM / WM) + strip * SH;
-    if (g.out_h) {
+    // How the output paths are written matters more than what they compute (ISA of the first version, measured with the
+    // per-tile stamps of tools/gemm_tile_timeline.py: 6 us per tile on an idle chip, 10-14 us in a full launch, where the
+    // same stores take 2.5 us in tools/store_probe.hip):
+    //  * vmcnt counts loads AND stores, and the two return out of order, so waiting for ANY global load while stores are
+    //    in flight is s_waitcnt vmcnt(0) — a full write-acknowledge round trip. The residual pieces used to be loaded in
+    //    the same loop as the stores (and, behind a runtime `if (g.resid)`, the compiler kept the wait on the path without
+    //    a residual too): every one of the 32 stores of a wave waited for the previous one to be acknowledged by the L2.
+    //    Now the variants with and without a residual are separate instantiations (RES), a variant without one contains
+    //    no global load at all, and a variant with one requests every piece of the strip before the strip's first store.
+    //  * every LDS read of a batch (staged rows, row scales) is issued before the first use (explicit arrays + a scheduling
+    //    barrier; the compiler otherwise sinks each read next to its use behind an lgkmcnt(0)).
+    auto planes_path = [&](auto res_tag) {
       // ---- f16-plane output (FF intermediate, residual stream): 8 columns per lane, 8 rows per pass
-      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = SH / RPI;
+      constexpr bool RES = decltype(res_tag)::value;
+      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = SH / RPI, KB = RES ? 2 : 4;   // (the residual pieces hold 64 registers)
       const int rrow = lane / LPR, rc8 = (lane % LPR) * 8;
       const int n0 = bn + wn * (BN / WN) + rc8;
       const bool ncol_ok = FULL || (n0 < g.N);          // N % 32 == 0
-      uint4 rh[NK], rl_[NK];
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int m = mrow0 + k * RPI + rrow;
-        const bool ok = ncol_ok && (FULL || m < Mlim);
-        if (g.resid_h) {
-          rh[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
-          rl_[k] = ok ? *reinterpret_cast<const uint4*>(g.resid_h + g.r_ps + (size_t)m * g.ldrh + n0) : make_uint4(0, 0, 0, 0);
-        }
-      }
       const float ps = g.plane_scale;
       float amax = 0.f;                                 // split_f16's range check: one max per element, one compare per strip
+      uint4 rh[RES ? NK : 1], rl_[RES ? NK : 1];
+      if (RES) {
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int rl = k * RPI + rrow, m = mrow0 + rl;
-        const bool ok = ncol_ok && (FULL || m < Mlim);
-        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + strip * SH + rl] : acc_scale;
-        // pairs of columns as 2-vectors: gfx950 multiplies / adds / fmas two fp32 per instruction (v_pk_*_f32) and
-        // converts two floats to a packed f16 pair in one (v_cvt_pk_f16_f32, round to nearest) — about half the VALU
-        // work of the element-by-element form, which also spent a shift + or per pair on packing
-        f32x2 v[4];
-        *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
-        *reinterpret_cast<float4*>(&v[2]) = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
-        f16x2 h[4], l[4];
-        f32x2 ss2 = {0.f, 0.f};
-        float am = 0.f;
+        for (int k = 0; k < NK; ++k) {
+          // unconditional loads from a clamped (always valid) address: a branch around a load brings the conservative
+          // vmcnt(0) back; rows / columns past the limits are never stored
+          const int m = min(mrow0 + k * RPI + rrow, Mlim - 1), nc = ncol_ok ? n0 : 0;
+          rh[k] = *reinterpret_cast<const uint4*>(g.resid_h + (size_t)m * g.ldrh + nc);
+          rl_[k] = *reinterpret_cast<const uint4*>(g.resid_h + g.r_ps + (size_t)m * g.ldrh + nc);
+        }
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x2 x = v[e] * sc;
-          if (g.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); }
-          if (g.resid_h) {   // X_PLANE_SCALE == 1
-            x += __builtin_convertvector(reinterpret_cast<const f16x2*>(&rh[k])[e], f32x2) +
-                 __builtin_convertvector(reinterpret_cast<const f16x2*>(&rl_[k])[e], f32x2);   // hi + lo is exact in fp32
+      for (int kb = 0; kb < NK; kb += KB) {
+        float4 sa[KB], sb[KB];
+        float scs[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow;
+          sa[k] = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
+          sb[k] = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
+          scs[k] = rs_tile ? rs_tile[wm * (BM / WM) + strip * SH + rl] : 1.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow, m = mrow0 + rl;
+          const bool ok = ncol_ok && (FULL || m < Mlim);
+          const float sc = rs_tile ? acc_scale * scs[k] : acc_scale;
+          // pairs of columns as 2-vectors: gfx950 multiplies / adds / fmas two fp32 per instruction (v_pk_*_f32) and
+          // converts two floats to a packed f16 pair in one (v_cvt_pk_f16_f32, round to nearest) — about half the VALU
+          // work of the element-by-element form, which also spent a shift + or per pair on packing
+          f32x2 v[4];
+          *reinterpret_cast<float4*>(&v[0]) = sa[k];
+          *reinterpret_cast<float4*>(&v[2]) = sb[k];
+          f16x2 h[4], l[4];
+          f32x2 ss2 = {0.f, 0.f};
+          float am = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f32x2 x = v[e] * sc;
+            if (g.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); }
+            if (RES) {   // X_PLANE_SCALE == 1
+              x += __builtin_convertvector(reinterpret_cast<const f16x2*>(&rh[RES ? kb + k : 0])[e], f32x2) +
+                   __builtin_convertvector(reinterpret_cast<const f16x2*>(&rl_[RES ? kb + k : 0])[e], f32x2);   // hi + lo is exact in fp32
+            }
+            ss2 += x * x;
+            f32x2 xs = x * ps;
+            am = fmaxf(am, fmaxf(fabsf(xs.x), fabsf(xs.y)));
+            xs.x = __builtin_amdgcn_fmed3f(xs.x, -65504.f, 65504.f);
+            xs.y = __builtin_amdgcn_fmed3f(xs.y, -65504.f, 65504.f);
+            h[e] = __builtin_convertvector(xs, f16x2);
+            l[e] = __builtin_convertvector(xs - __builtin_convertvector(h[e], f32x2), f16x2);
           }
-          ss2 += x * x;
-          f32x2 xs = x * ps;
-          am = fmaxf(am, fmaxf(fabsf(xs.x), fabsf(xs.y)));
-          xs.x = __builtin_amdgcn_fmed3f(xs.x, -65504.f, 65504.f);
-          xs.y = __builtin_amdgcn_fmed3f(xs.y, -65504.f, 65504.f);
-          h[e] = __builtin_convertvector(xs, f16x2);
-          l[e] = __builtin_convertvector(xs - __builtin_convertvector(h[e], f32x2), f16x2);
-        }
-        float ss = ss2.x + ss2.y;
-        if (ok) {
-          *reinterpret_cast<uint4*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(h);
-          *reinterpret_cast<uint4*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(l);
-          amax = fmaxf(amax, am);
-        }
-        if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
-          if (!ok) ss = 0.f;
+          float ss = ss2.x + ss2.y;
+          if (ok) {
+            *reinterpret_cast<uint4*>(g.out_h + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(h);
+            *reinterpret_cast<uint4*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n0) = *reinterpret_cast<uint4*>(l);
+            amax = fmaxf(amax, am);
+          }
+          if (g.ssq_out) {   // the LPR lanes of a staged row hold this wave's 64 columns of output row m
+            if (!ok) ss = 0.f;
 #pragma unroll
-          for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-          if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+            for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+          }
         }
       }
       if (amax > 65504.f && g.sat) *g.sat = 1u;
-    } else {
+    };
+    auto fp32_path = [&](auto res_tag) {
       // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes)
-      constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI;   // lanes per staged row, rows per read instruction
+      constexpr bool RES = decltype(res_tag)::value;
+      constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI, KB = RES ? 4 : 8;   // lanes per staged row, rows per read instruction
       const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
       const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
       const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
       const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
       float* outp = g.out[oi] + (size_t)blockIdx.y * g.part_stride;   // split-K: this block's partial result
       const int ldo = g.ldo[oi];
-      float4 res[NK];
-      if (g.resid) {
+      float4 res[RES ? NK : 1];
+      if (RES) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          const int m = mrow0 + k * RPI + rrow;
-          res[k] = (ncol_ok && (FULL || m < Mlim)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n0)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int m = min(mrow0 + k * RPI + rrow, Mlim - 1), nc = ncol_ok ? n0 : 0;   // clamped, unconditional (see planes_path)
+          res[k] = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + nc);
         }
       }
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int rl = k * RPI + rrow, m = mrow0 + rl;
-        float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
-        const float sc = rs_tile ? acc_scale * rs_tile[wm * (BM / WM) + strip * SH + rl] : acc_scale;   // fused RMSNorm row scale
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-        if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
-        if (ncol_ok && (FULL || m < Mlim)) *reinterpret_cast<float4*>(outp + out_off(g, oi, m, ldo, on)) = v;
+      for (int kb = 0; kb < NK; kb += KB) {
+        float4 st[KB];
+        float scs[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow;
+          st[k] = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+          scs[k] = rs_tile ? rs_tile[wm * (BM / WM) + strip * SH + rl] : 1.0f;   // fused RMSNorm row scale
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow, m = mrow0 + rl;
+          float4 v = st[k];
+          const float sc = rs_tile ? acc_scale * scs[k] : acc_scale;
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+          if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (RES) { const float4 r = res[RES ? kb + k : 0]; v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
+          if (ncol_ok && (FULL || m < Mlim)) {
+            const size_t off = g.rm_B ? out_off(g, oi, m, ldo, on) : (size_t)m * ldo + on;   // (uniform: no K/V-cache map in the tail pass)
+            *reinterpret_cast<float4*>(outp + off) = v;
+          }
+        }
       }
+    };
+    if (g.out_h) {
+      if (g.resid_h) planes_path(std::true_type{}); else planes_path(std::false_type{});
+    } else {
+      if (g.resid) fp32_path(std::true_type{}); else fp32_path(std::false_type{});
     }
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
   }
@@ -651,7 +699,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   int lane_e = lane;   // laundered like lane_t: the epilogue's per-lane offsets must not live through the K-loop
   asm volatile("" : "+v"(lane_e));
   h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
-  __syncthreads();   // the staging strips alias the operand buffers the next tile's LDS-DMA writes; rs_tile is rewritten
+  // The staging strips alias the operand buffers the next tile's LDS-DMA writes, and rs_tile is rewritten: every wave's LDS
+  // reads must have returned (lgkmcnt(0)) before anyone goes on. NOT __syncthreads(): its fence also waits for vmcnt(0),
+  // i.e. for every global store of this tile to be acknowledged by the L2 (2-5 us under load) — the stores take their data
+  // from registers and drain under the next tile's prologue instead.
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   PP_TILE_STAMP(3);
 #undef PP_TILE_STAMP
 #undef PP_PIECE

@@ -14,8 +14,8 @@ for _ in range(2): ctx.linear(A, W, R)
 torch.cuda.synchronize()
 t = np.loadtxt(os.environ["RPR_GEMM_TRACE"] + ".tiles").reshape(-1, 4) * 0.01   # us
 pro, kl, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-gap = t[1:, 0] - t[:-1, 3]
+gap = t[1:, 0] - t[:-1, 3] if len(t) > 1 else np.zeros(1)
 print(f"M={M} N={N} K={K} resid={resid}: {len(t)} tiles of block 0; per tile (us) median [min..max]:")
 for name, v in (("prologue", pro), ("K-loop", kl), ("epilogue", epi), ("between tiles", gap)):
     print(f"  {name:14s} {np.median(v):7.2f} [{v.min():6.2f} .. {v.max():6.2f}]")
-print(f"  tile period    {np.median(t[1:, 0] - t[:-1, 0]):7.2f}")
+if len(t) > 1: print(f"  tile period    {np.median(t[1:, 0] - t[:-1, 0]):7.2f}")
