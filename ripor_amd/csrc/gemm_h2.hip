@@ -289,29 +289,14 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
 // A wave stages 64 rows at a time: the strips of the 8 waves fill both operand buffers (128 KB).
-template <bool FULL, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
-                                                int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
-                                                float acc_scale) {
-  constexpr int BM = 256, BN = 256, SH = 64;
-  // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
-  // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
-  // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
-  // K = 768. Here each wave stages SH x 64 outputs at a time in its private strip of the (now idle)
-  // operand LDS and streams them out row-wise with 16-byte accesses. The epilogue is bound by the NUMBER of
-  // memory instructions and by its VALU work, not by bytes (measured: two extra 8-byte plane stores per float4
-  // tripled it; ~20 VALU ops per plane element cost ~5 us per tile; a global load of the fused-RMSNorm row scales
-  // cost a full memory latency per half), so the f16-plane outputs give a lane 8 consecutive columns = one 16-byte
-  // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
-  // one max per element plus one compare per half.
-  __syncthreads();                                   // all waves are done reading operand tiles
-  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
-  constexpr int SW = TN * 32;                         // staged row width (floats)
-  constexpr int NS = TM * 32 / SH;                    // strips per wave
-  float* stg = reinterpret_cast<float*>(smem) + wave * (SH * SW);
+// One strip (64 rows of a wave's 128 x 64 outputs) of the epilogue below. The strip index is a template parameter: the
+// accumulators are indexed with it, and a strip loop the compiler declines to unroll — it did once the output paths had
+// grown — puts all 128 of them into scratch.
+template <bool FULL, int TM, int TN, int WM, int WN, int strip>
+__device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&acc)[TM][TN], float* stg, int lane, int bm, int bn,
+                                                  int wm, int wn, const float* rs_tile, float acc_scale, int Mlim) {
+  constexpr int BM = 256, BN = 256, SH = 64, SW = TN * 32;
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-#pragma unroll
-  for (int strip = 0; strip < NS; ++strip) {
 #pragma unroll
     for (int ii = 0; ii < SH / 32; ++ii)
 #pragma unroll
@@ -333,7 +318,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     //    no global load at all, and a variant with one requests every piece of the strip before the strip's first store.
     //  * every LDS read of a batch (staged rows, row scales) is issued before the first use (explicit arrays + a scheduling
     //    barrier; the compiler otherwise sinks each read next to its use behind an lgkmcnt(0)).
-    auto planes_path = [&](auto res_tag) {
+    auto planes_path = [&](auto res_tag) __attribute__((always_inline)) {
       // ---- f16-plane output (FF intermediate, residual stream): 8 columns per lane, 8 rows per pass
       constexpr bool RES = decltype(res_tag)::value;
       constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = SH / RPI, KB = RES ? 2 : 4;   // (the residual pieces hold 64 registers)
@@ -411,16 +396,22 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
       }
       if (amax > 65504.f && g.sat) *g.sat = 1u;
     };
-    auto fp32_path = [&](auto res_tag) {
-      // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes)
-      constexpr bool RES = decltype(res_tag)::value;
+    auto fp32_path = [&](auto res_tag, auto kv_tag) __attribute__((always_inline)) {
+      // ---- fp32 output (q, K/V cache rows, logits, fp32 residual stream of callers without planes). KVMAP: the K/V-cache
+      // element map of the sequential steps (an integer division per store); the variant without it keeps the store loop
+      // free of branches (ReLU as a max against 0 or -inf, the row scale always multiplied): ~10 instructions per store
+      // instead of ~30 with five branches
+      constexpr bool RES = decltype(res_tag)::value, KVMAP = decltype(kv_tag)::value;
+      const float relu_lo = g.relu ? 0.f : -INFINITY;
       constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI, KB = RES ? 4 : 8;   // lanes per staged row, rows per read instruction
       const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
       const int n0 = bn + wn * (BN / WN) + rc4;           // first of this lane's 4 consecutive output columns
       const bool ncol_ok = FULL || (n0 < g.N);            // N % 4 == 0 is guaranteed (N % 32 == 0)
       const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;
-      float* outp = g.out[oi] + (size_t)blockIdx.y * g.part_stride;   // split-K: this block's partial result
-      const int ldo = g.ldo[oi];
+      // (selects, not g.out[oi]: a variable index into the by-value argument struct makes the compiler keep a private copy
+      // of all of it in scratch)
+      float* outp = (oi == 0 ? g.out[0] : oi == 1 ? g.out[1] : g.out[2]) + (size_t)blockIdx.y * g.part_stride;   // split-K: this block's partial result
+      const int ldo = oi == 0 ? g.ldo[0] : oi == 1 ? g.ldo[1] : g.ldo[2];
       float4 res[RES ? NK : 1];
       if (RES) {
 #pragma unroll
@@ -444,12 +435,11 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
         for (int k = 0; k < KB; ++k) {
           const int rl = (kb + k) * RPI + rrow, m = mrow0 + rl;
           float4 v = st[k];
-          const float sc = rs_tile ? acc_scale * scs[k] : acc_scale;
-          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-          if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const float sc = acc_scale * scs[k];
+          v.x = fmaxf(v.x * sc, relu_lo); v.y = fmaxf(v.y * sc, relu_lo); v.z = fmaxf(v.z * sc, relu_lo); v.w = fmaxf(v.w * sc, relu_lo);
           if (RES) { const float4 r = res[RES ? kb + k : 0]; v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
           if (ncol_ok && (FULL || m < Mlim)) {
-            const size_t off = g.rm_B ? out_off(g, oi, m, ldo, on) : (size_t)m * ldo + on;   // (uniform: no K/V-cache map in the tail pass)
+            const size_t off = KVMAP ? out_off(g, oi, m, ldo, on) : (size_t)m * ldo + on;
             *reinterpret_cast<float4*>(outp + off) = v;
           }
         }
@@ -458,10 +448,38 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
     if (g.out_h) {
       if (g.resid_h) planes_path(std::true_type{}); else planes_path(std::false_type{});
     } else {
-      if (g.resid) fp32_path(std::true_type{}); else fp32_path(std::false_type{});
+      if (g.resid) fp32_path(std::true_type{}, std::true_type{});            // (training / test callers: generic)
+      else if (g.rm_B) fp32_path(std::false_type{}, std::true_type{});
+      else fp32_path(std::false_type{}, std::false_type{});
     }
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
-  }
+}
+
+template <bool FULL, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
+                                                int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
+                                                float acc_scale) {
+  constexpr int BM = 256, BN = 256, SH = 64;
+  // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
+  // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
+  // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
+  // K = 768. Here each wave stages SH x 64 outputs at a time in its private strip of the (now idle)
+  // operand LDS and streams them out row-wise with 16-byte accesses. The epilogue is bound by the NUMBER of
+  // memory instructions and by its VALU work, not by bytes (measured: two extra 8-byte plane stores per float4
+  // tripled it; ~20 VALU ops per plane element cost ~5 us per tile; a global load of the fused-RMSNorm row scales
+  // cost a full memory latency per half), so the f16-plane outputs give a lane 8 consecutive columns = one 16-byte
+  // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
+  // one max per element plus one compare per half.
+  __syncthreads();                                   // all waves are done reading operand tiles
+  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
+  constexpr int SW = TN * 32;                         // staged row width (floats)
+  constexpr int NS = TM * 32 / SH;                    // strips per wave
+  float* stg = reinterpret_cast<float*>(smem) + wave * (SH * SW);
+  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
+  static_assert(NS == 2, "two strips of 64 rows per wave");
+  (void)ncol; (void)rsub;
+  h2_epilogue_strip<FULL, TM, TN, WM, WN, 0>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
+  h2_epilogue_strip<FULL, TM, TN, WM, WN, 1>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
 }
 
 // ---- ping-pong 256x256 variant -------------------------------------------------------------------------
@@ -539,19 +557,22 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   int lane_t = lane;
   asm volatile("" : "+v"(lane_t));
   const __half* src[PER_WAVE];
+// (operand, plane, limit and leading dimension are chosen from the wave-uniform 16-row group with value selects: an if / else
+// chain over the struct's fields made the compiler select field ADDRESSES and keep a private copy of the argument struct
+// in scratch)
 #define PP_SRC_SETUP(dst, lane_x, bm_x, bn_x)                                                                         \
   _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j) {                                                              \
-    const int lrow = 16 * (wave + NW * j) + ((lane_x) >> 2);                                                          \
+    const int grow = 16 * (wave + NW * j);                      /* first LDS row of this piece: wave-uniform */       \
+    const int lrow = grow + ((lane_x) >> 2);                                                                          \
     const int seg = ((lane_x) & 3) ^ ((lrow >> 2) & 3);                                                               \
-    const __half* base;                                                                                               \
-    int trow, limit;                                                                                                  \
-    size_t ld;                                                                                                        \
-    if (lrow < BM) { base = g.A; trow = (bm_x) + lrow; limit = g.M; ld = g.lda; }                                     \
-    else if (lrow < 2 * BM) { base = g.A + (BF16 ? (size_t)HBK : g.a_ps); trow = (bm_x) + lrow - BM; limit = g.M; ld = g.lda; } \
-    else if (lrow < 2 * BM + BN) { base = g.W; trow = (bn_x) + lrow - 2 * BM; limit = g.N; ld = g.ldw; }              \
-    else { base = g.W + (BF16 ? (size_t)HBK : g.w_ps); trow = (bn_x) + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; } \
+    const bool is_a = grow < 2 * BM, second = is_a ? grow >= BM : grow >= 2 * BM + BN;                                \
+    const __half* base = is_a ? g.A : g.W;                                                                            \
+    const size_t plane = second ? (BF16 ? (size_t)HBK : (is_a ? g.a_ps : g.w_ps)) : 0;                                \
+    const int limit = is_a ? g.M : g.N;                                                                               \
+    const size_t ld = is_a ? (size_t)g.lda : (size_t)g.ldw;                                                           \
+    int trow = (is_a ? (bm_x) + lrow - (second ? BM : 0) : (bn_x) + lrow - 2 * BM - (second ? BN : 0));               \
     if (!FULL && trow >= limit) trow = limit - 1;                                                                     \
-    dst[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;                                               \
+    dst[j] = base + plane + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;                                       \
   }
   PP_SRC_SETUP(src, lane_t, bm, bn)
 #define PP_PIECE(buf, k0, j)                                                                                   \
