@@ -594,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
   const int so0 = ((0 + hf) ^ sw) * 8, so1 = ((2 + hf) ^ sw) * 8;   // segment offsets of chunk 0 / 1
 
   f16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+  f16x8 ah2, ah3, al2, al3;   // two-phase schedule: all four 32-row fragments of the wave's A rows per k-chunk
 #define PP_LOAD_W(buf, so)                                                                              \
   {                                                                                                     \
     const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
@@ -609,6 +610,18 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     ah1 = *reinterpret_cast<const f16x8*>(base_ + (a_row + (i0) * 32 + 32) * HBK + (so));               \
     al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32) * HBK + (so));               \
     al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32 + 32) * HBK + (so));          \
+  }
+#define PP_LOAD_A4(buf, so)                                                                             \
+  {                                                                                                     \
+    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
+    ah0 = *reinterpret_cast<const f16x8*>(base_ + (a_row) * HBK + (so));                                \
+    ah1 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 32) * HBK + (so));                           \
+    ah2 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 64) * HBK + (so));                           \
+    ah3 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 96) * HBK + (so));                           \
+    al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row) * HBK + (so));                           \
+    al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 32) * HBK + (so));                      \
+    al2 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 64) * HBK + (so));                      \
+    al3 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 96) * HBK + (so));                      \
   }
 #define PP_MFMA(a, b, c)                                                                                 \
   do {                                                                                                   \
@@ -637,6 +650,28 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                   \
     __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                           \
     PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                           \
+    }                                                                                                   \
+  }
+// the 24 MFMAs of a phase of the two-phase schedule: lo*hi, hi*lo, hi*hi over the wave's 4 x 2 output tiles (every
+// accumulator is touched once per group of eight: no back-to-back dependence); D0..D7 = statements in the MFMA shadows
+#define PP_SB __builtin_amdgcn_sched_barrier(0)
+#define PP_MMA8(A0, A1, A2, A3, B0, B1, Da, Db, Dc)                                                     \
+    PP_MFMA(A0, B0, acc[0][0]); PP_MFMA(A0, B1, acc[0][1]); PP_MFMA(A1, B0, acc[1][0]);                 \
+    PP_SB; Da; PP_SB;                                                                                   \
+    PP_MFMA(A1, B1, acc[1][1]); PP_MFMA(A2, B0, acc[2][0]); PP_MFMA(A2, B1, acc[2][1]);                 \
+    PP_SB; Db; PP_SB;                                                                                   \
+    PP_MFMA(A3, B0, acc[3][0]); PP_MFMA(A3, B1, acc[3][1]);                                             \
+    PP_SB; Dc; PP_SB;
+#define PP_MMA24(D0, D1, D2, D3, D4, D5, D6, D7)                                                        \
+  {                                                                                                     \
+    if (BF16) {   /* slice 1 x slice 1 ("lo" rows), then slice 0 x slice 0 */                           \
+      PP_MMA8(al0, al1, al2, al3, bl0, bl1, D0, D1, D2)                                                 \
+      PP_SB; D3; D4; PP_SB;                                                                             \
+      PP_MMA8(ah0, ah1, ah2, ah3, bh0, bh1, D5, D6, D7)                                                 \
+    } else {                                                                                            \
+      PP_MMA8(al0, al1, al2, al3, bh0, bh1, D0, D1, D2)                                                 \
+      PP_MMA8(ah0, ah1, ah2, ah3, bl0, bl1, D3, D4, D5)                                                 \
+      PP_MMA8(ah0, ah1, ah2, ah3, bh0, bh1, D6, D7, (void)0)                                            \
     }                                                                                                   \
   }
 // the 8 LDS-DMA pieces of the next tile go into the MFMA shadows of M_0 / M_1 / M_2 (3 + 3 + 2); issuing them in
@@ -676,33 +711,25 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;
     const int k1 = (kt + 1) * KSTEP;
-    // phase 0: chunk 0, A rows 0..63
+    // Two phases per K-tile (one per 16-column k-chunk), each = load segment (4 W + 8 A fragments) | barrier | MFMA segment
+    // (24 MFMAs; the 8 LDS-DMA pieces of the next tile in the shadows of the FIRST one) | barrier. Four phases of 12 MFMAs
+    // (a phase per k-chunk and half of the A rows) cost twice the barriers: per-segment stamps showed every one of the 8
+    // barrier intervals of a K-tile at ~630 cycles for 384 of MFMA issue (M 460-550 with the DMA pieces and fixed costs,
+    // ~100 of barrier latency): 5076 cycles per K-tile against 3072 of matrix-pipe time.
     if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + 16] = __builtin_amdgcn_s_memrealtime(); }
     PP_STAMP(0);
     PP_LOAD_W(cur, so0);
-    PP_LOAD_A(cur, so0, 0);
+    PP_LOAD_A4(cur, so0);
     PP_L_END(WAIT_LGKM, 0);
-    PP_MMA(0, PP_DMA_M(0), PP_DMA_M(1), PP_DMA_M(2));
+    PP_MMA24(PP_DMA_M(0), PP_DMA_M(1), PP_DMA_M(2), PP_DMA_M(3), PP_DMA_M(4), PP_DMA_M(5), PP_DMA_M(6), PP_DMA_M(7));
     PP_M_END(0);
-    // phase 1: chunk 0, A rows 64..127
+    // phase 1: chunk 1; tile kt+1 must have landed before anyone's next L_0
     PP_STAMP(4);
-    PP_LOAD_A(cur, so0, 2);
-    PP_L_END(WAIT_LGKM, 1);
-    PP_MMA(2, PP_DMA_M(3), PP_DMA_M(4), PP_DMA_M(5));
-    PP_M_END(1);
-    // phase 2: chunk 1, A rows 0..63
-    PP_STAMP(8);
     PP_LOAD_W(cur, so1);
-    PP_LOAD_A(cur, so1, 0);
-    PP_L_END(WAIT_LGKM, 2);
-    PP_MMA(0, PP_DMA_M(6), PP_DMA_M(7), (void)0);
-    PP_M_END(2);
-    // phase 3: chunk 1, A rows 64..127; tile kt+1 must have landed before anyone's next L_0
-    PP_STAMP(12);
-    PP_LOAD_A(cur, so1, 2);
-    PP_L_END(WAIT_ALL, 3);
-    PP_MMA(2, (void)0, (void)0, (void)0);
-    PP_M_END(3);
+    PP_LOAD_A4(cur, so1);
+    PP_L_END(WAIT_ALL, 1);
+    PP_MMA24((void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
+    PP_M_END(1);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();         // group 0 catches the extra barrier of group 1
   __builtin_amdgcn_sched_barrier(0);
@@ -711,6 +738,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 #undef PP_LOAD_A
 #undef PP_MFMA
 #undef PP_MMA
+#undef PP_MMA8
+#undef PP_MMA24
+#undef PP_SB
+#undef PP_LOAD_A4
 #undef PP_DMA
 #undef PP_DMA_M
 #undef PP_L_END

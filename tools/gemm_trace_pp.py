@@ -18,11 +18,12 @@ for w in (0, 4):
     mid = cyc[2:-2, w, :]
     nxt0 = cyc[3:-1, w, 0]
     seg = []
-    for ph in range(4):
+    NPH = int(os.environ.get("TRACE_PHASES", 2))   # phases per K-tile of the build under test (2 since round 4, 4 before)
+    for ph in range(NPH):
         L = mid[:, ph * 4 + 1] - mid[:, ph * 4 + 0]
         B1 = mid[:, ph * 4 + 2] - mid[:, ph * 4 + 1]
         Mm = mid[:, ph * 4 + 3] - mid[:, ph * 4 + 2]
-        end = mid[:, ph * 4 + 4] if ph < 3 else nxt0
+        end = mid[:, ph * 4 + 4] if ph < NPH - 1 else nxt0
         B2 = end - mid[:, ph * 4 + 3]
         seg.append((np.median(L), np.median(B1), np.median(Mm), np.median(B2)))
     print("   per phase median (L, wait@B1, M, wait@B2):", [tuple(int(x) for x in s) for s in seg])
