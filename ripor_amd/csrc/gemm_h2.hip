@@ -448,8 +448,8 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
     if (g.out_h) {
       if (g.resid_h) planes_path(std::true_type{}); else planes_path(std::false_type{});
     } else {
-      if (g.resid) fp32_path(std::true_type{}, std::true_type{});            // (training / test callers: generic)
-      else if (g.rm_B) fp32_path(std::false_type{}, std::true_type{});
+      if (g.rm_B) { if (g.resid) fp32_path(std::true_type{}, std::true_type{}); else fp32_path(std::false_type{}, std::true_type{}); }
+      else if (g.resid) fp32_path(std::true_type{}, std::false_type{});      // (training GEMMs with an fp32 residual)
       else fp32_path(std::false_type{}, std::false_type{});
     }
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
