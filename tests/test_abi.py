@@ -144,3 +144,31 @@ def test_hot_gemm_kernels_use_no_scratch():
            ("gemm_h2_dma_kernel" in k and "Lb1E" in k)]
     assert len(hot) >= 5, sorted(usage)
     assert all(usage[k] == 0 for k in hot), {k: usage[k] for k in hot if usage[k]}
+
+
+def test_hot_gemm_kernels_use_no_scratch():
+    """The 256 x 256 ping-pong GEMM and the skinny GEMM must compile without scratch: twice in round 4 (and once in round 2)
+    a harmless-looking edit made hipcc keep the accumulators or a private copy of the 336-byte argument struct in scratch —
+    correct results, +20 % per launch, no warning. Cross-compiles gemm_h2.hip for gfx950 (no GPU needed, ~1 min)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(REPO, "ripor_amd", "csrc", "gemm_h2.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, src], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            seen[name] = int(m.group(1))
+    hot = {k: v for k, v in seen.items() if "gemm_h2_pp_kernel" in k or "gemm_h2_skinny_kernel" in k}
+    assert len(hot) >= 4, seen
+    assert all(v == 0 for v in hot.values()), {k: v for k, v in hot.items() if v}
