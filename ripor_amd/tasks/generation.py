@@ -14,7 +14,6 @@ Mirrors reference t5_pretrainer/tasks/generation.py:
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -23,25 +22,79 @@ import torch
 from .. import engine as E
 
 
-@dataclass
 class BeamSearchEncoderDecoderOutput:
-    sequences: torch.Tensor = None
-    sequences_scores: Optional[torch.Tensor] = None
-    scores: Optional[tuple] = None
-    beam_indices: Optional[tuple] = None
-    encoder_attentions: Optional[tuple] = None
-    encoder_hidden_states: Optional[tuple] = None
-    decoder_attentions: Optional[tuple] = None
-    cross_attentions: Optional[tuple] = None
-    decoder_hidden_states: Optional[tuple] = None
-    # extras of this implementation: sorted-row range of every returned smtid (docids = perm[lo:hi])
-    row_lo: Optional[torch.Tensor] = None
-    row_hi: Optional[torch.Tensor] = None
-    # with defer_status=True: the E.GuardedSearch whose result() must be consulted before the tensors above are trusted
-    guard: Optional[object] = None
+    """The reference's return object (HF 4.17 ``BeamSearchEncoderDecoderOutput``, generation.py:554-564).
+
+    ``sequences`` / ``sequences_scores`` are what every caller on the path reads (evaluate.py:76-77, :116-117, :164-165).
+    ``scores`` (tuple of L float64 tensors ``[Q*B, V]``: the processed scores of every step, logits or log-probabilities
+    plus ``(1 - valid_mask) * (-1e9)``, reference :453-468) and ``beam_indices`` (per returned beam slot the tuple of
+    the L parent indices ``q*B + slot`` it descended from, :521-522, :548-552) are produced ON FIRST ACCESS: the search
+    proper never forms V logits per step behind a fork, so reading either attribute runs one more search of the same
+    batch step by step with the library's debug taps (no forks, no lanes, eager) and converts its per-step record.
+    ``None`` when the call was made without ``output_scores``."""
+
+    _LAZY = ("scores", "beam_indices")
+
+    def __init__(self, sequences=None, sequences_scores=None, scores=None, beam_indices=None, encoder_attentions=None,
+                 encoder_hidden_states=None, decoder_attentions=None, cross_attentions=None, decoder_hidden_states=None,
+                 row_lo=None, row_hi=None, guard=None, _step_record=None):
+        self.sequences, self.sequences_scores = sequences, sequences_scores
+        self._scores, self._beam_indices = scores, beam_indices
+        self.encoder_attentions, self.encoder_hidden_states = encoder_attentions, encoder_hidden_states
+        self.decoder_attentions, self.cross_attentions = decoder_attentions, cross_attentions
+        self.decoder_hidden_states = decoder_hidden_states
+        # extras of this implementation: sorted-row range of every returned smtid (docids = perm[lo:hi])
+        self.row_lo, self.row_hi = row_lo, row_hi
+        # with defer_status=True: the E.GuardedSearch whose result() must be consulted before the tensors above are trusted
+        self.guard = guard
+        self._step_record = _step_record      # callable -> (scores tuple, beam_indices tuple), or None
+
+    def _materialise(self):
+        if self._step_record is not None:
+            self._scores, self._beam_indices = self._step_record()
+            self._step_record = None
+
+    @property
+    def scores(self):
+        self._materialise()
+        return self._scores
+
+    @property
+    def beam_indices(self):
+        self._materialise()
+        return self._beam_indices
 
     def __getitem__(self, k):
         return getattr(self, k)
+
+
+def _per_step_record(em, trie, input_ids, attention_mask, B, L, K, log_softmax):
+    """``scores`` and ``beam_indices`` of the reference's output object from one tapped search (see the class above)."""
+    ctx = em.ctx
+    saved = ctx.get_precision()
+    res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
+    torch.cuda.synchronize(ctx.device)
+    if ctx.status(clear=True) & E._lib.STATUS_SATURATED and saved != "f32":
+        ctx.set_precision("f32")
+        try:
+            res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
+            torch.cuda.synchronize(ctx.device)
+        finally:
+            ctx.set_precision(saved)
+    t = res.taps
+    Q, V = input_ids.shape[0], em.V
+    logits = t["step_logits"].view(L, Q * B, V)                                  # fp32, row = q*B + slot of the step's beams
+    words = t["step_valid"].view(L, Q * B, V // 64)                              # bit (token % 64) of word token // 64
+    bits = (words.unsqueeze(-1) >> torch.arange(64, device=words.device, dtype=torch.int64)) & 1
+    valid = bits.view(L, Q * B, V).to(torch.float64)
+    base = torch.log_softmax(logits, dim=-1) if log_softmax else logits          # fp32 like the reference (:453-455)
+    scores = tuple((base[s].to(torch.float64) + (1.0 - valid[s]) * (-1e9)) for s in range(L))
+    parent = t["step_parent"].view(L, Q, B).cpu().numpy()                        # slot of the previous step every new slot came from
+    hist = [[() for _ in range(B)] for _ in range(Q)]
+    for s in range(L):
+        hist = [[hist[q][int(parent[s, q, b])] + (q * B + int(parent[s, q, b]),) for b in range(B)] for q in range(Q)]
+    beam_indices = tuple(hist[q][b] for q in range(Q) for b in range(K))          # first K slots of every query (:548-552)
+    return scores, beam_indices
 
 
 class PrefixConstrainLogitProcessorFastSparse:
@@ -191,7 +244,12 @@ def generate_for_constrained_prefix_beam_search(
     seqs = torch.cat([torch.zeros((Q, K, 1), dtype=torch.long, device=tok.device), tok], dim=2).reshape(Q * K, L + 1)
     if not return_dict_in_generate:
         return seqs
+    record = None
+    if output_scores and em.V % 64 == 0:   # (the debug taps need a vocab size on the 64 grid)
+        ids_keep, mask_keep, ls = input_ids, attention_mask, bool(apply_log_softmax_for_scores)
+        record = lambda: _per_step_record(em, trie, ids_keep, mask_keep, B, L, K, ls)   # noqa: E731  (run on first access)
     return BeamSearchEncoderDecoderOutput(
         sequences=seqs,
         sequences_scores=res.scores[:, :K].reshape(Q * K) if output_scores else None,
-        row_lo=res.row_lo[:, :K].reshape(Q * K), row_hi=res.row_hi[:, :K].reshape(Q * K), guard=guard if defer else None)
+        row_lo=res.row_lo[:, :K].reshape(Q * K), row_hi=res.row_hi[:, :K].reshape(Q * K), guard=guard if defer else None,
+        _step_record=record)

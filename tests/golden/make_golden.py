@@ -333,6 +333,7 @@ def run_reference(gen, utils, shim, model, processor, input_ids, attention_mask,
         apply_log_softmax_for_scores=log_softmax,
         encoder_outputs=BaseModelOutput(last_hidden_state=enc.repeat_interleave(B, 0)),
         attention_mask=attention_mask.repeat_interleave(B, 0), use_cache=False)
+    run_reference.last_beam_indices = np.asarray([list(map(int, bi)) for bi in out.beam_indices], dtype=np.int64)   # [Q*B, L]
     strs = utils.convert_ptsmtids_to_strsmtid(out.sequences.view(-1, B, L + 1), L)
     # per-step processed scores (float64) -> per-step sorted top-(B+1) margins are derived by tests
     step_scores = np.stack([s.numpy() for s in out.scores])  # [L, Q*B, V] float64 (without beam score)
@@ -821,6 +822,26 @@ def make_lngknp_data_case(name="c6_lngknp_data"):
     print(f"[golden] {name}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)")
 
 
+def make_beam_indices_case(gen, mod, utils, shim, name="c7_beam_indices"):
+    """``beam_indices`` of the reference's output object (generation.py:521-522, :548-552) for two committed search fixtures
+    (the ``scores`` tuple is already stored there as ``step_scores``): per returned slot the L parent indices q*B + slot."""
+    out = {}
+    for case in ("g1_mini_b4_l8", "g1_mini_b4_l8_logsoftmax", "g1_mini_b10_l32"):
+        spec = CASES[case]
+        N, Q, B, L, V, seed = spec["N"], spec["Q"], spec["B"], spec["L"], spec["V"], spec["seed"]
+        dims = synth.mini_dims(L=L, V=V, shared_output_input_embeds=spec.get("shared", False))
+        model = build_reference_model(mod, dims, synth.make_state_dict(dims, seed=seed))
+        codes = synth.make_codes(N, L, V, seed=seed)
+        _, lst = reference_trie(gen, codes)
+        processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
+        ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=20)
+        run_reference(gen, utils, shim, model, processor, ids, mask, B, L, spec.get("log_softmax", False))
+        out[case] = run_reference.last_beam_indices
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {name}: {[(k, v.shape) for k, v in out.items()]} -> {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -841,6 +862,8 @@ def main():
         make_caller_case(name, spec, gen, mod, utils, shim)
     if not args.only or args.only in ("c6_lngknp_data", "callers"):
         make_lngknp_data_case()
+    if not args.only or args.only in ("c7_beam_indices", "callers"):
+        make_beam_indices_case(gen, mod, utils, shim)
 
 
 if __name__ == "__main__":
