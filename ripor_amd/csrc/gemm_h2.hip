@@ -310,12 +310,14 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
     // How the output paths are written matters more than what they compute (ISA of the first version, measured with the
     // per-tile stamps of tools/gemm_tile_timeline.py: 6 us per tile on an idle chip, 10-14 us in a full launch, where the
     // same stores take 2.5 us in tools/store_probe.hip):
-    //  * vmcnt counts loads AND stores, and the two return out of order, so waiting for ANY global load while stores are
-    //    in flight is s_waitcnt vmcnt(0) — a full write-acknowledge round trip. The residual pieces used to be loaded in
-    //    the same loop as the stores (and, behind a runtime `if (g.resid)`, the compiler kept the wait on the path without
-    //    a residual too): every one of the 32 stores of a wave waited for the previous one to be acknowledged by the L2.
-    //    Now the variants with and without a residual are separate instantiations (RES), a variant without one contains
-    //    no global load at all, and a variant with one requests every piece of the strip before the strip's first store.
+    //  * vmcnt counts loads AND stores in issue order. The residual pieces used to be loaded behind runtime branches in the
+    //    same loop as the stores; at every join the compiler no longer knows what is pending and waits for vmcnt(0) — and
+    //    it kept that wait on the path WITHOUT a residual too: each of the 32 stores of a wave waited for the previous
+    //    one's write acknowledgement from the L2. Now the variants with and without a residual are separate
+    //    instantiations (RES), a variant without one contains no global load at all, and one with a residual requests every
+    //    piece of the strip with unconditional loads before the strip's first store. (Requesting strip 1's pieces before
+    //    strip 0's stores as well — they otherwise complete behind them — needs registers the kernel does not have: all
+    //    of them spill 120-290 B, half of them fits and measured -0.2 % same-box.)
     //  * every LDS read of a batch (staged rows, row scales) is issued before the first use (explicit arrays + a scheduling
     //    barrier; the compiler otherwise sinks each read next to its use behind an lgkmcnt(0)).
     auto planes_path = [&](auto res_tag) __attribute__((always_inline)) {
