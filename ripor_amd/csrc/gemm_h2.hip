@@ -485,18 +485,17 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 }
 
 // ---- ping-pong 256x256 variant -------------------------------------------------------------------------
-// Same tile, LDS layout and epilogue as the pipe kernel; different K-loop synchronisation. The 8 waves are
-// two groups of four (wm = 0 / 1), one wave of each group per SIMD. A K-tile is four phases (k-chunk x
-// half of the wave's A rows), each phase = a load segment (fragment ds_reads + LDS-DMA issue) and an MFMA
-// segment (12 MFMAs), separated by raw s_barriers:
+// 256x256x32 tiles, LDS-DMA feed into two 64-KB operand buffers, LDS-transposed epilogue. The 8 waves are two groups of
+// four (wm = 0 / 1), one wave of each group per SIMD. A K-tile is two phases (one per 16-column k-chunk), each phase = a
+// load segment (4 W + 8 A fragment ds_reads) and an MFMA segment (24 MFMAs), separated by raw s_barriers:
 //       L_p | barrier | M_p | barrier | L_p+1 | ...
 // Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA segment while the other
-// issues its loads: the LDS read latency (which the in-phase pipe kernel pays with the MFMA pipe idle) is
-// hidden behind the other group's MFMAs. LDS-DMA of tile t+1 is issued in the MFMA shadows of M_0..M_2 of tile t
-// (a piece costs ~100 issue cycles in a load segment, which made L longer than M), retired by
-// `s_waitcnt vmcnt(0)` at the end of L_3 and first read in L_0 of tile t+1 (one phase after the wait, as
-// the staggered groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's
-// last reads are retired before the other group starts overwriting it.
+// issues its loads: the LDS read latency (which an in-phase kernel pays with the MFMA pipe idle) is hidden behind the
+// other group's MFMAs. The 8 LDS-DMA pieces of tile t+1 are issued in the MFMA shadows of M_0 of tile t, retired by
+// `s_waitcnt vmcnt(0)` at the end of L_1 and first read in L_0 of tile t+1 (one phase after the wait, as the staggered
+// groups need one barrier more); each L ends with lgkmcnt(0) BEFORE its barrier, so a buffer's last reads are retired
+// before the other group starts overwriting it. (Rounds 1-3 ran four phases of 12 MFMAs: twice the barriers, 5076 instead
+// of 4224 cycles per K-tile.)
 // BF16 = true (training GEMMs, RPR_PREC_BF16): one bf16 plane per operand; the LDS rows of the lo planes hold the NEXT
 // 32 columns of K instead, a K-tile is 64 deep and a phase issues 8 v_mfma_f32_32x32x16_bf16 (slice 0 x slice 0 and
 // slice 1 x slice 1) on the same fragment reads — see gemm_h2_dma_kernel.
