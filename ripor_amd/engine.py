@@ -517,9 +517,10 @@ class GuardedSearch:
     f16 plane range of the split-precision GEMMs) -> exact fp32 MFMA. ``STATUS_EMPTY_QUERY`` raises ``ValueError``.
     ``repeated`` tells whether the returned result is a second run (its tensors are then new ones)."""
 
-    def __init__(self, model, trie, ids, mask, B, L, log_softmax, res, ticket):
+    def __init__(self, model, trie, ids, mask, B, L, log_softmax, res, ticket, optimistic=False):
         self._args = (model, trie, ids, mask, B, L, log_softmax)
         self._res, self._ticket = res, ticket
+        self._optimistic = bool(optimistic)      # this call ran in the optimistic forced-tail mode on the caller's behalf
         self.repeated = False
         self._done = False
         self._error: Optional[BaseException] = None
@@ -552,6 +553,8 @@ class GuardedSearch:
                 ctx.set_precision("f32")
             if saved_mode == 2:
                 ctx.set_forced_tail(1)
+            if st & _lib.STATUS_TAIL_LEFTOVER:
+                _note_optimistic_outcome(ctx, leftover=True)
             try:
                 ctx.status(clear=True)
                 self._res = search(model, trie, ids, mask, B, L, apply_log_softmax_for_scores=log_softmax)
@@ -560,7 +563,35 @@ class GuardedSearch:
                 ctx.set_precision(saved_prec)
                 ctx.set_forced_tail(saved_mode)
             self.repeated = True
+        elif self._optimistic:
+            _note_optimistic_outcome(self._args[0].ctx, leftover=False)
         return self._res
+
+
+# Back-off of the optimistic forced-tail mode (search_guarded). The optimistic mode bets that the last fork leaves no query
+# behind; when it loses, the batch is searched twice. On a trie whose popular prefixes stay dense for longer than its node
+# statistics suggest (real residual-quantiser codes may) the bet would be lost batch after batch: after two lost bets in a row
+# the ctx runs the exact mode for the next OPTIMISTIC_BACKOFF calls, then tries again.
+OPTIMISTIC_BACKOFF = 20
+
+
+def _note_optimistic_outcome(ctx: Context, leftover: bool) -> None:
+    if leftover:
+        ctx._leftover_streak = getattr(ctx, "_leftover_streak", 0) + 1
+        if ctx._leftover_streak >= 2:
+            ctx._exact_calls_left = OPTIMISTIC_BACKOFF
+    else:
+        ctx._leftover_streak = 0
+
+
+def _optimistic_allowed(ctx: Context) -> bool:
+    left = getattr(ctx, "_exact_calls_left", 0)
+    if left > 0:
+        ctx._exact_calls_left = left - 1
+        if ctx._exact_calls_left == 0:
+            ctx._leftover_streak = 1      # one more lost bet after the pause and the pause starts again
+        return False
+    return True
 
 
 def search_guarded(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor, attention_mask: torch.Tensor,
@@ -576,7 +607,8 @@ def search_guarded(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor
         optimistic = os.environ.get("RPR_OPTIMISTIC_TAIL", "1") != "0"
     mode = ctx.forced_tail()
     ctx.clear_status_async()
-    if optimistic and mode == 1:
+    went_optimistic = bool(optimistic and mode == 1 and _optimistic_allowed(ctx))
+    if went_optimistic:
         ctx.set_forced_tail(2)
     try:
         res = search(model, trie, input_ids, attention_mask, num_beams, max_new_tokens,
@@ -585,7 +617,7 @@ def search_guarded(model: DeviceModel, trie: DeviceTrie, input_ids: torch.Tensor
         ctx.set_forced_tail(mode)
     ticket = ctx.status_async(clear=True)
     return GuardedSearch(model, trie, input_ids, attention_mask, int(num_beams), int(max_new_tokens),
-                         bool(apply_log_softmax_for_scores), res, ticket)
+                         bool(apply_log_softmax_for_scores), res, ticket, optimistic=went_optimistic)
 
 
 def lngknp_forward(model: DeviceModel, input_ids: torch.Tensor, attention_mask: torch.Tensor, doc_codes: torch.Tensor,

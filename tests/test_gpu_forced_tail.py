@@ -450,3 +450,32 @@ def test_late_first_fork(E):
         _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"late fork, explicit {[depths[0] + 1, depths[0] + 3]}")
     finally:
         ctx.set_fork_depths(None)
+
+
+def test_optimistic_mode_backs_off_after_repeated_leftovers(E):
+    """search_guarded bets on the optimistic forced tail; on a trie where the last fork keeps leaving queries behind (a dense
+    60k-doc trie with early explicit forks) the bet is lost every time and each batch would be searched twice. After two
+    lost bets in a row the ctx runs the exact mode for the next OPTIMISTIC_BACKOFF calls: same results, no repeat."""
+    from ripor_amd.utils import synth
+    L, V, B, N = 12, 256, 10, 60_000
+    codes = synth.make_codes(N, L, V, seed=11)
+    ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=48)
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ctx.set_forced_tail(True)
+    exact = E.search(model, trie, ti, tm, B, L)
+    ctx._leftover_streak, ctx._exact_calls_left = 0, 0
+    ctx.set_fork_depths([1, 2])          # depth 2 of a 60k-doc trie: most beams still have several leaves below them
+    try:
+        ref = E.search(model, trie, ti, tm, B, L)
+        runs = [E.search_guarded(model, trie, ti, tm, B, L) for _ in range(4)]
+        res = [r.result() for r in runs]
+        assert [r.repeated for r in runs] == [True, True, False, False], [r.repeated for r in runs]
+        assert ctx._exact_calls_left == E.OPTIMISTIC_BACKOFF - 2
+        for r in res:
+            assert torch.equal(r.tokens, ref.tokens) and torch.equal(r.scores, ref.scores)
+        assert ctx.forced_tail() == 1, "the ctx mode must be what it was"
+    finally:
+        ctx.set_fork_depths(None)
+        ctx._leftover_streak, ctx._exact_calls_left = 0, 0
+    same = (exact.tokens == ref.tokens).all(dim=2) | ((exact.scores - ref.scores).abs() <= ORDER_TOL)
+    assert bool(same.all())
