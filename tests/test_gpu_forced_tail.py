@@ -467,8 +467,10 @@ def test_optimistic_mode_backs_off_after_repeated_leftovers(E):
     ctx.set_fork_depths([1, 2])          # depth 2 of a 60k-doc trie: most beams still have several leaves below them
     try:
         ref = E.search(model, trie, ti, tm, B, L)
-        runs = [E.search_guarded(model, trie, ti, tm, B, L) for _ in range(4)]
-        res = [r.result() for r in runs]
+        runs, res = [], []
+        for _ in range(4):              # (evaluate.py consults a guard one batch later; here: before the next call)
+            runs.append(E.search_guarded(model, trie, ti, tm, B, L))
+            res.append(runs[-1].result())
         assert [r.repeated for r in runs] == [True, True, False, False], [r.repeated for r in runs]
         assert ctx._exact_calls_left == E.OPTIMISTIC_BACKOFF - 2
         for r in res:
