@@ -481,3 +481,37 @@ def test_optimistic_mode_backs_off_after_repeated_leftovers(E):
         ctx._leftover_streak, ctx._exact_calls_left = 0, 0
     same = (exact.tokens == ref.tokens).all(dim=2) | ((exact.scores - ref.scores).abs() <= ORDER_TOL)
     assert bool(same.all())
+
+
+@pytest.mark.parametrize("lens", [(20, 60), (70, 150)])
+def test_tail_pass_with_long_queries(E, lens):
+    """Cross-attention of the tail pass over long queries: 33-64 encoder keys take the two-key-tile MFMA kernel, more than 64
+    the block kernel of the sequential steps (tail_kernels.hip::launch_tail_cross_attn). Forced tail vs the plain loop, and
+    the CPU oracle on two queries."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd.utils import synth
+    L, V, B, N = 10, 256, 6, 20_000
+    codes = synth.make_codes(N, L, V, seed=91)
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    sd = synth.make_state_dict(dims, seed=9)
+    ids, mask = synth.make_queries(10, vocab_size=dims.vocab_size, seed=9, min_len=lens[0], max_len=lens[1],
+                                   mean_len=(lens[0] + lens[1]) / 2, std_len=(lens[1] - lens[0]) / 4)
+    assert lens[0] <= int(mask.sum(1).min()) and ids.shape[1] > (64 if lens[0] >= 70 else 32)
+    ctx = E.Context.get(0)
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    ctx.set_fork_depths([2, 3])
+    try:
+        res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, f"long queries {lens}, forks [2, 3]")
+    finally:
+        ctx.set_fork_depths(None)
+    assert stats and stats[0]["forced"] + stats[1]["forced"] > 0, stats
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids[:2], mask[:2], B, L, use_kv_cache=True)
+    ref_tok, ref_sc = seqs.numpy().reshape(2, B, L + 1)[:, :, 1:], sc.numpy().reshape(2, B)
+    got_tok, got_sc = res.tokens[:2].cpu().numpy(), res.scores[:2].cpu().numpy()
+    near = np.zeros((2, B), dtype=bool)
+    near[:, 1:] |= (ref_sc[:, :-1] - ref_sc[:, 1:]) <= ORDER_TOL
+    near[:, :-1] |= (ref_sc[:, :-1] - ref_sc[:, 1:]) <= ORDER_TOL
+    assert ((got_tok == ref_tok).all(axis=2) | near).all()
+    np.testing.assert_allclose(got_sc, ref_sc, atol=SCORE_TOL, rtol=0)
