@@ -145,6 +145,17 @@ __device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, in
   return (size_t)m * ldo + on;
 }
 hipError_t launch_gemm_h2(GemmH2Args& a, hipStream_t s);
+// several bf16 products C_i[M_i, N_i] = A_i[M_i, K] W_i[N_i, K]^T (fp32 output, no fused extras) in one launch of the 256x256
+// ping-pong kernel, one K-loop per tile (gemm_h2_pp_group_kernel): the weight gradients of one transformer layer
+struct GemmGroupArgs {
+  static constexpr int MAXP = 8;
+  const __half* A[MAXP]; const __half* W[MAXP]; float* out[MAXP];
+  int M[MAXP], N[MAXP], ldo[MAXP];
+  int K, lda, ldw, n;
+};
+// table: device scratch for MAXP argument structs, written on stream s in front of the product launch (a later group on the
+// same stream may reuse it)
+hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, GemmH2Args* table, hipStream_t s);
 // colscale (nullable, length cols): element (r, c) is multiplied by colscale[c] before the split (folds a layer-norm
 // weight into the columns of the consuming projection); cols is ignored when colscale is null
 hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s,
@@ -395,7 +406,8 @@ hipError_t launch_split_dyn_T(const float* x, int R, int C, int ldi, int Rpad, _
 // fp32 [R, C] (row stride ldi) -> one bf16 plane (round to nearest even): plain out[R][C] and / or transposed
 // out_t[C][Rpad] (columns r >= R zero); RPR_PREC_BF16 training GEMMs
 hipError_t launch_to_bf16(const float* x, int R, int C, int ldi, void* out, hipStream_t s);
-hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s);
+hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s,
+                            const float* relu_act = nullptr, int ldt = 0);
 // all GEMM weights at once: segs[i] = fp32 tensor [R][C] (R % 2 == 0, C % 4 == 0), off = element offset of its copies in
 // `plain` ([R][C]) and `tr` ([C][R]); pref = exclusive prefix sums of ceil(R/64) * ceil(C/64)
 struct WSeg { const float* src; int R, C; unsigned long long off; };

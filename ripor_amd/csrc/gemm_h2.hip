@@ -504,267 +504,41 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
 // Schedules that were measured and removed (DESIGN.md "tried and rejected"; the code is in the history): a phase skew
 // between the persistent blocks, a per-round barrier between the blocks of an XCD, and the next tile's first K-tile
 // prefetched under the epilogue — all of them slower or equal on the power-capped headline step.
+// The body is textually shared by two kernels (gemm_h2_pp_body.inc): gemm_h2_pp_kernel (one product, its arguments by value)
+// and gemm_h2_pp_group_kernel (a table of products in device memory, blockIdx.y = product; see there).
 template <bool FULL, bool TRACE = false, bool BF16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
-  // per-tensor dynamic plane scales (training): read from the device; g itself must stay untouched — a kernel that writes
-  // to its by-value argument struct gets a private copy of all 320 bytes in scratch (measured: +20 % per launch)
-  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TN = 2;
-  constexpr int ROWS = 2 * (BM + BN), PER_WAVE = ROWS / 16 / NW;   // 8 DMA pieces per wave and K-tile
-  __shared__ __attribute__((aligned(16))) __half smem[2 * ROWS * HBK];
-  __shared__ float rs_tile[BM];                      // fused RMSNorm: rsqrt(mean(x^2) + eps) of the tile's rows
+#include "gemm_h2_pp_body.inc"
+}
 
-  // PERSISTENT: the grid is (at most) one block per CU and a block walks the tiles of its XCD's chunk — the stores of a
-  // tile's epilogue drain under the first K-tiles of the block's next tile instead of holding the CU until the block
-  // retires.
-  int nt = tiles_m * tiles_n;
-  if (g.m_dev) {                                             // packed rows: only the tiles holding live rows
-    if (g.live_hi > 0 && (*g.m_dev <= g.live_lo || *g.m_dev > g.live_hi)) return;   // the other kernel of the pair runs
-    nt = ((min(*g.m_dev, g.M) + BM - 1) / BM) * tiles_n;
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  // tile order: XCD x = block & 7 owns a contiguous chunk of the live tiles; its blocks walk the chunk side by side
-  // (blocks of XCD x: those with index = x mod 8, (gridDim.x - x + 7) / 8 of them — with one block per tile that is the
-  // chunk size and every block handles exactly one tile)
-  const int xq = nt >> 3, xr = nt & 7, xcd = blockIdx.x & 7, xk = blockIdx.x >> 3, xstep = ((int)gridDim.x - xcd + 7) >> 3;
-  const int chunk0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, chunk_n = xcd < xr ? xq + 1 : xq;
-  int round = 0;
-  for (int ti = xk; ti < chunk_n; ti += xstep, ++round) {
-  const int bid = chunk0 + ti;
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int bm = tm * BM, bn = tn * BN;
-  // TRACE: wall-clock stamps (100 MHz) of block 0 per tile: start, first K-tile landed, K-loop done, epilogue issued
-  const bool tl = TRACE && g.trace != nullptr && blockIdx.x == 0 && tid == 0 && round < 4096;
-#define PP_TILE_STAMP(k) if (TRACE) { if (tl) g.trace[100000 + round * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); }
-  PP_TILE_STAMP(0);
-  if (g.row_ssq && tid < BM) {   // one dependent load + rsqrt per row, hidden behind the first K-tile's DMA; the epilogue
-    const int m = bm + tid;      // (after the K-loop's barriers) reads the scales from LDS instead of global memory
-    rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
-  }
+// Grouped launch (bf16 training GEMMs): the weight-gradient products of one transformer layer, dW[N, K] = dY^T X for its six
+// (encoder: four) linear layers, are 9 .. 36 output tiles each with a reduction over all rows of the batch. One launch per
+// product cannot fill the chip without split-K (5-K-tile loops, fp32 partials, a reduce pass: 240 TF/s, and every
+// 252-block launch takes the whole chip from the input-gradient chain on the main stream); here ONE launch walks all
+// products of the layer, grid = (most tiles of any product, products): a block reads its product's argument struct from a
+// table in device memory (scalar loads; a struct assembled in the kernel from by-value arrays stayed in scratch, 344 bytes
+// per lane, because the epilogue indexes out[] / ldo[] at run time) and runs the whole reduction of one tile in a single
+// K-loop (t5-base decoder layer: 126 tiles x 128 K-tiles of 64 rows). Blocks past their product's tile count exit at once.
+// The table is written by gemm_group_table_kernel from by-value arguments on the same stream, directly in front of the
+// product launch: no host memory whose lifetime would have to outlast the enqueue.
+template <bool FULL>
+__global__ __launch_bounds__(512, 2) void gemm_h2_pp_group_kernel(const GemmH2Args* __restrict__ table) {
+  constexpr bool TRACE = false, BF16 = true;
+  const GemmH2Args& g = table[blockIdx.y];
+  const int tiles_m = (g.M + 255) >> 8, tiles_n = (g.N + 255) >> 8;
+#include "gemm_h2_pp_body.inc"
+}
 
-  // split-K (weight gradients of the training step: few output tiles, K = thousands of rows): blockIdx.y walks its own
-  // range of K-tiles and stores a partial result at out + blockIdx.y * part_stride (splitk_reduce_kernel adds them in order)
-  constexpr int KSTEP = BF16 ? 2 * HBK : HBK;
-  int nkt = g.K / KSTEP, kbeg = 0;
-  if (g.ksplit > 1) {
-    const int per = (nkt + g.ksplit - 1) / g.ksplit;
-    kbeg = blockIdx.y * per;
-    nkt = min(per, nkt - kbeg);
-  }
-  // (the lane index is laundered per tile: otherwise the compiler hoists the eight per-piece row / segment terms out of
-  // the tile loop and the 256-register kernel spills)
-  int lane_t = lane;
-  asm volatile("" : "+v"(lane_t));
-  const __half* src[PER_WAVE];
-// (operand, plane, limit and leading dimension are chosen from the wave-uniform 16-row group with value selects: an if / else
-// chain over the struct's fields made the compiler select field ADDRESSES and keep a private copy of the argument struct
-// in scratch)
-#define PP_SRC_SETUP(dst, lane_x, bm_x, bn_x)                                                                         \
-  _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j) {                                                              \
-    const int grow = 16 * (wave + NW * j);                      /* first LDS row of this piece: wave-uniform */       \
-    const int lrow = grow + ((lane_x) >> 2);                                                                          \
-    const int seg = ((lane_x) & 3) ^ ((lrow >> 2) & 3);                                                               \
-    const bool is_a = grow < 2 * BM, second = is_a ? grow >= BM : grow >= 2 * BM + BN;                                \
-    const __half* base = is_a ? g.A : g.W;                                                                            \
-    const size_t plane = second ? (BF16 ? (size_t)HBK : (is_a ? g.a_ps : g.w_ps)) : 0;                                \
-    const int limit = is_a ? g.M : g.N;                                                                               \
-    const size_t ld = is_a ? (size_t)g.lda : (size_t)g.ldw;                                                           \
-    int trow = (is_a ? (bm_x) + lrow - (second ? BM : 0) : (bn_x) + lrow - 2 * BM - (second ? BN : 0));               \
-    if (!FULL && trow >= limit) trow = limit - 1;                                                                     \
-    dst[j] = base + plane + (size_t)trow * ld + seg * 8 + (size_t)kbeg * KSTEP;                                       \
-  }
-  PP_SRC_SETUP(src, lane_t, bm, bn)
-#define PP_PIECE(buf, k0, j)                                                                                   \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (k0)),             \
-                                   (__attribute__((address_space(3))) void*)(smem + (size_t)(buf) * ROWS * HBK + \
-                                                                             16 * (wave + NW * (j)) * HBK),     \
-                                   16, 0, 0)
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
-  const int a_row = wm * (BM / WM) + frow, w_row = 2 * BM + wn * (BN / WN) + frow;
-  const int so0 = ((0 + hf) ^ sw) * 8, so1 = ((2 + hf) ^ sw) * 8;   // segment offsets of chunk 0 / 1
-
-  f16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
-  f16x8 ah2, ah3, al2, al3;   // two-phase schedule: all four 32-row fragments of the wave's A rows per k-chunk
-#define PP_LOAD_W(buf, so)                                                                              \
-  {                                                                                                     \
-    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
-    bh0 = *reinterpret_cast<const f16x8*>(base_ + (w_row) * HBK + (so));                                \
-    bh1 = *reinterpret_cast<const f16x8*>(base_ + (w_row + 32) * HBK + (so));                           \
-    bl0 = *reinterpret_cast<const f16x8*>(base_ + (BN + w_row) * HBK + (so));                           \
-    bl1 = *reinterpret_cast<const f16x8*>(base_ + (BN + w_row + 32) * HBK + (so));                      \
-  }
-#define PP_LOAD_A(buf, so, i0)                                                                          \
-  {                                                                                                     \
-    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
-    ah0 = *reinterpret_cast<const f16x8*>(base_ + (a_row + (i0) * 32) * HBK + (so));                    \
-    ah1 = *reinterpret_cast<const f16x8*>(base_ + (a_row + (i0) * 32 + 32) * HBK + (so));               \
-    al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32) * HBK + (so));               \
-    al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + (i0) * 32 + 32) * HBK + (so));          \
-  }
-#define PP_LOAD_A4(buf, so)                                                                             \
-  {                                                                                                     \
-    const __half* base_ = smem + (size_t)(buf) * ROWS * HBK;                                            \
-    ah0 = *reinterpret_cast<const f16x8*>(base_ + (a_row) * HBK + (so));                                \
-    ah1 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 32) * HBK + (so));                           \
-    ah2 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 64) * HBK + (so));                           \
-    ah3 = *reinterpret_cast<const f16x8*>(base_ + (a_row + 96) * HBK + (so));                           \
-    al0 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row) * HBK + (so));                           \
-    al1 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 32) * HBK + (so));                      \
-    al2 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 64) * HBK + (so));                      \
-    al3 = *reinterpret_cast<const f16x8*>(base_ + (BM + a_row + 96) * HBK + (so));                      \
-  }
-#define PP_MFMA(a, b, c)                                                                                 \
-  do {                                                                                                   \
-    if (BF16) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0); \
-    else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);                                   \
-  } while (0)
-// the 12 MFMAs of a phase in three groups of four (lo*hi, hi*lo, hi*hi); D1..D3 are statements issued in the
-// MFMA shadows after the 2nd, 6th and 10th MFMA (LDS-DMA pieces of the next tile, or nothing)
-#define PP_MMA(i0, D1, D2, D3)                                                                          \
-  {                                                                                                     \
-    if (BF16) {   /* slice 1 x slice 1 ("lo" rows), then slice 0 x slice 0 */                           \
-      PP_MFMA(al0, bl0, acc[(i0)][0]); PP_MFMA(al0, bl1, acc[(i0)][1]);                                 \
-      __builtin_amdgcn_sched_barrier(0); D1; __builtin_amdgcn_sched_barrier(0);                         \
-      PP_MFMA(al1, bl0, acc[(i0) + 1][0]); PP_MFMA(al1, bl1, acc[(i0) + 1][1]);                         \
-      __builtin_amdgcn_sched_barrier(0); D2; __builtin_amdgcn_sched_barrier(0);                         \
-      PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                 \
-      __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                         \
-      PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                         \
-    } else {                                                                                            \
-    PP_MFMA(al0, bh0, acc[(i0)][0]); PP_MFMA(al0, bh1, acc[(i0)][1]);                                   \
-    __builtin_amdgcn_sched_barrier(0); D1; __builtin_amdgcn_sched_barrier(0);                           \
-    PP_MFMA(al1, bh0, acc[(i0) + 1][0]); PP_MFMA(al1, bh1, acc[(i0) + 1][1]);                           \
-    PP_MFMA(ah0, bl0, acc[(i0)][0]); PP_MFMA(ah0, bl1, acc[(i0)][1]);                                   \
-    __builtin_amdgcn_sched_barrier(0); D2; __builtin_amdgcn_sched_barrier(0);                           \
-    PP_MFMA(ah1, bl0, acc[(i0) + 1][0]); PP_MFMA(ah1, bl1, acc[(i0) + 1][1]);                           \
-    PP_MFMA(ah0, bh0, acc[(i0)][0]); PP_MFMA(ah0, bh1, acc[(i0)][1]);                                   \
-    __builtin_amdgcn_sched_barrier(0); D3; __builtin_amdgcn_sched_barrier(0);                           \
-    PP_MFMA(ah1, bh0, acc[(i0) + 1][0]); PP_MFMA(ah1, bh1, acc[(i0) + 1][1]);                           \
-    }                                                                                                   \
-  }
-// the 24 MFMAs of a phase of the two-phase schedule: lo*hi, hi*lo, hi*hi over the wave's 4 x 2 output tiles (every
-// accumulator is touched once per group of eight: no back-to-back dependence); D0..D7 = statements in the MFMA shadows
-#define PP_SB __builtin_amdgcn_sched_barrier(0)
-#define PP_MMA8(A0, A1, A2, A3, B0, B1, Da, Db, Dc)                                                     \
-    PP_MFMA(A0, B0, acc[0][0]); PP_MFMA(A0, B1, acc[0][1]); PP_MFMA(A1, B0, acc[1][0]);                 \
-    PP_SB; Da; PP_SB;                                                                                   \
-    PP_MFMA(A1, B1, acc[1][1]); PP_MFMA(A2, B0, acc[2][0]); PP_MFMA(A2, B1, acc[2][1]);                 \
-    PP_SB; Db; PP_SB;                                                                                   \
-    PP_MFMA(A3, B0, acc[3][0]); PP_MFMA(A3, B1, acc[3][1]);                                             \
-    PP_SB; Dc; PP_SB;
-#define PP_MMA24(D0, D1, D2, D3, D4, D5, D6, D7)                                                        \
-  {                                                                                                     \
-    if (BF16) {   /* slice 1 x slice 1 ("lo" rows), then slice 0 x slice 0 */                           \
-      PP_MMA8(al0, al1, al2, al3, bl0, bl1, D0, D1, D2)                                                 \
-      PP_SB; D3; D4; PP_SB;                                                                             \
-      PP_MMA8(ah0, ah1, ah2, ah3, bh0, bh1, D5, D6, D7)                                                 \
-    } else {                                                                                            \
-      PP_MMA8(al0, al1, al2, al3, bh0, bh1, D0, D1, D2)                                                 \
-      PP_MMA8(ah0, ah1, ah2, ah3, bl0, bl1, D3, D4, D5)                                                 \
-      PP_MMA8(ah0, ah1, ah2, ah3, bh0, bh1, D6, D7, (void)0)                                            \
-    }                                                                                                   \
-  }
-// the 8 LDS-DMA pieces of the next tile go into the MFMA shadows of M_0 / M_1 / M_2 (3 + 3 + 2); issuing them in
-// the load segments instead (4+4 or 3+3+2), with or without s_setprio, measured the same within 0.5 % (DVFS)
-#define PP_DMA(j) if (more) PP_PIECE(nxt, k1, j)
-#define PP_DMA_M(j) PP_DMA(j)
-// end of a load segment: retire this wave's ds_reads (and, with VM, its LDS-DMA), then the segment barrier
-#define PP_L_END(waitimm, ph)                                                                           \
-  __builtin_amdgcn_sched_barrier(0);                                                                    \
-  __builtin_amdgcn_s_waitcnt(waitimm);                                                                  \
-  PP_STAMP((ph) * 4 + 1);                                                                               \
-  __builtin_amdgcn_s_barrier();                                                                         \
-  PP_STAMP((ph) * 4 + 2);                                                                               \
-  __builtin_amdgcn_sched_barrier(0);                                                                    \
-  __builtin_amdgcn_s_setprio(1)
-#define PP_M_END(ph)                                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                    \
-  __builtin_amdgcn_s_setprio(0);                                                                        \
-  PP_STAMP((ph) * 4 + 3);                                                                               \
-  __builtin_amdgcn_s_barrier();                                                                         \
-  __builtin_amdgcn_sched_barrier(0)
-  constexpr int WAIT_LGKM = 0xc07f, WAIT_ALL = 0x0070;   // lgkmcnt(0) | vmcnt(0) lgkmcnt(0)
-
-  // TRACE: block 0 stamps s_memtime (shader cycles) at the 4 segment edges of each phase -> 16 per (K-tile, wave),
-  // slot 16 = s_memrealtime (100 MHz) at the start of the tile, so the sustained shader clock can be derived
-  const bool tr = TRACE && g.trace != nullptr && blockIdx.x == 0 && lane == 0;
-#define PP_STAMP(slot) if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + (slot)] = __builtin_readcyclecounter(); }
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) PP_PIECE(0, 0, j);
-  __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-  __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
-  __builtin_amdgcn_sched_barrier(0);
-  PP_TILE_STAMP(1);
-  if (wm == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
-  __builtin_amdgcn_sched_barrier(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1, nxt = cur ^ 1;
-    const bool more = kt + 1 < nkt;
-    const int k1 = (kt + 1) * KSTEP;
-    // Two phases per K-tile (one per 16-column k-chunk), each = load segment (4 W + 8 A fragments) | barrier | MFMA segment
-    // (24 MFMAs; the 8 LDS-DMA pieces of the next tile in the shadows of the FIRST one) | barrier. Four phases of 12 MFMAs
-    // (a phase per k-chunk and half of the A rows) cost twice the barriers: per-segment stamps showed every one of the 8
-    // barrier intervals of a K-tile at ~630 cycles for 384 of MFMA issue (M 460-550 with the DMA pieces and fixed costs,
-    // ~100 of barrier latency): 5076 cycles per K-tile against 3072 of matrix-pipe time.
-    if (TRACE) { if (tr) g.trace[((size_t)kt * NW + wave) * 18 + 16] = __builtin_amdgcn_s_memrealtime(); }
-    PP_STAMP(0);
-    PP_LOAD_W(cur, so0);
-    PP_LOAD_A4(cur, so0);
-    PP_L_END(WAIT_LGKM, 0);
-    PP_MMA24(PP_DMA_M(0), PP_DMA_M(1), PP_DMA_M(2), PP_DMA_M(3), PP_DMA_M(4), PP_DMA_M(5), PP_DMA_M(6), PP_DMA_M(7));
-    PP_M_END(0);
-    // phase 1: chunk 1; tile kt+1 must have landed before anyone's next L_0
-    PP_STAMP(4);
-    PP_LOAD_W(cur, so1);
-    PP_LOAD_A4(cur, so1);
-    PP_L_END(WAIT_ALL, 1);
-    PP_MMA24((void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
-    PP_M_END(1);
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();         // group 0 catches the extra barrier of group 1
-  __builtin_amdgcn_sched_barrier(0);
-  PP_TILE_STAMP(2);
-#undef PP_LOAD_W
-#undef PP_LOAD_A
-#undef PP_MFMA
-#undef PP_MMA
-#undef PP_MMA8
-#undef PP_MMA24
-#undef PP_SB
-#undef PP_LOAD_A4
-#undef PP_DMA
-#undef PP_DMA_M
-#undef PP_L_END
-#undef PP_M_END
-#undef PP_STAMP
-
-  int lane_e = lane;   // laundered like lane_t: the epilogue's per-lane offsets must not live through the K-loop
-  asm volatile("" : "+v"(lane_e));
-  h2_epilogue_256<FULL, TM, TN, WM, WN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
-  // The staging strips alias the operand buffers the next tile's LDS-DMA writes, and rs_tile is rewritten: every wave's LDS
-  // reads must have returned (lgkmcnt(0)) before anyone goes on. NOT __syncthreads(): its fence also waits for vmcnt(0),
-  // i.e. for every global store of this tile to be acknowledged by the L2 (2-5 us under load) — the stores take their data
-  // from registers and drain under the next tile's prologue instead.
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  PP_TILE_STAMP(3);
-#undef PP_TILE_STAMP
-#undef PP_PIECE
-#undef PP_SRC_SETUP
-  }
+__global__ void gemm_group_table_kernel(GemmGroupArgs p, GemmH2Args* __restrict__ table) {
+  const int i = threadIdx.x;
+  if (i >= p.n) return;
+  GemmH2Args g{};
+  g.A = p.A[i]; g.W = p.W[i]; g.lda = p.lda; g.ldw = p.ldw;
+  g.out[0] = g.out[1] = g.out[2] = p.out[i];
+  g.ldo[0] = g.ldo[1] = g.ldo[2] = p.ldo[i];
+  g.M = p.M[i]; g.N = p.N[i]; g.K = p.K; g.split_n = p.N[i];
+  g.acc_scale = 1.0f; g.plane_scale = 1.0f; g.bf16 = 1;
+  table[i] = g;
 }
 
 // ---- skinny variant: M <= 400 rows (one to a few dozen queries in flight) ---------------------------------------
@@ -967,6 +741,23 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_h2_pp_kernel<true>), gr, bl, 0, s, a, tiles_m, tiles_n);
   else
     hipLaunchKernelGGL((gemm_h2_pp_kernel<false>), gr, bl, 0, s, a, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, GemmH2Args* table, hipStream_t s) {
+  if (p.n <= 0) return hipSuccess;
+  if (!table || p.n > GemmGroupArgs::MAXP || p.K <= 0 || (p.K & 63) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
+  int max_tiles = 0;
+  bool full = true;
+  for (int i = 0; i < p.n; ++i) {
+    if (!p.A[i] || !p.W[i] || !p.out[i] || p.M[i] <= 0 || p.N[i] <= 0 || (p.ldo[i] & 3) || (p.N[i] & 3)) return hipErrorInvalidValue;
+    max_tiles = std::max(max_tiles, ((p.M[i] + 255) / 256) * ((p.N[i] + 255) / 256));
+    full = full && (p.M[i] % 256 == 0) && (p.N[i] % 256 == 0);
+  }
+  hipLaunchKernelGGL(gemm_group_table_kernel, dim3(1), dim3(64), 0, s, p, table);
+  const dim3 gr(max_tiles, p.n), bl(512);
+  if (full) hipLaunchKernelGGL((gemm_h2_pp_group_kernel<true>), gr, bl, 0, s, table);
+  else hipLaunchKernelGGL((gemm_h2_pp_group_kernel<false>), gr, bl, 0, s, table);
   return hipGetLastError();
 }
 

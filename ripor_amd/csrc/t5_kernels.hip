@@ -148,6 +148,10 @@ hipError_t launch_dec_embed(const float* start, const float* in_embeds, const ui
 // One block per (query, head). K and V of the head are staged once in LDS ([Lq][65] padded), every
 // wave then handles query rows i = wave, wave+4, ...: lane j scores keys j, j+64, ...; the q row is
 // broadcast through SGPRs (v_readlane); softmax across the wave; PV with lane = output dim.
+// Nothing inside the row loop reads global memory: the relative-position bias of every key offset (bucket table + bias
+// table, two dependent loads), the key mask and the q rows (eight rows of the wave per batch, requested together) are
+// staged in LDS first. With those three loads in the loop a row cost two memory round trips: 61 us for the 3072 blocks of
+// a teacher-forced decoder layer (32 positions), 290 us for 2150 packed queries of the search encoder.
 __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Lq = a.Lq, H = a.H, inner = H * DKV, ld = 3 * inner;
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   float* Ks = smem;                    // [Lq][65]
   float* Vs = smem + (size_t)Lq * 65;  // [Lq][64]
   float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq] normalised weights per wave
-  float* Bs = Ps + 4 * Lq;             // [buckets<=64] bias of this head
+  float* RB = Ps + 4 * Lq;             // [2 Lq] bias of this head per key offset (causal: i - j; else j - i + nrow - 1)
+  float* Qs = RB + 2 * Lq;             // [4][8][64] q rows of the wave's current batch
+  int* Ms = reinterpret_cast<int*>(Qs + 4 * 8 * 64);   // [Lq] key mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // packed encoder: the query's rows start at offs[qi] and only its own lens[qi] positions exist (the padded
   // positions behind them are masked keys and unused query rows in the padded layout)
@@ -170,13 +176,29 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
     *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
   }
-  if (tid < a.buckets) Bs[tid] = a.rel_bias[tid * H + h];
+  const int nrb = a.causal ? nrow : 2 * nrow - 1, rb0 = a.causal ? 0 : MAX_LQ - nrow;
+  for (int k = tid; k < nrb; k += 256) RB[k] = a.rel_bias[a.bucket[rb0 + k] * H + h];
+  if (!a.causal) {
+    const int32_t* mrow = a.mask + (size_t)qi * Lq;
+    for (int j = tid; j < nrow; j += 256) Ms[j] = mrow[j];
+  }
   __syncthreads();
-  const int32_t* mrow = a.mask + (size_t)qi * Lq;
   const int nchunk = (nrow + 63) >> 6;
   float* P = Ps + wave * Lq;
-  for (int i = wave; i < nrow; i += 4) {
-    const float qv = base[(size_t)i * ld + lane];  // lane d holds q_i[d]
+  float* Qw = Qs + wave * 8 * 64;
+  for (int i0 = wave; i0 < nrow; i0 += 32) {
+    {   // the wave's next eight q rows: all requests go out before the first one is used
+      float qb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + 4 * u; qb[u] = i < nrow ? base[(size_t)i * ld + lane] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) Qw[u * 64 + lane] = qb[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + 4 * u;
+    if (i >= nrow) break;
+    const float qv = Qw[u * 64 + lane];  // lane d holds q_i[d]
     float sc[MAX_LQ / 64];
     float mx = -INFINITY;
 #pragma unroll
@@ -192,8 +214,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
         acc = fmaf(qd, kr[d], acc);
       }
       float s = -INFINITY;
-      if (a.causal) { if (j <= i) s = acc + Bs[a.bucket[i - j]]; }   // teacher-forced decoder: rel = j - i <= 0, table[n = i - j]
-      else if (j < nrow && mrow[j] != 0) s = acc + Bs[a.bucket[j - i + (MAX_LQ - 1)]];
+      if (a.causal) { if (j <= i) s = acc + RB[i - j]; }   // teacher-forced decoder: rel = j - i <= 0, table[n = i - j]
+      else if (j < nrow && Ms[j] != 0) s = acc + RB[j - i + nrow - 1];
       sc[c] = s;
       mx = fmaxf(mx, s);
     }
@@ -227,12 +249,15 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+  }
 }
 
+static size_t enc_attn_smem(int Lq) {
+  return ((size_t)Lq * 65 + (size_t)Lq * 64 + 4 * (size_t)Lq + 2 * (size_t)Lq + 4 * 8 * 64 + (size_t)Lq) * sizeof(float);
+}
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
-  const size_t smem = ((size_t)a.Lq * 65 + (size_t)a.Lq * 64 + 4 * (size_t)a.Lq + 64) * sizeof(float);
-  hipLaunchKernelGGL(enc_attn_kernel, dim3(a.Q * a.H), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(enc_attn_kernel, dim3(a.Q * a.H), dim3(256), enc_attn_smem(a.Lq), s, a);
   return hipGetLastError();
 }
 

@@ -41,6 +41,17 @@ struct TrainWs {
   // linear layer's input behind — the X^T operand of its weight-gradient product — so the backward pass neither converts
   // X again nor recomputes the normalised inputs it would only need for that
   DevBuf wc, wcT, wseg, wpref, xT;
+  // bf16 mode, grouped weight gradients: the dY^T operands of one layer's products live side by side in one of two sets
+  // (a set is rewritten two layers later, after its group launch has finished: ev_gdone), the products are collected in
+  // `grp` while the layer's input-gradient chain is enqueued and go out as ONE launch on the side stream (gtab = the
+  // device table the launch reads its argument structs from)
+  DevBuf dyT[2], gtab;
+  hipEvent_t ev_gfork[2] = {}, ev_gdone[2] = {};
+  bool gdone_pending[2] = {};
+  GemmGroupArgs grp = {};
+  int gset = 0;
+  size_t dyT_used = 0;
+  double grp_flops = 0, grp_bytes = 0;
   DevBuf aseg, apref;                  // rpr_adamw_step: one launch over all tensors (table built once per model)
   const rpr_model* aw_model = nullptr;
   int aw_nseg = 0, aw_chunks = 0;
@@ -107,6 +118,13 @@ int tensure(rpr_ctx* c, DevBuf& b, size_t bytes) {   // like ensure(), without t
 
 inline int pad32(int n) { return (n + 31) & ~31; }
 inline int pad64(int n) { return (n + 63) & ~63; }
+// row stride (elements) of the transposed bf16 operands [cols][pad64(rows)] of the weight-gradient products. RPR_TRAIN_XT_PAD=n
+// pads it by n elements: a stride of 8192 rows = 16 KB looked like a memory-channel hazard for the K-tiles (128-byte pieces
+// of 256 rows), but measured no different (27.4 ms per step unpadded, 27.6 with 64, 28.3 with 32): the default is unpadded.
+inline int ldT(int rows) {
+  static const int pad = [] { const char* e = getenv("RPR_TRAIN_XT_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v + 7) & ~7; }();
+  return pad64(rows) + pad;
+}
 
 struct Dims {
   int bz, Lq, L, S, R, T, dm, inner, dff, H, ne, nd, V, xld, buckets;
@@ -163,7 +181,7 @@ void gemm_bf16(Launcher& Ln, const void* A, int lda, const void* B, int ldb, flo
          &g.kernel_cls);
 }
 
-// save_xt (bf16 mode): where to leave the transposed copy [K][pad64(M)] of A for the weight-gradient product
+// save_xt (bf16 mode): where to leave the transposed copy [K][pad64(M)] (row stride ldT(M)) of A for the weight-gradient product
 void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
           const float* resid = nullptr, int relu = 0, void* save_xt = nullptr) {
   if (Ln.c->precision == RPR_PREC_BF16) {
@@ -172,7 +190,7 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
     TrainWs& w = *Ln.c->tws;
     if (lda != K || ldb != K) { Ln.err = RPR_ERR_INVALID; return; }
     hipStream_t s = Ln.s;
-    if (save_xt) Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_to_bf16_T(A, M, K, lda, pad64(M), save_xt, w.tA.p, s); });
+    if (save_xt) Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_to_bf16_T(A, M, K, lda, pad64(M), save_xt, w.tA.p, s, nullptr, ldT(M)); });
     else Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16(A, M, K, lda, w.tA.p, s); });
     const void* wb = w.wT.p;
     auto it = w.wc_off.find(B);
@@ -202,12 +220,12 @@ void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float*
 }
 
 // Saved X^T operands (bf16 mode): encoder layer i holds [qkv | o | wi | wo], then the cross K/V projection, then decoder
-// layer i [qkv | o | xq | xo | wi | wo]; a slot is [K][pad64(rows)] bf16.
+// layer i [qkv | o | xq | xo | wi | wo]; a slot is [K][pad64(rows)] bf16 with row stride ldT(rows).
 enum XtSite { XT_QKV, XT_O, XT_XQ, XT_XO, XT_WI, XT_WO };
 struct XtLayout {
   size_t Tp, Rp, enc_layer, dec_layer, xkv_off, dec_off, total;
   int dm, inner, dff;
-  explicit XtLayout(const Dims& D) : Tp(pad64(D.T)), Rp(pad64(D.R)), dm(D.dm), inner(D.inner), dff(D.dff) {
+  explicit XtLayout(const Dims& D) : Tp(ldT(D.T)), Rp(ldT(D.R)), dm(D.dm), inner(D.inner), dff(D.dff) {   // Tp, Rp: row strides
     enc_layer = Tp * (size_t)(2 * dm + inner + dff);
     dec_layer = Rp * (size_t)(3 * dm + 2 * inner + dff);
     xkv_off = enc_layer * D.ne;
@@ -304,14 +322,63 @@ struct Bwd {
                               return n < 1 ? 1 : (n > TrainWs::NSIDE ? TrainWs::NSIDE : n); }();
     return whole_k() ? v : 1;
   }
+  // bf16 mode: the weight gradients of a layer as one grouped launch (gemm_h2_pp_group_kernel); RPR_TRAIN_DW_GROUP=0 selects
+  // the per-product routes above. Measured, t5-base bz 128: see DESIGN.md section 9.
+  static bool grouped() {
+    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_GROUP"); return e ? atoi(e) : 1; }();
+    return v != 0;
+  }
+  // enqueue the products collected since the last flush on the side stream; the main stream goes on
+  void flush_group() {
+    if (w.grp.n == 0 || Ln.err) return;
+    hipStream_t s = Ln.s, side = w.side[0];
+    const int gs = w.gset;
+    if (hipEventRecord(w.ev_gfork[gs], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_gfork[gs], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    Launcher L2{c, side};
+    const GemmGroupArgs grp = w.grp;
+    L2.run(RPR_K_GEMM, w.grp_flops, w.grp_bytes, [&] { return launch_gemm_h2_group(grp, P<GemmH2Args>(w.gtab), side); });
+    if (L2.err) { Ln.err = L2.err; return; }
+    if (hipEventRecord(w.ev_gdone[gs], side) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    w.gdone_pending[gs] = true;
+    w.grp.n = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0;
+    w.gset = gs ^ 1;
+    if (w.gdone_pending[w.gset]) {   // the next layer writes into the other set: its last group launch must be over
+      if (hipStreamWaitEvent(s, w.ev_gdone[w.gset], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+      w.gdone_pending[w.gset] = false;
+    }
+  }
   // dX[M, K] = dY[M, N] W[N, K]  and  dW[N, K] = dY[M, N]^T X[M, K]  (dX may alias X: X is consumed first)
-  void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K, const void* saved_xt = nullptr) {
+  // relu_act (bf16 mode only): dY is the gradient w.r.t. relu(.) and relu_act the stored activation; the mask is applied
+  // while dY is converted (the caller skips launch_relu_bwd)
+  void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K, const void* saved_xt = nullptr,
+            const float* relu_act = nullptr) {
     const int Mp = pad32(M);
     hipStream_t s = Ln.s;
     if (c->precision == RPR_PREC_BF16) {
       // bf16 operands (see gemm()): one read of dY gives its plain and its transposed copy; dW on the side stream.
       // The bf16 kernel walks K in tiles of 64: the reduction length of the dW product (the rows) is padded to 64.
       const int Mp = (M + 63) & ~63;
+      auto wit_g = w.wc_off.find(W);
+      const int Ml = ldT(M);
+      const size_t need = (((size_t)N * Ml * sizeof(__half)) + 255) & ~(size_t)255;
+      if (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && w.dyT_used + need <= w.dyT[w.gset].cap &&
+          (w.grp.n == 0 || w.grp.K == Mp) && w.grp.n < GemmGroupArgs::MAXP) {
+        // grouped route: dY^T into this layer's set, the product into the group, dX on the main stream at once
+        void* py = w.tA.p;
+        __half* pyt = reinterpret_cast<__half*>(static_cast<char*>(w.dyT[w.gset].p) + w.dyT_used);
+        w.dyT_used += need;
+        Ln.run(RPR_K_OTHER, 0, (relu_act ? 12.0 : 8.0) * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s, relu_act, Ml); });
+        GemmGroupArgs& gp = w.grp;
+        const int i = gp.n++;
+        gp.A[i] = pyt; gp.W[i] = reinterpret_cast<const __half*>(saved_xt); gp.out[i] = dW;
+        gp.M[i] = N; gp.N[i] = K; gp.ldo[i] = K; gp.K = Mp; gp.lda = Ml; gp.ldw = Ml;
+        w.grp_flops += 2.0 * N * (double)K * Mp;
+        w.grp_bytes += 2.0 * ((double)N * Mp + (double)K * Mp) + 4.0 * (double)N * K;
+        const void* pwt = reinterpret_cast<const __half*>(w.wcT.p) + wit_g->second;
+        gemm_bf16(Ln, py, N, pwt, N, dX, K, M, K, N, nullptr, 0);
+        return;
+      }
+      flush_group();   // (a product the group cannot take: keep the order of the side stream's work)
       const int f = w.flip; w.flip = (w.flip + 1) % TrainWs::NSIDE;
       hipStream_t side = whole_k() ? w.side[f % side_streams()] : w.side[0];
       void *py = w.tA.p, *pyt = w.tC[f].p;
@@ -320,7 +387,7 @@ struct Bwd {
         if (hipStreamWaitEvent(s, w.ev_done[f], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = false;
       }
-      Ln.run(RPR_K_OTHER, 0, 8.0 * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s); });
+      Ln.run(RPR_K_OTHER, 0, (relu_act ? 12.0 : 8.0) * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s, relu_act); });
       if (saved_xt) pxt = saved_xt;                       // left behind by the forward pass
       else Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16_T(X, M, K, K, Mp, w.tB[f].p, nullptr, s); });
       auto wit = w.wc_off.find(W);
@@ -332,7 +399,7 @@ struct Bwd {
       static const bool side_on_b = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
       {
         Launcher L2{c, side_on_b ? side : s};
-        gemm_bf16(L2, pyt, Mp, pxt, Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
+        gemm_bf16(L2, pyt, Mp, pxt, saved_xt ? Ml : Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
         if (L2.err) { Ln.err = L2.err; return; }
         if (hipEventRecord(w.ev_done[f], side_on_b ? side : s) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
         w.done_pending[f] = true;
@@ -414,7 +481,17 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
   E(w.tA, wide * rp * f);
   // the transposed operands of a weight-gradient product (fp32, two f16 planes or bf16), one set per side stream
   for (int i = 0; i < TrainWs::NSIDE; ++i) { E(w.tB[i], wide * rp * f); E(w.tC[i], wide * rp * f); }
-  if (c->precision == RPR_PREC_BF16) E(w.xT, XtLayout(D).total * sizeof(__half));
+  if (c->precision == RPR_PREC_BF16) {
+    E(w.xT, XtLayout(D).total * sizeof(__half));
+    if (Bwd::grouped()) {
+      // dY^T of one layer's products: [N_out][pad64(rows)] bf16 each, 256-byte aligned
+      const size_t Rp = ldT(D.R), Tp = ldT(D.T);
+      const size_t dec = (3 * dm + dff + 4 * inner) * Rp, enc = (2 * dm + dff + 3 * inner) * Tp, xkv = (size_t)D.xld * Tp;
+      const size_t need = std::max(std::max(dec, enc), xkv) * sizeof(__half) + 8 * 256;
+      E(w.dyT[0], need); E(w.dyT[1], need);
+      E(w.gtab, GemmGroupArgs::MAXP * sizeof(GemmH2Args));
+    }
+  }
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
   E(w.w_part, ((rows + 3) / 4) * dm * f);
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
@@ -425,6 +502,10 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
       if (i < Bwd::side_streams()) RPR_HIP(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking));   // only the streams in use
       RPR_HIP(hipEventCreateWithFlags(&w.ev_fork[i], hipEventDisableTiming));
       RPR_HIP(hipEventCreateWithFlags(&w.ev_done[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; ++i) {
+      RPR_HIP(hipEventCreateWithFlags(&w.ev_gfork[i], hipEventDisableTiming));
+      RPR_HIP(hipEventCreateWithFlags(&w.ev_gdone[i], hipEventDisableTiming));
     }
   }
   return e;
@@ -535,6 +616,8 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     // ... and for the weight gradients in flight: the last product of every side stream (stream order covers the earlier ones)
     for (int i = 0; i < TrainWs::NSIDE; ++i)
       if (w.done_pending[i] && hipStreamWaitEvent(hook->comm, w.ev_done[i], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
+    for (int i = 0; i < 2; ++i)     // grouped weight gradients: the launch of every set still in flight
+      if (w.gdone_pending[i] && hipStreamWaitEvent(hook->comm, w.ev_gdone[i], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
     hook->cb(hook->user, (int64_t)off, (int64_t)numel);
   };
   auto layer_numel = [&](int first_kind, int last_kind, int layer) {
@@ -546,6 +629,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   Bwd B{Ln, c, w, D};
   const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
   const bool saved = xt.base != nullptr;   // the normalised inputs are only recomputed for their weight-gradient products
+  const bool bf16 = c->precision == RPR_PREC_BF16;   // ReLU backward folded into the conversion of its result (dxdw)
   auto g = [&](int kind, int layer = -1) { return G + param_offset(m, kind, layer); };
   float *dxa = P<float>(w.dxa), *dxb = P<float>(w.dxb), *dbig = P<float>(w.dbig), *dattn = P<float>(w.dattn), *h = P<float>(w.h);
   unsigned long long* fix = P<unsigned long long>(w.fix);
@@ -566,9 +650,9 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     DecAct a = dec_act(w, D, i);
     // feed-forward: x3 = x2 + relu(norm(x2) Wi^T) Wo^T
     B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff, xt.dec(i, XT_WO));
-    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
+    if (!bf16) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
     if (!saved) B.norm(a.x2, m->dec_ln2[i], R);
-    B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm, xt.dec(i, XT_WI));     // dh into the (now free) h buffer
+    B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm, xt.dec(i, XT_WI), bf16 ? a.ff : nullptr);     // dh into the (now free) h buffer
     B.norm_bwd(a.x2, m->dec_ln2[i], h, dx, dx2, g(K_DEC_LN2, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x2
     // cross-attention: x2 = x1 + CrossAttn(norm(x1) Wq^T, Kx, Vx) Wo^T
@@ -594,6 +678,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.dxdw(dbig, m->dec_qkv[i], h, h, g(K_DEC_QKV, i), R, 3 * inner, dm, xt.dec(i, XT_QKV));
     B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
+    B.flush_group();                                               // the layer's six weight gradients: one launch on the side stream
     { const auto b = layer_numel(K_DEC_LN0, K_DEC_WO, i); bucket(b.first, b.second); }
   }
   // decoder input embeddings: codebook rows and the start embedding
@@ -603,15 +688,16 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   // ---- cross K/V projection and the encoder's final norm
   float* denc = P<float>(w.denc);
   B.dxdw(P<float>(w.dxkv), d.dec_xkv, P<float>(w.enc_out), denc, g(K_XKV), T, D.xld, dm, xt.xkv());
+  B.flush_group();
   float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
   B.norm_bwd(xe_last, d.enc_final_ln, denc, nullptr, dxa, g(K_ENC_FLN), T);
   dx = dxa; dx2 = dxb;
   for (int i = D.ne - 1; i >= 0; --i) {
     EncAct a = enc_act(w, D, i);
     B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff, xt.enc(i, XT_WO));
-    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
+    if (!bf16) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
     if (!saved) B.norm(a.xm, m->enc_ln1[i], T);
-    B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm, xt.enc(i, XT_WI));
+    B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm, xt.enc(i, XT_WI), bf16 ? a.ff : nullptr);
     B.norm_bwd(a.xm, m->enc_ln1[i], h, dx, dx2, g(K_ENC_LN1, i), T);
     std::swap(dx, dx2);
     B.dxdw(dx, m->enc_o[i], a.attn, dattn, g(K_ENC_O, i), T, dm, inner, xt.enc(i, XT_O));
@@ -623,6 +709,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.dxdw(dbig, m->enc_qkv[i], h, h, g(K_ENC_QKV, i), T, 3 * inner, dm, xt.enc(i, XT_QKV));
     B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
     std::swap(dx, dx2);
+    B.flush_group();
     { const auto b = layer_numel(K_ENC_LN0, K_ENC_WO, i); bucket(b.first, b.second); }
   }
   // token embeddings (the encoder's table is the shared one)
@@ -633,6 +720,12 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     if (w.done_pending[i]) {
       if (hipStreamWaitEvent(s, w.ev_done[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;
       w.done_pending[i] = false;
+    }
+  B.flush_group();
+  for (int i = 0; i < 2; ++i)
+    if (w.gdone_pending[i]) {
+      if (hipStreamWaitEvent(s, w.ev_gdone[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;
+      w.gdone_pending[i] = false;
     }
   bucket(0, param_offset(m, K_ENC_LN0, 0));   // everything in front of the first layer: final only now
 }
@@ -651,6 +744,12 @@ void rpr::free_train_ws(rpr_ctx* c) {
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.wT, &w.w_part, &w.bias_part,
                    &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT, &w.aseg, &w.apref};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  for (int i = 0; i < 2; ++i) {
+    if (w.dyT[i].p) (void)hipFree(w.dyT[i].p);
+    if (w.ev_gfork[i]) (void)hipEventDestroy(w.ev_gfork[i]);
+    if (w.ev_gdone[i]) (void)hipEventDestroy(w.ev_gdone[i]);
+  }
+  if (w.gtab.p) (void)hipFree(w.gtab.p);
   for (int i = 0; i < TrainWs::NSIDE; ++i) {
     if (w.tB[i].p) (void)hipFree(w.tB[i].p);
     if (w.tC[i].p) (void)hipFree(w.tC[i].p);

@@ -653,17 +653,29 @@ hipError_t launch_train_indices(const int32_t* codes, int32_t* in_idx, int32_t* 
   return hipGetLastError();
 }
 
-// out[k] += sum over rows r with sel[r] < 0 of src[r][k], rows in increasing order (gradient of the start embedding)
+// out[k] += sum over rows r with sel[r] < 0 of src[r][k] (gradient of the start embedding). A block owns 16 columns; 16 row
+// groups add their contiguous share of the rows in increasing order, then the 16 group sums are added in group order
+// (deterministic; one thread walking all rows took 480 us of the step)
 __global__ __launch_bounds__(256) void sum_selected_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ sel,
                                                                  float* __restrict__ out, int rows, int d) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= d) return;
+  __shared__ float red[16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + col;
+  const int per = (rows + 15) / 16, r0 = grp * per, r1 = min(rows, r0 + per);
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) if (sel[r] < 0) a += src[(size_t)r * d + k];
-  out[k] += a;
+  if (k < d)
+    for (int r = r0; r < r1; ++r) if (sel[r] < 0) a += src[(size_t)r * d + k];
+  red[grp][col] = a;
+  __syncthreads();
+  if (grp == 0 && k < d) {
+    float t = 0.f;
+#pragma unroll
+    for (int g16 = 0; g16 < 16; ++g16) t += red[g16][col];
+    out[k] += t;
+  }
 }
 hipError_t launch_sum_selected_rows(const float* src, const int32_t* sel, float* out, int rows, int d, hipStream_t s) {
-  hipLaunchKernelGGL(sum_selected_rows_kernel, dim3((d + 255) / 256), dim3(256), 0, s, src, sel, out, rows, d);
+  hipLaunchKernelGGL(sum_selected_rows_kernel, dim3((d + 15) / 16), dim3(256), 0, s, src, sel, out, rows, d);
   return hipGetLastError();
 }
 
@@ -955,9 +967,14 @@ hipError_t launch_to_bf16(const float* x, int R, int C, int ldi, void* out, hipS
   return hipGetLastError();
 }
 
-// 64 x 64 tile through LDS (as split_dyn_T_kernel): transposed out_t[C][Rpad] and, when given, the plain out_p[R][C]
-__global__ __launch_bounds__(256) void to_bf16_T_kernel(const float* __restrict__ x, int R, int C, int ldi, int Rpad,
-                                                         __bf16* __restrict__ out_t, __bf16* __restrict__ out_p) {
+// 64 x 64 tile through LDS (as split_dyn_T_kernel): transposed out_t[C][Rpad] and, when given, the plain out_p[R][C].
+// RELU: x is the gradient w.r.t. a ReLU output and act (same shape and row stride) the stored activation: elements whose
+// activation is not positive convert as zero — the ReLU backward of the feed-forward block folded into the conversion of
+// its result (the fp32 gradient itself is not read again in bf16 mode), one pass over x less per feed-forward block.
+template <bool RELU>
+__global__ __launch_bounds__(256) void to_bf16_T_kernel(const float* __restrict__ x, int R, int C, int ldi, int Rpad, int ldt,
+                                                         __bf16* __restrict__ out_t, __bf16* __restrict__ out_p,
+                                                         const float* __restrict__ act) {
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
 #pragma unroll
@@ -966,6 +983,10 @@ __global__ __launch_bounds__(256) void to_bf16_T_kernel(const float* __restrict_
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + r < R && c0 + c < C) {
       v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ldi + c0 + c);
+      if (RELU) {
+        const float4 a = *reinterpret_cast<const float4*>(act + (size_t)(r0 + r) * ldi + c0 + c);
+        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+      }
       if (out_p) {
         __bf16 b[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         *reinterpret_cast<uint2*>(out_p + (size_t)(r0 + r) * C + c0 + c) = *reinterpret_cast<uint2*>(b);
@@ -979,15 +1000,23 @@ __global__ __launch_bounds__(256) void to_bf16_T_kernel(const float* __restrict_
     const int c = (tid >> 5) + 8 * k, r = (tid & 31) * 2;        // Rpad % 2 == 0
     if (c0 + c < C && r0 + r < Rpad) {
       __bf16 b[2] = {(__bf16)tile[r][c], (__bf16)tile[r + 1][c]};
-      *reinterpret_cast<unsigned int*>(out_t + (size_t)(c0 + c) * Rpad + r0 + r) = *reinterpret_cast<unsigned int*>(b);
+      *reinterpret_cast<unsigned int*>(out_t + (size_t)(c0 + c) * ldt + r0 + r) = *reinterpret_cast<unsigned int*>(b);
     }
   }
 }
-hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s) {
+// ldt: row stride of out_t in elements (0 = Rpad); see ldT() in train_api.hip.
+hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, void* out_t, void* out_plain, hipStream_t s,
+                            const float* relu_act, int ldt) {
   if (R <= 0 || C <= 0) return hipSuccess;
-  if ((C & 3) || (ldi & 3) || (Rpad & 1)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(to_bf16_T_kernel, dim3((C + 63) / 64, (Rpad + 63) / 64), dim3(256), 0, s, x, R, C, ldi, Rpad,
-                     reinterpret_cast<__bf16*>(out_t), reinterpret_cast<__bf16*>(out_plain));
+  if (ldt == 0) ldt = Rpad;
+  if ((C & 3) || (ldi & 3) || (Rpad & 1) || (ldt & 1) || ldt < Rpad) return hipErrorInvalidValue;
+  const dim3 grid((C + 63) / 64, (Rpad + 63) / 64);
+  if (relu_act)
+    hipLaunchKernelGGL(to_bf16_T_kernel<true>, grid, dim3(256), 0, s, x, R, C, ldi, Rpad, ldt, reinterpret_cast<__bf16*>(out_t),
+                       reinterpret_cast<__bf16*>(out_plain), relu_act);
+  else
+    hipLaunchKernelGGL(to_bf16_T_kernel<false>, grid, dim3(256), 0, s, x, R, C, ldi, Rpad, ldt, reinterpret_cast<__bf16*>(out_t),
+                       reinterpret_cast<__bf16*>(out_plain), relu_act);
   return hipGetLastError();
 }
 
