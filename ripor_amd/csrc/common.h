@@ -204,8 +204,16 @@ struct EncAttnArgs {
   unsigned int* sat;       // sticky saturation word (planes output)
   int causal;              // teacher-forced decoder self-attention (rpr_train_forward): key j <= query i only,
                            //   bucket table indexed by i - j (unidirectional)
+  int mfma;                // 1: sequences of <= 32 padded positions with fp32 output may take the fp32-MFMA kernel (training
+                           //   forward; the search encoder keeps the summation order of enc_attn_kernel)
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
+// training forward, Lq <= 32, padded layout, fp32 output: one wave per (sequence, head) on fp32 MFMA tiles (tail_kernels.hip)
+hipError_t launch_train_self_attn_mfma(const EncAttnArgs& a, hipStream_t s);
+// its backward (Ls <= 32): dqkv and the per-(sequence, head) bias-gradient parts, as self_attn_bwd_kernel writes them
+hipError_t launch_train_self_attn_bwd_mfma(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias,
+                                           const int32_t* bucket, float* dqkv, float* dbias_part, int S, int Ls, int H, int buckets,
+                                           int causal, hipStream_t s);
 
 struct DecSelfAttnArgs {
   const float* q;          // [R, inner]
@@ -414,6 +422,9 @@ struct WSeg { const float* src; int R, C; unsigned long long off; };
 hipError_t launch_weights_bf16(const WSeg* segs, const int* pref, int nseg, int ntiles, void* plain, void* tr, hipStream_t s);
 hipError_t launch_transpose_pad(const float* in, float* out, int R, int C, int ldi, int Rpad, hipStream_t s);
 hipError_t launch_relu_bwd(float* dy, const float* act, size_t n, hipStream_t s);
+// bf16 mode: RMSNorm written as the plain bf16 rows [rows][d] and their transposed copy [d][ldt] (columns rows .. Rpad zero)
+hipError_t launch_rmsnorm_bf16_T(const float* x, const float* w, int rows, int d, float eps, float post, void* out_plain, void* out_t,
+                                 int Rpad, int ldt, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
                               float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s);
 size_t self_attn_bwd_smem(int Ls, int buckets);

@@ -527,6 +527,238 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Self-attention of the training forward (teacher-forced decoder: causal, bias by distance i - j; encoder: key padding
+// mask, bidirectional bias by j - i) for sequences of at most 32 positions, on the same fp32-MFMA tiles: one wave per
+// (sequence, head), all keys in one tile. qkv [S * Ls, 3 inner] -> out [S * Ls, inner] (fp32). The block-per-head VALU kernel
+// (enc_attn_kernel) spends 64 readlane + 64 LDS reads + 64 FMAs per query row with half of the lanes idle at 32 keys:
+// 61 us per layer of 256 sequences x 12 heads, issue-bound; here a head is 64 MFMAs.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void train_self_attn_mfma_kernel(EncAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, Ls = a.Lq, inner = H * DKV, ld = 3 * inner;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+  const int w = blockIdx.x * 4 + wave;
+  const int seq = w / H, h = w - seq * H;
+  if (seq >= a.Q) return;                               // wave-uniform
+  float* Vs = smem + (size_t)wave * (32 * 64 + 64);
+  float* Bs = Vs + 32 * 64;
+  const float* base = a.qkv + (size_t)seq * Ls * ld + h * DKV;
+  {  // V rows -> LDS, four coalesced 256-B rows per instruction; rows past Ls are zero (0 * garbage must stay 0)
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int j = it * 4 + g;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < Ls) v = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * inner + li * 4);
+      *reinterpret_cast<float4*>(Vs + j * 64 + li * 4) = v;
+    }
+  }
+  // bias per key offset: causal n = i - j in [0, Ls); bidirectional j - i + Ls - 1 in [0, 2 Ls - 1)
+  if (lane < (CAUSAL ? Ls : 2 * Ls - 1)) Bs[lane] = a.rel_bias[a.bucket[CAUSAL ? lane : lane - (Ls - 1) + (MAX_LQ - 1)] * H + h];
+  const int n = lane & 31;
+  const bool kok = n < Ls && (CAUSAL || a.mask[(size_t)seq * Ls + n] != 0);
+  float4 kreg[8], qreg[8];
+  load_row_pieces(n < Ls ? base + (size_t)n * ld + inner : nullptr, half, kreg);
+  load_row_pieces(n < Ls ? base + (size_t)n * ld : nullptr, half, qreg);
+  __builtin_amdgcn_wave_barrier();
+  f32x16 s[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
+  mfma_scores(kreg, qreg, s[0]);
+  const unsigned long long okm = __ballot(kok) & 0xffffffffull;   // bit j: key j is attended
+  const int iq = n < Ls ? n : Ls - 1;                    // rows past Ls are computed on clamped indices and never stored
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = kappa(r, half);
+    const bool ok = ((okm >> j) & 1ull) && (!CAUSAL || j <= iq);
+    const int bi = CAUSAL ? iq - j : j - iq + Ls - 1;
+    s[0][r] = ok ? s[0][r] + Bs[ok ? bi : 0] : -INFINITY;
+  }
+  softmax_rows<1>(s);
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  mfma_pv<1>(s, Vs, lane, o);
+  store_o_tile(o, Vs, lane, 0, Ls, (size_t)seq * Ls, inner, h * DKV, a.out, nullptr, 0, nullptr);
+}
+
+hipError_t launch_train_self_attn_mfma(const EncAttnArgs& a, hipStream_t s) {
+  if (a.Lq > 32 || a.Lq < 1 || a.offs || a.out_h || a.buckets > 64) return hipErrorInvalidValue;
+  const long waves = (long)a.Q * a.H;
+  const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  const size_t smem = 4 * (32 * 64 + 64) * sizeof(float);
+  if (a.causal) hipLaunchKernelGGL(train_self_attn_mfma_kernel<true>, grid, blk, smem, s, a);
+  else hipLaunchKernelGGL(train_self_attn_mfma_kernel<false>, grid, blk, smem, s, a);
+  return hipGetLastError();
+}
+
+// Backward of the same attention (reference: autograd through T5Attention inside loss.backward(), tasks/trainer.py:203-275)
+// for sequences of at most 32 positions: one wave per (sequence, head), seven 32 x 32 (x 64) products on the fp32 matrix
+// cores. With P = softmax(S), S = Q K^T + bias, O = P V:
+//   dP = dO V^T,  dS = P * (dP - rowsum(dP * P)),  dQ = dS K,  dK = dS^T Q,  dV = P^T dO,  dbias[bucket] += diagonals of dS.
+// dQ wants dS with a lane per QUERY (its A operand's row), dK and dV want dS and P with a lane per KEY: both layouts are
+// computed by the matrix cores — S^T = K Q^T and dP^T = V dO^T put a query in a lane (as the forward kernel), S = Q K^T and
+// dP = dO V^T a key — and the per-query softmax statistics (maximum, 1 / sum, rowsum(dP * P)) found in the first layout are
+// passed to the second through 96 floats of LDS; two more score products cost 64 MFMAs, a transposition of P and dS
+// through LDS would cost 64 LDS accesses per lane and two more strips. K, Q and dO are staged row-major in LDS as the B
+// operands of dQ / dK / dV (each strip then serves as the transposition scratch of its own product's output tile); the
+// VALU kernel (self_attn_bwd_kernel, any length) took 75 us per layer of 256 sequences x 12 heads.
+template <bool CAUSAL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void train_self_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                                        const int32_t* __restrict__ mask,
+                                                                        const float* __restrict__ rel_bias,
+                                                                        const int32_t* __restrict__ bucket, float* __restrict__ dqkv,
+                                                                        float* __restrict__ dbias_part, int S, int Ls, int H, int buckets) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WAVE_FLOATS = 3 * 32 * 64 + 64 + 96 + 64 + 64;
+  const int inner = H * DKV, ld = 3 * inner;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
+  const int w = blockIdx.x * 2 + wave;
+  const int seq = w / H, h = w - seq * H;
+  if (seq >= S) return;                                 // wave-uniform
+  float* Ks = smem + (size_t)wave * WAVE_FLOATS;
+  float* Qs = Ks + 32 * 64;
+  float* Ds = Qs + 32 * 64;
+  float* Bs = Ds + 32 * 64;          // [64] bias per key offset
+  float* st = Bs + 64;               // [3][32] per query: row maximum, 1 / row sum, rowsum(dP * P)
+  float* diag = st + 96;             // [64] sum of dS along each diagonal
+  int* bk = reinterpret_cast<int*>(diag + 64);   // [64] bucket of each diagonal
+  const float* base = qkv + (size_t)seq * Ls * ld + h * DKV;
+  const float* dob = dO + (size_t)seq * Ls * inner + h * DKV;
+  {  // K, Q, dO rows -> LDS, four coalesced 256-B rows per instruction; rows past Ls are zero
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int j = it * 4 + g;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), qv = kv, dv = kv;
+      if (j < Ls) {
+        kv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + inner + li * 4);
+        qv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + li * 4);
+        dv = *reinterpret_cast<const float4*>(dob + (size_t)j * inner + li * 4);
+      }
+      *reinterpret_cast<float4*>(Ks + j * 64 + li * 4) = kv;
+      *reinterpret_cast<float4*>(Qs + j * 64 + li * 4) = qv;
+      *reinterpret_cast<float4*>(Ds + j * 64 + li * 4) = dv;
+    }
+  }
+  // diagonal t: causal i - j = t; bidirectional j - i = t - (Ls - 1)
+  const int nd = CAUSAL ? Ls : 2 * Ls - 1;
+  if (lane < nd) {
+    const int b = bucket[CAUSAL ? lane : lane - (Ls - 1) + (MAX_LQ - 1)];
+    bk[lane] = b;
+    Bs[lane] = rel_bias[b * H + h];
+  }
+  const bool kok = n < Ls && (CAUSAL || mask[(size_t)seq * Ls + n] != 0);
+  // row pieces of the score products: V from global memory; K, Q, dO from their LDS strips (rows past Ls are zero there).
+  // Four sets of 32-byte pieces from global memory were 1024 cache-line requests per wave (32 rows per instruction) and made
+  // this kernel as slow as the VALU one (76 us); the strip reads all fall on the same banks (row stride 256 B) and still
+  // cost only ~64 cycles each.
+  float4 kreg[8], qreg[8], vreg[8], greg[8];
+  load_row_pieces(n < Ls ? base + (size_t)n * ld + 2 * inner : nullptr, half, vreg);
+  __builtin_amdgcn_wave_barrier();
+  load_row_pieces(Ks + n * 64, half, kreg);
+  load_row_pieces(Qs + n * 64, half, qreg);
+  load_row_pieces(Ds + n * 64, half, greg);
+  const unsigned long long okm = __ballot(kok) & 0xffffffffull;   // bit j: key j is attended
+  const int iq = n < Ls ? n : Ls - 1;                    // rows past Ls run on clamped indices and are never stored
+
+  // ---- a lane per query: P^T, dS^T (registers = keys kappa(r, half)) ----------------------------------------------
+  f32x16 p1[1], ds1[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { p1[0][r] = 0.f; ds1[0][r] = 0.f; }
+  mfma_scores(kreg, qreg, p1[0]);                        // S^T[key][query]
+  // the two products of the second layout (a lane per key) are issued here as well: the row pieces die early
+  f32x16 p2[1], ds2[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { p2[0][r] = 0.f; ds2[0][r] = 0.f; }
+  mfma_scores(qreg, kreg, p2[0]);                        // S[query][key]
+  mfma_scores(vreg, greg, ds1[0]);                       // dP^T[key][query]
+  mfma_scores(greg, vreg, ds2[0]);                       // dP[query][key]
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = kappa(r, half);
+    const bool ok = ((okm >> j) & 1ull) && (!CAUSAL || j <= iq);
+    const int bi = CAUSAL ? iq - j : j - iq + Ls - 1;
+    p1[0][r] = ok ? p1[0][r] + Bs[ok ? bi : 0] : -INFINITY;
+    mx = fmaxf(mx, p1[0][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = (p1[0][r] == -INFINITY) ? 0.f : expf(p1[0][r] - mx);
+    p1[0][r] = e;
+    sum += e;
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  float cq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { p1[0][r] *= inv; cq = fmaf(ds1[0][r], p1[0][r], cq); }
+  cq += __shfl_xor(cq, 32, 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ds1[0][r] = p1[0][r] * (ds1[0][r] - cq);
+  if (half == 0) { st[n] = mx; st[32 + n] = inv; st[64 + n] = cq; }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  mfma_pv<1>(ds1, Ks, lane, o);                          // dQ[query][d] = sum_key dS[query][key] K[key][d]
+  store_o_tile(o, Ks, lane, 0, Ls, (size_t)seq * Ls, ld, h * DKV, dqkv, nullptr, 0, nullptr);
+  // dS[i][j] -> the (now free) K strip for the diagonal sums
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ks[n * 33 + kappa(r, half)] = ds1[0][r];
+
+  // ---- a lane per key: P, dS (registers = queries kappa(r, half)) ---------------------------------------------------
+  __builtin_amdgcn_wave_barrier();                       // st[] written above
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = kappa(r, half);
+    const bool ok = kok && i < Ls && (!CAUSAL || n <= i);
+    const int bi = CAUSAL ? i - n : n - i + Ls - 1;
+    const float pe = ok ? expf(p2[0][r] + Bs[ok ? bi : 0] - st[i]) * st[32 + i] : 0.f;
+    p2[0][r] = pe;
+    ds2[0][r] = ok ? pe * (ds2[0][r] - st[64 + i]) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  mfma_pv<1>(ds2, Qs, lane, o);                          // dK[key][d] = sum_query dS[query][key] Q[query][d]
+  store_o_tile(o, Qs, lane, 0, Ls, (size_t)seq * Ls, ld, inner + h * DKV, dqkv, nullptr, 0, nullptr);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  mfma_pv<1>(p2, Ds, lane, o);                           // dV[key][d] = sum_query P[query][key] dO[query][d]
+  store_o_tile(o, Ds, lane, 0, Ls, (size_t)seq * Ls, ld, 2 * inner + h * DKV, dqkv, nullptr, 0, nullptr);
+
+  // ---- bias gradient of this (sequence, head): every diagonal of dS in row order, then the diagonals of a bucket in order
+  // (the order of self_attn_bwd_kernel)
+  if (lane < nd) {
+    const int off = CAUSAL ? -lane : lane - (Ls - 1);    // j - i
+    float acc = 0.f;
+    for (int i = 0; i < Ls; ++i) { const int j = i + off; if (j >= 0 && j < Ls) acc += Ks[i * 33 + j]; }
+    diag[lane] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < buckets) {
+    float acc = 0.f;
+    for (int t = 0; t < nd; ++t) if (bk[t] == lane) acc += diag[t];
+    dbias_part[((size_t)seq * H + h) * buckets + lane] = acc;
+  }
+}
+
+hipError_t launch_train_self_attn_bwd_mfma(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias,
+                                           const int32_t* bucket, float* dqkv, float* dbias_part, int S, int Ls, int H, int buckets,
+                                           int causal, hipStream_t s) {
+  if (Ls > 32 || Ls < 1 || buckets > 64) return hipErrorInvalidValue;
+  const long waves = (long)S * H;
+  const dim3 grid((unsigned)((waves + 1) / 2)), blk(128);
+  const size_t smem = 2 * (3 * 32 * 64 + 64 + 96 + 64 + 64) * sizeof(float);
+  if (causal) hipLaunchKernelGGL(train_self_attn_bwd_mfma_kernel<true>, grid, blk, smem, s, qkv, dO, mask, rel_bias, bucket, dqkv,
+                                 dbias_part, S, Ls, H, buckets);
+  else hipLaunchKernelGGL(train_self_attn_bwd_mfma_kernel<false>, grid, blk, smem, s, qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part,
+                          S, Ls, H, buckets);
+  return hipGetLastError();
+}
+
 static size_t tail_self_attn_smem(int L) { return ((size_t)L * 65 + (size_t)L * 64 + 4 * 64 + 64) * sizeof(float); }
 
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {

@@ -331,7 +331,8 @@ struct Bwd {
   // enqueue the products collected since the last flush on the side stream; the main stream goes on
   void flush_group() {
     if (w.grp.n == 0 || Ln.err) return;
-    hipStream_t s = Ln.s, side = w.side[0];
+    static const bool side_on = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();   // 0: in line on the main stream (diagnostic)
+    hipStream_t s = Ln.s, side = side_on ? w.side[0] : Ln.s;
     const int gs = w.gset;
     if (hipEventRecord(w.ev_gfork[gs], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_gfork[gs], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
     Launcher L2{c, side};
@@ -539,6 +540,21 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
     Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * dm, [&] { return launch_rmsnorm(x, ln, out, rows, dm, D.eps, s, post); });
   };
   const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
+  // out = act(norm(x) W^T): in bf16 mode the norm writes the product's bf16 operand and its transposed copy itself
+  // (rmsnorm_bf16_T_kernel); otherwise norm into h, then gemm() converts. RPR_TRAIN_NORM_FUSE=0: the two-kernel route.
+  static const bool norm_fuse = [] { const char* e = getenv("RPR_TRAIN_NORM_FUSE"); return !(e && atoi(e) == 0); }();
+  auto norm_gemm = [&](const float* x, const float* ln, const float* W, float* C, int rows, int N, int relu, void* save_xt) {
+    auto it = w.wc_off.find(W);
+    if (norm_fuse && c->precision == RPR_PREC_BF16 && save_xt && it != w.wc_off.end() && w.wc.p && dm <= 1024 && (dm & 63) == 0) {
+      Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * dm, [&] {
+        return launch_rmsnorm_bf16_T(x, ln, rows, dm, D.eps, 1.0f, w.tA.p, save_xt, pad64(rows), ldT(rows), s);
+      });
+      gemm_bf16(Ln, w.tA.p, dm, reinterpret_cast<const __half*>(w.wc.p) + it->second, dm, C, N, rows, N, dm, nullptr, relu);
+      return;
+    }
+    norm(x, ln, h, rows);
+    gemm(Ln, h, dm, W, dm, C, N, rows, N, dm, nullptr, relu, save_xt);
+  };
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(mask, last, D.bz, D.Lq, s, c->status + 1); });
   // ---- encoder over the padded [bz, Lq] layout (padded positions get no gradient: nothing downstream reads them)
   float* xe_last = P<float>(w.enc_act) + (size_t)D.ne * D.enc_stride;
@@ -546,14 +562,12 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   for (int i = 0; i < D.ne; ++i) {
     EncAct a = enc_act(w, D, i);
     float* xnext = i + 1 < D.ne ? enc_act(w, D, i + 1).x : xe_last;
-    norm(a.x, m->enc_ln0[i], h, T);
-    gemm(Ln, h, dm, m->enc_qkv[i], dm, a.qkv, 3 * inner, T, 3 * inner, dm, nullptr, 0, xt.enc(i, XT_QKV));
+    norm_gemm(a.x, m->enc_ln0[i], m->enc_qkv[i], a.qkv, T, 3 * inner, 0, xt.enc(i, XT_QKV));
     EncAttnArgs ea{a.qkv, mask, d.enc_rel_bias, m->enc_bucket, a.attn, D.bz, D.Lq, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
-                   nullptr, 0};
+                   nullptr, 0, 1};
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(ea, s); });
     gemm(Ln, a.attn, inner, m->enc_o[i], inner, a.xm, dm, T, dm, inner, a.x, 0, xt.enc(i, XT_O));
-    norm(a.xm, m->enc_ln1[i], h, T);
-    gemm(Ln, h, dm, m->enc_wi[i], dm, a.ff, dff, T, dff, dm, nullptr, 1, xt.enc(i, XT_WI));
+    norm_gemm(a.xm, m->enc_ln1[i], m->enc_wi[i], a.ff, T, dff, 1, xt.enc(i, XT_WI));
     gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm, 0, xt.enc(i, XT_WO));
   }
   norm(xe_last, d.enc_final_ln, P<float>(w.enc_out), T);
@@ -564,20 +578,18 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   for (int i = 0; i < D.nd; ++i) {
     DecAct a = dec_act(w, D, i);
     float* xnext = i + 1 < D.nd ? dec_act(w, D, i + 1).x0 : P<float>(w.x_last);
-    norm(a.x0, m->dec_ln0[i], h, R);
-    gemm(Ln, h, dm, m->dec_qkv[i], dm, a.qkv, 3 * inner, R, 3 * inner, dm, nullptr, 0, xt.dec(i, XT_QKV));
+    norm_gemm(a.x0, m->dec_ln0[i], m->dec_qkv[i], a.qkv, R, 3 * inner, 0, xt.dec(i, XT_QKV));
     EncAttnArgs sa{a.qkv, nullptr, d.dec_rel_bias, m->dec_bucket, a.a0, D.S, D.L, D.H, d.rel_buckets, nullptr, 0, nullptr, nullptr,
-                   nullptr, 1};
+                   nullptr, 1, 1};
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(sa, s); });
     gemm(Ln, a.a0, inner, m->dec_o[i], inner, a.x1, dm, R, dm, inner, a.x0, 0, xt.dec(i, XT_O));
-    norm(a.x1, m->dec_ln1[i], h, R);
-    gemm(Ln, h, dm, m->dec_xq[i], dm, a.qx, inner, R, inner, dm, nullptr, 0, xt.dec(i, XT_XQ));
+    norm_gemm(a.x1, m->dec_ln1[i], m->dec_xq[i], a.qx, R, inner, 0, xt.dec(i, XT_XQ));
     const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
     DecCrossAttnArgs ca{a.qx, xk, xk + inner, D.xld, mask, a.a1, D.bz, 2 * D.L, D.H, D.Lq, nullptr, 0, last, nullptr, 0, nullptr};
-    Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] { return launch_dec_cross_attn(ca, s); });
+    // (the query's 2 L decoder rows as 32-row tiles on the fp32-MFMA kernel of the search tail when Lq <= 64)
+    Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] { return launch_tail_cross_attn(ca, s); });
     gemm(Ln, a.a1, inner, m->dec_xo[i], inner, a.x2, dm, R, dm, inner, a.x1, 0, xt.dec(i, XT_XO));
-    norm(a.x2, m->dec_ln2[i], h, R);
-    gemm(Ln, h, dm, m->dec_wi[i], dm, a.ff, dff, R, dff, dm, nullptr, 1, xt.dec(i, XT_WI));
+    norm_gemm(a.x2, m->dec_ln2[i], m->dec_wi[i], a.ff, R, dff, 1, xt.dec(i, XT_WI));
     gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2, 0, xt.dec(i, XT_WO));
   }
   Ln.run(RPR_K_OTHER, 0, 0, [&] {

@@ -530,6 +530,11 @@ hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t
                                 hipStream_t s) {
   const size_t smem = self_attn_bwd_smem(Ls, buckets);
   if (smem > 160 * 1024 || buckets > 64) return hipErrorInvalidValue;
+  static const bool mfma_off = [] { const char* e = getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  if (Ls <= 32 && !mfma_off) {   // one wave per (sequence, head) on the fp32 matrix cores (tail_kernels.hip)
+    const hipError_t e = launch_train_self_attn_bwd_mfma(qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part, S, Ls, H, buckets, causal, s);
+    if (e != hipSuccess) return e;
+  } else
   hipLaunchKernelGGL(self_attn_bwd_kernel, dim3(S * H), dim3(256), smem, s, qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part, S, Ls,
                      H, buckets, causal);
   hipLaunchKernelGGL(bias_reduce_kernel, dim3(H), dim3(512), 0, s, dbias_part, dbias, S, H, buckets);
@@ -737,8 +742,18 @@ hipError_t launch_gold_score_bwd(const float* x, const float* ln, const float* o
 // sum of squares of a flat buffer: block partials in double, then one block adds them in order (deterministic)
 __global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, size_t n, double* __restrict__ part) {
   __shared__ double red[256];
-  double a = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += (double)g[i] * (double)g[i];
+  // 16-byte loads (the flat gradient buffer is 16-byte aligned), four independent double accumulators per thread; the
+  // n % 4 trailing elements go to the last thread of the grid. (One 4-byte load per iteration ran at 2.2 TB/s.)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const size_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = g4[i];
+    a0 += (double)v.x * (double)v.x; a1 += (double)v.y * (double)v.y; a2 += (double)v.z * (double)v.z; a3 += (double)v.w * (double)v.w;
+  }
+  double a = (a0 + a1) + (a2 + a3);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255)
+    for (size_t i = n4 << 2; i < n; ++i) a += (double)g[i] * (double)g[i];
   red[threadIdx.x] = a;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -1020,6 +1035,86 @@ hipError_t launch_to_bf16_T(const float* x, int R, int C, int ldi, int Rpad, voi
   return hipGetLastError();
 }
 
+// RMSNorm of the training forward in bf16 mode, written straight in the two operand formats of the layer's products: the
+// plain bf16 rows [rows][d] (A operand of the forward GEMM) and the transposed copy [d][ldt] (X^T operand of the weight
+// gradient), columns rows .. Rpad of the latter zero. Replaces rmsnorm_kernel (fp32 out) + to_bf16_T_kernel (fp32 in): one
+// read of x instead of a write and a read of the normalised fp32 rows in between. A block owns 32 rows (8 waves x 4 rows,
+// all of a wave's loads requested up front); the transposed copy goes through a bf16 tile in LDS and leaves as 64-byte
+// row pieces (two columns per thread). Arithmetic as rmsnorm_kernel: w * (x * rsqrt(mean(x^2) + eps)) (* post). d <= 1024.
+__global__ __launch_bounds__(512) void rmsnorm_bf16_T_kernel(const float* __restrict__ x, const float* __restrict__ w, int rows, int d,
+                                                              float eps, float post, __bf16* __restrict__ out_p,
+                                                              __bf16* __restrict__ out_t, int Rpad, int ldt) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 nt_tile[];   // [32][d + 4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n4 = d >> 2, tld = d + 4;
+  const int r0 = blockIdx.x * 32;
+  constexpr int NV = 4, NR = 4;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  float4 xv[NR][NV];
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    const int row = r0 + wave * NR + rr;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(row < rows ? row : 0) * d);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k;
+      xv[rr][k] = (row < rows && i < n4) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 wv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; wv[k] = i < n4 ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    const int lr = wave * NR + rr, row = r0 + lr;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { const float4 v = xv[rr][k]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    ss = wave_sum_f(ss);
+    const float rs = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < n4) {
+        const float4 v = xv[rr][k], g = wv[k];
+        float4 o = make_float4(g.x * (v.x * rs), g.y * (v.y * rs), g.z * (v.z * rs), g.w * (v.w * rs));
+        if (post != 1.0f) { o.x *= post; o.y *= post; o.z *= post; o.w *= post; }
+        if (row >= rows) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        __bf16 b[4] = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+        if (row < rows) *reinterpret_cast<uint2*>(out_p + (size_t)row * d + 4 * i) = *reinterpret_cast<uint2*>(b);
+        *reinterpret_cast<uint2*>(nt_tile + lr * tld + 4 * i) = *reinterpret_cast<uint2*>(b);
+      }
+    }
+  }
+  __syncthreads();
+  // columns (c, c + 1) of the tile -> 32 consecutive row entries of out_t[c] and out_t[c + 1]
+  for (int c = 2 * threadIdx.x; c < d; c += 2 * 512) {
+    unsigned int lo[16], hi[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const unsigned int a = *reinterpret_cast<const unsigned int*>(nt_tile + (2 * p) * tld + c);
+      const unsigned int b = *reinterpret_cast<const unsigned int*>(nt_tile + (2 * p + 1) * tld + c);
+      lo[p] = (a & 0xffffu) | (b << 16);       // rows 2p, 2p + 1 of column c
+      hi[p] = (a >> 16) | (b & 0xffff0000u);   // ... of column c + 1
+    }
+    uint4* d0 = reinterpret_cast<uint4*>(out_t + (size_t)c * ldt + r0);
+    uint4* d1 = reinterpret_cast<uint4*>(out_t + (size_t)(c + 1) * ldt + r0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      d0[q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+      d1[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+    }
+  }
+}
+hipError_t launch_rmsnorm_bf16_T(const float* x, const float* w, int rows, int d, float eps, float post, void* out_plain, void* out_t,
+                                 int Rpad, int ldt, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (d > 1024 || (d & 7) || (Rpad & 31) || (ldt & 7) || ldt < Rpad || Rpad < rows) return hipErrorInvalidValue;
+  const size_t smem = (size_t)32 * (d + 4) * sizeof(__bf16);
+  hipLaunchKernelGGL(rmsnorm_bf16_T_kernel, dim3(Rpad / 32), dim3(512), smem, s, x, w, rows, d, eps, post,
+                     reinterpret_cast<__bf16*>(out_plain), reinterpret_cast<__bf16*>(out_t), Rpad, ldt);
+  return hipGetLastError();
+}
+
 // Every GEMM weight of the model in one launch: plain bf16 copy [N][K] (forward operand) and transposed copy [K][N]
 // (operand of the input-gradient product), both at the tensor's offset in the flat parameter layout. Block -> tensor by
 // binary search over the prefix sums of the tensors' 64 x 64 tile counts.
@@ -1067,6 +1162,8 @@ hipError_t launch_weights_bf16(const WSeg* segs, const int* pref, int nseg, int 
 
 hipError_t init_train_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(self_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bf16_T_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
