@@ -376,6 +376,14 @@ int64_t rpr_workspace_bytes(const rpr_ctx* ctx);
 /* C[M,N] = act(A[M,K] @ W[N,K]^T) (+ residual[M,N]); fp32 MFMA. K % 32 == 0, N % 32 == 0. */
 int rpr_op_linear(rpr_ctx* ctx, const float* A, const float* W, const float* residual, float* C,
                   int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
+/* The bf16 GEMM kernels of the fine-tune step (RPR_PREC_BF16; row f4), as a kernel-level parity hook: operands rounded to
+ * bf16, one bf16 MFMA per product, fp32 accumulation. n_products = 0: C[M,N] = act(A W^T) (+ residual) through the step's
+ * own kernel choice (128-row LDS-DMA tiles, 256x256 ping-pong tiles, split-K for long reductions into few tiles).
+ * n_products = 1..8: the grouped launch of the weight-gradient products (gemm_h2_pp_group_kernel, one K-loop per tile):
+ * product i = rows [0, M - 256 i) of A against W, written to C + i * M * N (row stride N); residual and relu must be 0.
+ * K % 64 == 0. Reference arithmetic: torch bf16 autocast matmul with fp32 accumulation (tasks/trainer.py:229). */
+int rpr_op_linear_bf16(rpr_ctx* ctx, const float* A, const float* W, const float* residual, float* C,
+                       int32_t M, int32_t N, int32_t K, int32_t relu, int32_t n_products, void* stream);
 /* out[rows,d] = w * x * rsqrt(mean(x^2) + eps) */
 int rpr_op_rmsnorm(rpr_ctx* ctx, const float* x, const float* w, float* out, int32_t rows, int32_t d,
                    float eps, void* stream);

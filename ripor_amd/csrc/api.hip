@@ -1556,6 +1556,44 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   return Ln.err;
 }
 
+int rpr_op_linear_bf16(rpr_ctx* c, const float* A, const float* W, const float* residual, float* C, int32_t M, int32_t N, int32_t K,
+                       int32_t relu, int32_t n_products, void* stream) {
+  RPR_REQUIRE(c && A && W && C, "NULL argument");
+  RPR_REQUIRE(M >= 1 && N >= 1 && K >= 64 && K % 64 == 0, "bad GEMM shape (K must be a multiple of 64)");
+  RPR_REQUIRE(n_products >= 0 && n_products <= GemmGroupArgs::MAXP, "n_products out of range");
+  RPR_REQUIRE(n_products == 0 || (!residual && !relu && (N & 3) == 0), "the grouped launch has no fused extras");
+  RPR_HIP(hipSetDevice(c->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DevTmp At, Wt, part, tab;
+  RPR_HIP(At.alloc((size_t)M * K * sizeof(__half)));
+  RPR_HIP(Wt.alloc((size_t)N * K * sizeof(__half)));
+  RPR_HIP(launch_to_bf16(A, M, K, K, At.p, s));
+  RPR_HIP(launch_to_bf16(W, N, K, K, Wt.p, s));
+  if (n_products == 0) {
+    const size_t part_bytes = (size_t)64 << 20;
+    RPR_HIP(part.alloc(part_bytes));
+    GemmH2Args g{};
+    g.A = At.as<__half>(); g.lda = K; g.W = Wt.as<__half>(); g.ldw = K;
+    g.resid = residual; g.ldr = N;
+    g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = N; g.split_n = N;
+    g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.bf16 = 1;
+    g.part = part.as<float>(); g.part_cap = part_bytes / sizeof(float);
+    RPR_HIP(launch_gemm_h2(g, s));
+  } else {
+    RPR_HIP(tab.alloc(GemmGroupArgs::MAXP * sizeof(GemmH2Args)));
+    GemmGroupArgs p{};
+    p.K = K; p.lda = K; p.ldw = K;
+    for (int i = 0; i < n_products && M - 256 * i > 0; ++i) {
+      p.A[i] = At.as<__half>(); p.W[i] = Wt.as<__half>(); p.out[i] = C + (size_t)i * M * N;
+      p.M[i] = M - 256 * i; p.N[i] = N; p.ldo[i] = N;
+      p.n = i + 1;
+    }
+    RPR_HIP(launch_gemm_h2_group(p, tab.as<GemmH2Args>(), s));
+  }
+  RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
+  return RPR_OK;
+}
+
 int rpr_op_rmsnorm(rpr_ctx* c, const float* x, const float* w, float* out, int32_t rows, int32_t d, float eps,
                    void* stream) {
   RPR_REQUIRE(c && x && w && out, "NULL argument");

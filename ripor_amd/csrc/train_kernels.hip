@@ -608,6 +608,8 @@ hipError_t launch_cross_attn_bwd(const float* q, const float* xk, const float* x
                                  float* dq, float* dxk, float* dxv, int bz, int n, int Lq, int H, hipStream_t s) {
   const size_t smem = cross_attn_bwd_smem(n, Lq);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
+  // (an fp32-MFMA version — one wave per (query, head), dK / dV accumulated over the row tiles in the matrix cores — measured
+  // 91 us against this kernel's 88: one wave per SIMD by its 33 KB of strips; removed)
   hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(bz * H), dim3(256), smem, s, q, xk, xv, xld, mask, dO, dq, dxk, dxv, n, Lq, H);
   return hipGetLastError();
 }

@@ -155,6 +155,23 @@ class Context:
                                      out.data_ptr(), M, N, K, 1 if relu else 0, _stream_ptr(A.device)), "rpr_op_linear")
         return out
 
+    def linear_bf16(self, A: torch.Tensor, W: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = False,
+                    n_products: int = 0):
+        """The bf16 GEMM kernels of the fine-tune step (rpr_op_linear_bf16). n_products = 0: one product through the step's own
+        kernel choice -> [M, N]; n_products >= 1: the grouped weight-gradient launch -> [n_products, M, N] (product i = the
+        first M - 256 i rows of A; the rows behind them stay zero)."""
+        assert A.is_cuda and W.is_cuda and A.dtype == torch.float32 and W.dtype == torch.float32
+        A, W = A.contiguous(), W.contiguous()
+        M, K = A.shape
+        N = W.shape[0]
+        shape = (M, N) if n_products == 0 else (n_products, M, N)
+        out = torch.zeros(shape, dtype=torch.float32, device=A.device)
+        res = residual.contiguous() if residual is not None else None
+        check(self.lib.rpr_op_linear_bf16(self.handle, A.data_ptr(), W.data_ptr(), res.data_ptr() if res is not None else None,
+                                          out.data_ptr(), M, N, K, 1 if relu else 0, n_products, _stream_ptr(A.device)),
+              "rpr_op_linear_bf16")
+        return out
+
     def rmsnorm(self, x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6):
         x, w = x.contiguous(), w.contiguous()
         out = torch.empty_like(x)

@@ -533,3 +533,70 @@ def test_training_loop_schedule_and_checkpoint(tmp_path):
     assert os.path.exists(os.path.join(args.output_dir, "checkpoint", "tokenizer.txt"))
     st = json.load(open(os.path.join(args.output_dir, "checkpoint-4", "trainer_state.json")))
     assert st["global_step"] == 4 and st["warmup_steps"] == 2
+
+
+def _bf16_ref(A, W):
+    """torch's bf16 autocast matmul arithmetic: operands rounded to bf16, products exact, fp32-or-better accumulation."""
+    return A.to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().t()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,relu,resid", [
+    (8192, 3072, 768, True, False),      # 384 tiles of 256 x 256: the persistent ping-pong kernel, 12 K-tiles of 64
+    (8192, 768, 3072, False, True),      # 128 x 128 LDS-DMA tiles, residual
+    (8192, 2304, 768, False, False),     # 288 tiles: a little over one round
+    (768, 768, 8192, False, False),      # weight-gradient shape: 9 tiles, split-K over the 8192 rows + reduce
+    (3072, 768, 4096, False, False),     # 36 tiles, split-K
+    (300, 832, 192, True, True),         # ragged small-tile launch, 3 K-tiles
+    (256, 256, 64, False, False),        # one tile, ONE K-tile (the slice pipeline's shortest loop)
+    (512, 256, 128, False, False),       # two K-tiles
+])
+def test_bf16_gemm_kernels_against_torch_bf16_matmul(M, N, K, relu, resid):
+    """The bf16 GEMM kernels of the fine-tune step (row f4) one by one, through rpr_op_linear_bf16. The only error source
+    besides the operand rounding (which the reference shares) is the fp32 accumulation order."""
+    from ripor_amd import engine as E
+    ctx = E.Context.get(0)
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * K ** -0.5
+    R = torch.randn(M, N, device="cuda") if resid else None
+    out = ctx.linear_bf16(A, W, R, relu)
+    ref = _bf16_ref(A, W)
+    if relu:
+        ref = torch.relu(ref)
+    if resid:
+        ref = ref + R.double()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), (M, N, K, err)
+    again = ctx.linear_bf16(A, W, R, relu)
+    assert torch.equal(out, again), "bf16 GEMM is not repeatable bitwise"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,n", [
+    (3072, 768, 8192, 6),      # a decoder layer's weight gradients: up to 36 tiles per product, 128 K-tiles of 64 rows each
+    (768, 3072, 4096, 3),      # an encoder layer at 4096 packed rows; the third product has 256 rows (12 tiles)
+    (768, 768, 64, 2),         # ONE K-tile
+    (768, 768, 192, 2),        # three K-tiles (odd count: the slice pipeline ends in the second buffer)
+    (600, 200, 256, 2),        # ragged tiles (rows and columns off the 256 grid), second product 344 rows
+])
+def test_bf16_grouped_weight_gradient_launch(M, N, K, n):
+    """gemm_h2_pp_group_kernel: several products in one launch, every tile's whole reduction in one K-loop (the bf16 slice
+    pipeline at its longest), blocks beyond a product's tile count exit. Product i = the first M - 256 i rows of A."""
+    from ripor_amd import engine as E
+    ctx = E.Context.get(0)
+    torch.manual_seed(n * 1000 + K)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * K ** -0.5
+    out = ctx.linear_bf16(A, W, n_products=n)
+    ref = _bf16_ref(A, W)
+    for i in range(n):
+        rows = M - 256 * i
+        if rows <= 0:
+            assert not out[i].any()
+            continue
+        err = (out[i, :rows].double() - ref[:rows]).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (i, rows, err)
+        assert not out[i, rows:].any(), "a product wrote past its rows"
+    again = ctx.linear_bf16(A, W, n_products=n)
+    assert torch.equal(out, again), "grouped bf16 GEMM is not repeatable bitwise"
