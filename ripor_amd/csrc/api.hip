@@ -1580,7 +1580,7 @@ int rpr_op_linear_bf16(rpr_ctx* c, const float* A, const float* W, const float* 
     g.part = part.as<float>(); g.part_cap = part_bytes / sizeof(float);
     RPR_HIP(launch_gemm_h2(g, s));
   } else {
-    RPR_HIP(tab.alloc(GemmGroupArgs::MAXP * sizeof(GemmH2Args)));
+    RPR_HIP(tab.alloc(GemmGroupArgs::SCRATCH_BYTES));
     GemmGroupArgs p{};
     p.K = K; p.lda = K; p.ldw = K;
     for (int i = 0; i < n_products && M - 256 * i > 0; ++i) {
@@ -1588,7 +1588,7 @@ int rpr_op_linear_bf16(rpr_ctx* c, const float* A, const float* W, const float* 
       p.M[i] = M - 256 * i; p.N[i] = N; p.ldo[i] = N;
       p.n = i + 1;
     }
-    RPR_HIP(launch_gemm_h2_group(p, tab.as<GemmH2Args>(), s));
+    RPR_HIP(launch_gemm_h2_group(p, tab.p, s));
   }
   RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
   return RPR_OK;

@@ -146,16 +146,18 @@ __device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, in
 }
 hipError_t launch_gemm_h2(GemmH2Args& a, hipStream_t s);
 // several bf16 products C_i[M_i, N_i] = A_i[M_i, K] W_i[N_i, K]^T (fp32 output, no fused extras) in one launch of the 256x256
-// ping-pong kernel, one K-loop per tile (gemm_h2_pp_group_kernel): the weight gradients of one transformer layer
+// ping-pong kernel, one block and one K-loop per tile (gemm_h2_pp_group_kernel): the weight gradients of one transformer
+// layer. At most MAX_TILES tiles in total (the greedy assignment then stays within 64 per XCD); otherwise hipErrorInvalidValue.
 struct GemmGroupArgs {
-  static constexpr int MAXP = 8;
+  static constexpr int MAXP = 8, MAX_TILES = 384, MAX_BLOCKS = 512;
+  static constexpr size_t TABLE_BYTES = 4096, SCRATCH_BYTES = TABLE_BYTES + MAX_BLOCKS * sizeof(int);
   const __half* A[MAXP]; const __half* W[MAXP]; float* out[MAXP];
   int M[MAXP], N[MAXP], ldo[MAXP];
   int K, lda, ldw, n;
 };
-// table: device scratch for MAXP argument structs, written on stream s in front of the product launch (a later group on the
-// same stream may reuse it)
-hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, GemmH2Args* table, hipStream_t s);
+// scratch: SCRATCH_BYTES of device memory, written on stream s in front of the product launch (a later group on the same
+// stream may reuse it)
+hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, void* scratch, hipStream_t s);
 // colscale (nullable, length cols): element (r, c) is multiplied by colscale[c] before the split (folds a layer-norm
 // weight into the columns of the consuming projection); cols is ignored when colscale is null
 hipError_t launch_split_planes(const float* x, __half* out, size_t n, size_t plane_stride, hipStream_t s,

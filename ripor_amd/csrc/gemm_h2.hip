@@ -28,6 +28,9 @@
 
 #include "common.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace rpr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -515,22 +518,34 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmH2Args g, int ti
 // (encoder: four) linear layers, are 9 .. 36 output tiles each with a reduction over all rows of the batch. One launch per
 // product cannot fill the chip without split-K (5-K-tile loops, fp32 partials, a reduce pass: 240 TF/s, and every
 // 252-block launch takes the whole chip from the input-gradient chain on the main stream); here ONE launch walks all
-// products of the layer, grid = (most tiles of any product, products): a block reads its product's argument struct from a
-// table in device memory (scalar loads; a struct assembled in the kernel from by-value arrays stayed in scratch, 344 bytes
-// per lane, because the epilogue indexes out[] / ldo[] at run time) and runs the whole reduction of one tile in a single
-// K-loop (t5-base decoder layer: 126 tiles x 128 K-tiles of 64 rows). Blocks past their product's tile count exit at once.
-// The table is written by gemm_group_table_kernel from by-value arguments on the same stream, directly in front of the
+// products of the layer, one block per tile (at most 384 tiles), each running the whole reduction of its tile in a single
+// K-loop (t5-base decoder layer: 126 tiles x 128 K-tiles of 64 rows). A block reads (product, tile) from an assignment
+// table and its product's argument struct from a table in device memory (scalar loads; a struct assembled in the kernel
+// from by-value arrays stayed in scratch, 344 bytes per lane, because the epilogue indexes out[] / ldo[] at run time).
+// Both tables are written by gemm_group_table_kernel from by-value arguments on the same stream, directly in front of the
 // product launch: no host memory whose lifetime would have to outlast the enqueue.
+// Assignment (launch_gemm_h2_group): workgroup i of a 1-D grid runs on XCD i % 8. Every product's tile grid is cut into
+// super-tiles of up to 4 x 4 tiles, the tiles are listed super-tile by super-tile and every XCD takes an equal run of that
+// list: the blocks of a super-tile run side by side on one XCD and share their A and W panels in its L2 (a 4 x 3 super-tile
+// streams 7 panels for 12 tiles). With the products' tiles in
+// plain row-major order over the XCDs the launch fetched 773 MB from the fabric for 276 MB of distinct operands
+// (rocprofv3 FETCH_SIZE; 1.03 GB go through LDS).
 template <bool FULL>
-__global__ __launch_bounds__(512, 2) void gemm_h2_pp_group_kernel(const GemmH2Args* __restrict__ table) {
+__global__ __launch_bounds__(512, 2) void gemm_h2_pp_group_kernel(const GemmH2Args* __restrict__ table, const int* __restrict__ assign) {
   constexpr bool TRACE = false, BF16 = true;
-  const GemmH2Args& g = table[blockIdx.y];
+  const int asg = assign[blockIdx.x];
+  if (asg < 0) return;
+  const GemmH2Args& g = table[asg >> 16];
   const int tiles_m = (g.M + 255) >> 8, tiles_n = (g.N + 255) >> 8;
+#define PP_GROUP_TILE (asg & 0xffff)
 #include "gemm_h2_pp_body.inc"
+#undef PP_GROUP_TILE
 }
 
-__global__ void gemm_group_table_kernel(GemmGroupArgs p, GemmH2Args* __restrict__ table) {
+struct GroupAssign { int n; int v[GemmGroupArgs::MAX_BLOCKS]; };
+__global__ void gemm_group_table_kernel(GemmGroupArgs p, GroupAssign a, GemmH2Args* __restrict__ table, int* __restrict__ assign) {
   const int i = threadIdx.x;
+  for (int k = i; k < a.n; k += blockDim.x) assign[k] = a.v[k];
   if (i >= p.n) return;
   GemmH2Args g{};
   g.A = p.A[i]; g.W = p.W[i]; g.lda = p.lda; g.ldw = p.ldw;
@@ -744,20 +759,50 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, GemmH2Args* table, hipStream_t s) {
+hipError_t launch_gemm_h2_group(const GemmGroupArgs& p, void* scratch, hipStream_t s) {
   if (p.n <= 0) return hipSuccess;
-  if (!table || p.n > GemmGroupArgs::MAXP || p.K <= 0 || (p.K & 63) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
-  int max_tiles = 0;
+  if (!scratch || p.n > GemmGroupArgs::MAXP || p.K <= 0 || (p.K & 63) || (p.lda & 7) || (p.ldw & 7)) return hipErrorInvalidValue;
   bool full = true;
+  int total = 0;
+  struct Super { int p, tm0, tn0, rm, rn; };
+  std::vector<Super> sup;
   for (int i = 0; i < p.n; ++i) {
     if (!p.A[i] || !p.W[i] || !p.out[i] || p.M[i] <= 0 || p.N[i] <= 0 || (p.ldo[i] & 3) || (p.N[i] & 3)) return hipErrorInvalidValue;
-    max_tiles = std::max(max_tiles, ((p.M[i] + 255) / 256) * ((p.N[i] + 255) / 256));
+    const int tm = (p.M[i] + 255) / 256, tn = (p.N[i] + 255) / 256;
+    total += tm * tn;
     full = full && (p.M[i] % 256 == 0) && (p.N[i] % 256 == 0);
+    // nearly equal parts of at most 4 tile rows / columns
+    const int pm = (tm + 3) / 4, pn = (tn + 3) / 4, sm = (tm + pm - 1) / pm, sn = (tn + pn - 1) / pn;
+    for (int a = 0; a < tm; a += sm)
+      for (int b = 0; b < tn; b += sn) sup.push_back({i, a, b, std::min(sm, tm - a), std::min(sn, tn - b)});
   }
-  hipLaunchKernelGGL(gemm_group_table_kernel, dim3(1), dim3(64), 0, s, p, table);
-  const dim3 gr(max_tiles, p.n), bl(512);
-  if (full) hipLaunchKernelGGL((gemm_h2_pp_group_kernel<true>), gr, bl, 0, s, table);
-  else hipLaunchKernelGGL((gemm_h2_pp_group_kernel<false>), gr, bl, 0, s, table);
+  if (total > GemmGroupArgs::MAX_TILES || total >= 65536) return hipErrorInvalidValue;
+  // the tiles in super-tile order, cut into 8 equal runs: every XCD gets the same number of tiles (the main stream's kernels
+  // run beside this launch and are spread evenly over the XCDs: whole super-tiles per XCD, 21 blocks on one XCD and 12 on
+  // another, slowed those by 10 %), a run is one or two super-tiles plus parts of its neighbours
+  std::vector<int> order;
+  for (const Super& u : sup) {
+    const int tn = (p.N[u.p] + 255) / 256;
+    for (int a = 0; a < u.rm; ++a)
+      for (int b = 0; b < u.rn; ++b) order.push_back((u.p << 16) | ((u.tm0 + a) * tn + u.tn0 + b));
+  }
+  std::vector<int> per_xcd[8];
+  for (int x = 0; x < 8; ++x)
+    for (size_t k = (size_t)x * order.size() / 8; k < (size_t)(x + 1) * order.size() / 8; ++k) per_xcd[x].push_back(order[k]);
+  size_t slots = 0;
+  for (int x = 0; x < 8; ++x) slots = std::max(slots, per_xcd[x].size());
+  GroupAssign asg;
+  asg.n = (int)slots * 8;
+  if (asg.n > GemmGroupArgs::MAX_BLOCKS) return hipErrorInvalidValue;
+  for (int i = 0; i < asg.n; ++i) asg.v[i] = -1;
+  for (int x = 0; x < 8; ++x)
+    for (size_t k = 0; k < per_xcd[x].size(); ++k) asg.v[x + 8 * k] = per_xcd[x][k];
+  GemmH2Args* table = reinterpret_cast<GemmH2Args*>(scratch);
+  int* assign = reinterpret_cast<int*>(static_cast<char*>(scratch) + GemmGroupArgs::TABLE_BYTES);
+  hipLaunchKernelGGL(gemm_group_table_kernel, dim3(1), dim3(256), 0, s, p, asg, table, assign);
+  const dim3 gr(asg.n), bl(512);
+  if (full) hipLaunchKernelGGL((gemm_h2_pp_group_kernel<true>), gr, bl, 0, s, table, assign);
+  else hipLaunchKernelGGL((gemm_h2_pp_group_kernel<false>), gr, bl, 0, s, table, assign);
   return hipGetLastError();
 }
 

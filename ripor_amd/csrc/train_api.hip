@@ -49,7 +49,7 @@ struct TrainWs {
   hipEvent_t ev_gfork[2] = {}, ev_gdone[2] = {};
   bool gdone_pending[2] = {};
   GemmGroupArgs grp = {};
-  int gset = 0;
+  int gset = 0, grp_tiles = 0;
   size_t dyT_used = 0;
   double grp_flops = 0, grp_bytes = 0;
   DevBuf aseg, apref;                  // rpr_adamw_step: one launch over all tensors (table built once per model)
@@ -337,11 +337,11 @@ struct Bwd {
     if (hipEventRecord(w.ev_gfork[gs], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_gfork[gs], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
     Launcher L2{c, side};
     const GemmGroupArgs grp = w.grp;
-    L2.run(RPR_K_GEMM, w.grp_flops, w.grp_bytes, [&] { return launch_gemm_h2_group(grp, P<GemmH2Args>(w.gtab), side); });
+    L2.run(RPR_K_GEMM, w.grp_flops, w.grp_bytes, [&] { return launch_gemm_h2_group(grp, w.gtab.p, side); });
     if (L2.err) { Ln.err = L2.err; return; }
     if (hipEventRecord(w.ev_gdone[gs], side) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
     w.gdone_pending[gs] = true;
-    w.grp.n = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0;
+    w.grp.n = 0; w.grp_tiles = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0;
     w.gset = gs ^ 1;
     if (w.gdone_pending[w.gset]) {   // the next layer writes into the other set: its last group launch must be over
       if (hipStreamWaitEvent(s, w.ev_gdone[w.gset], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
@@ -362,8 +362,13 @@ struct Bwd {
       auto wit_g = w.wc_off.find(W);
       const int Ml = ldT(M);
       const size_t need = (((size_t)N * Ml * sizeof(__half)) + 255) & ~(size_t)255;
+      const int ptiles = ((N + 255) / 256) * ((K + 255) / 256);
+      if (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && ptiles <= GemmGroupArgs::MAX_TILES &&
+          (w.grp.n == 0 || w.grp.K != Mp || w.grp.n >= GemmGroupArgs::MAXP || w.grp_tiles + ptiles > GemmGroupArgs::MAX_TILES ||
+           w.dyT_used + need > w.dyT[w.gset].cap))
+        flush_group();   // the product does not fit the group being collected: send that one off, start the next
       if (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && w.dyT_used + need <= w.dyT[w.gset].cap &&
-          (w.grp.n == 0 || w.grp.K == Mp) && w.grp.n < GemmGroupArgs::MAXP) {
+          ptiles <= GemmGroupArgs::MAX_TILES) {
         // grouped route: dY^T into this layer's set, the product into the group, dX on the main stream at once
         void* py = w.tA.p;
         __half* pyt = reinterpret_cast<__half*>(static_cast<char*>(w.dyT[w.gset].p) + w.dyT_used);
@@ -373,6 +378,7 @@ struct Bwd {
         const int i = gp.n++;
         gp.A[i] = pyt; gp.W[i] = reinterpret_cast<const __half*>(saved_xt); gp.out[i] = dW;
         gp.M[i] = N; gp.N[i] = K; gp.ldo[i] = K; gp.K = Mp; gp.lda = Ml; gp.ldw = Ml;
+        w.grp_tiles += ptiles;
         w.grp_flops += 2.0 * N * (double)K * Mp;
         w.grp_bytes += 2.0 * ((double)N * Mp + (double)K * Mp) + 4.0 * (double)N * K;
         const void* pwt = reinterpret_cast<const __half*>(w.wcT.p) + wit_g->second;
@@ -490,7 +496,8 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
       const size_t dec = (3 * dm + dff + 4 * inner) * Rp, enc = (2 * dm + dff + 3 * inner) * Tp, xkv = (size_t)D.xld * Tp;
       const size_t need = std::max(std::max(dec, enc), xkv) * sizeof(__half) + 8 * 256;
       E(w.dyT[0], need); E(w.dyT[1], need);
-      E(w.gtab, GemmGroupArgs::MAXP * sizeof(GemmH2Args));
+      static_assert(GemmGroupArgs::MAXP * sizeof(GemmH2Args) <= GemmGroupArgs::TABLE_BYTES, "argument table");
+      E(w.gtab, GemmGroupArgs::SCRATCH_BYTES);
     }
   }
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
