@@ -921,6 +921,11 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // long reductions into few tiles (weight gradients); K-tiles of 64 columns
     if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63)) return hipErrorInvalidValue;
     const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // (A kernel with 128x128 wave tiles — 256x256 block, four waves, one per SIMD, 512 registers: two thirds of the LDS reads
+    // per MFMA — was built and measured: 31-34 us per 256x256x768 tile against 23 us for this shape on the 128-row kernel
+    // and 60-65 us against 54-58 on the ping-pong kernel. With ONE wave per SIMD the 16 LDS-DMA pieces and 32 fragment reads
+    // of a K-tile are issued by the wave that also issues the 64 MFMAs, in series: ~2.2 us per K-tile again. Source kept
+    // as tools/gemm_bf16_w128.hip.txt; HISTORY.md.)
     if (a.prefer_pp) {
       static const int dwk = [] { const char* e = getenv("RPR_TRAIN_DW_TILE"); return e ? atoi(e) : 256; }();   // experiment: 128 / 64
       if (dwk == 128) return launch_cfg<128, 128, 2, 2, true>(a, s);
