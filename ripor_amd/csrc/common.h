@@ -429,6 +429,13 @@ hipError_t launch_rmsnorm_bf16_T(const float* x, const float* w, int rows, int d
                                  int Rpad, int ldt, hipStream_t s);
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
                               float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s);
+// partials of several rmsnorm_bwd launches (dw == nullptr there) summed in one launch: out_i[k] = sum over p of part_i[p][k]
+struct ColsumSites {
+  static constexpr int MAXS = 4;
+  const float* part[MAXS]; float* out[MAXS]; int nparts[MAXS]; int n;
+};
+int rmsnorm_bwd_parts(int rows);
+hipError_t launch_colsum_multi(const ColsumSites& p, int d, hipStream_t s);
 size_t self_attn_bwd_smem(int Ls, int buckets);
 hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t* mask, const float* rel_bias, const int32_t* bucket,
                                 float* dqkv, float* dbias_part, float* dbias, int S, int Ls, int H, int buckets, int causal,

@@ -462,11 +462,25 @@ struct Bwd {
   void norm(const float* x, const float* ln, int rows, float post = 1.0f) {   // recompute the normalised input into w.h
     Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * D.dm, [&] { return launch_rmsnorm(x, ln, P<float>(w.h), rows, D.dm, D.eps, Ln.s, post); });
   }
+  // The layer-norm weight gradient of a site is the column sum of its blocks' partials: the sites of a layer keep their
+  // partials in separate regions of w_part and are summed by ONE launch at the end of the layer (flush_norms; 62 launches
+  // of 10 us per step before)
+  ColsumSites cs = {};
   void norm_bwd(const float* x, const float* ln, const float* dh, const float* dres, float* dx_out, float* dln, int rows,
                 float post = 1.0f) {
+    if (cs.n == ColsumSites::MAXS) flush_norms();
+    const size_t region = ((size_t)(std::max(D.R, D.T) + 3) / 4) * D.dm;
+    float* part = P<float>(w.w_part) + (size_t)cs.n * region;
     Ln.run(RPR_K_RMSNORM, 0, 16.0 * rows * D.dm, [&] {
-      return launch_rmsnorm_bwd(x, ln, dh, dres, dx_out, P<float>(w.w_part), dln, rows, D.dm, D.eps, post, 0, Ln.s);
+      return launch_rmsnorm_bwd(x, ln, dh, dres, dx_out, part, nullptr, rows, D.dm, D.eps, post, 0, Ln.s);
     });
+    cs.part[cs.n] = part; cs.out[cs.n] = dln; cs.nparts[cs.n] = rmsnorm_bwd_parts(rows); ++cs.n;
+  }
+  void flush_norms() {
+    if (cs.n == 0 || Ln.err) return;
+    const ColsumSites p = cs;
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_colsum_multi(p, D.dm, Ln.s); });
+    cs.n = 0;
   }
 };
 
@@ -501,7 +515,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
     }
   }
   E(w.wT, std::max<size_t>(std::max<size_t>(dff * dm, 3 * inner * dm), (size_t)D.xld * dm) * f);
-  E(w.w_part, ((rows + 3) / 4) * dm * f);
+  E(w.w_part, ColsumSites::MAXS * ((rows + 3) / 4) * dm * f);   // the partials of up to four norm sites (Bwd::norm_bwd)
   E(w.bias_part, std::max<size_t>((size_t)D.S, (size_t)D.bz) * D.H * D.buckets * f);
   E(w.fix, std::max<size_t>((size_t)m->d.vocab_size, (size_t)m->d.L * D.V) * dm * 8);
   E(w.gn_part, 1024 * 8); E(w.gn_out, 16); E(w.amax, AMAX_SLOTS * f); E(w.part, (size_t)16 << 20 << 2); E(w.part2, (size_t)16 << 20 << 2);   // split-K partials: 16 M floats per stream
@@ -698,6 +712,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.norm_bwd(a.x0, m->dec_ln0[i], h, dx, dx2, g(K_DEC_LN0, i), R);
     std::swap(dx, dx2);                                            // dx = gradient w.r.t. x0 = the previous layer's output
     B.flush_group();                                               // the layer's six weight gradients: one launch on the side stream
+    B.flush_norms();                                               // ... and its three layer-norm weight gradients
     { const auto b = layer_numel(K_DEC_LN0, K_DEC_WO, i); bucket(b.first, b.second); }
   }
   // decoder input embeddings: codebook rows and the start embedding
@@ -729,6 +744,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     B.norm_bwd(a.x, m->enc_ln0[i], h, dx, dx2, g(K_ENC_LN0, i), T);
     std::swap(dx, dx2);
     B.flush_group();
+    B.flush_norms();
     { const auto b = layer_numel(K_ENC_LN0, K_ENC_WO, i); bucket(b.first, b.second); }
   }
   // token embeddings (the encoder's table is the shared one)
@@ -741,6 +757,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
       w.done_pending[i] = false;
     }
   B.flush_group();
+  B.flush_norms();                                                 // the encoder's final norm (the decoder's went with its last layer)
   for (int i = 0; i < 2; ++i)
     if (w.gdone_pending[i]) {
       if (hipStreamWaitEvent(s, w.ev_gdone[i], 0) != hipSuccess) Ln.err = RPR_ERR_HIP;

@@ -335,13 +335,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   }
 }
 
+// dw == nullptr: only the partials are written (w_part[nblk][d], nblk = rmsnorm_bwd_parts(rows)); the caller sums the
+// partials of several norm sites in one launch_colsum_multi
+int rmsnorm_bwd_parts(int rows) { return (rows + NB_ROWS - 1) / NB_ROWS; }
 hipError_t launch_rmsnorm_bwd(const float* x, const float* w, const float* dh, const float* dres, float* dx_out, float* w_part,
                               float* dw, int rows, int d, float eps, float post, int accumulate_dw, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  const int nblk = (rows + NB_ROWS - 1) / NB_ROWS;
+  const int nblk = rmsnorm_bwd_parts(rows);
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nblk), dim3(256), 4 * d * sizeof(float), s, x, w, dh, dres, dx_out, w_part, rows, d,
                      eps, post);
-  hipLaunchKernelGGL(colsum_kernel, dim3((d + 15) / 16), dim3(256), 0, s, w_part, dw, nblk, d, accumulate_dw);
+  if (dw) hipLaunchKernelGGL(colsum_kernel, dim3((d + 15) / 16), dim3(256), 0, s, w_part, dw, nblk, d, accumulate_dw);
+  return hipGetLastError();
+}
+
+// colsum_kernel for up to four sites at once (blockIdx.y = site; the layer-norm weight gradients of one transformer layer):
+// the same arithmetic and order per site
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumSites p, int d) {
+  __shared__ float red[16][16];
+  const int y = blockIdx.y;
+  const float* part = y == 0 ? p.part[0] : y == 1 ? p.part[1] : y == 2 ? p.part[2] : p.part[3];
+  float* out = y == 0 ? p.out[0] : y == 1 ? p.out[1] : y == 2 ? p.out[2] : p.out[3];
+  const int nparts = y == 0 ? p.nparts[0] : y == 1 ? p.nparts[1] : y == 2 ? p.nparts[2] : p.nparts[3];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + col;
+  const int per = (nparts + 15) / 16, p0 = grp * per, p1 = min(nparts, p0 + per);
+  float s = 0.f;
+  if (k < d)
+    for (int q = p0; q < p1; ++q) s += part[(size_t)q * d + k];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && k < d) {
+    float t = 0.f;
+#pragma unroll
+    for (int g16 = 0; g16 < 16; ++g16) t += red[g16][col];
+    out[k] = t;
+  }
+}
+hipError_t launch_colsum_multi(const ColsumSites& p, int d, hipStream_t s) {
+  if (p.n <= 0) return hipSuccess;
+  if (p.n > ColsumSites::MAXS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3((d + 15) / 16, p.n), dim3(256), 0, s, p, d);
   return hipGetLastError();
 }
 
