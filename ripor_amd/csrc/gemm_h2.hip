@@ -714,6 +714,144 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   }
 }
 
+// ---- skinny variant for at most 16 rows (ONE query in flight: the beams of a step, its encoder tokens) ------------------
+// The 32-row skinny kernel gives a 768 x 768 weight 24 blocks, and a wave's ring holds three of its six K-tiles (8-KB
+// stages: 32 activation + 32 weight rows, two planes): two memory round trips per launch, 11 us, 413 launches = 85 % of a
+// single-query search. Here a block is a 16 x 16 output tile (v_mfma_f32_16x16x32_f16: a K-tile of 32 is ONE MFMA per
+// product term): twice the blocks, 4-KB stages, six stages per wave = all of K = 768 in flight at once (K = 3072: a ring of
+// six). Same K split over the four waves, same fixed-order reduction, same fused epilogue arithmetic as the 32-row kernel.
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, int tiles_n) {
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
+  constexpr int BT = 16, ST = 6, ROWS = 4 * BT, PIECES = ROWS / 16;   // 4 KB per stage: A hi, A lo, W hi, W lo x 16 rows
+  __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];   // 96 KB
+  const int bn = blockIdx.x * BT;
+  int Mlive = g.M;
+  if (g.m_dev) {
+    const int md = *g.m_dev;
+    if (g.live_hi > 0 && (md <= g.live_lo || md > g.live_hi)) return;
+    Mlive = min(md, g.M);
+  }
+  if (Mlive <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
+  // epilogue operands of wave 0, requested before the K walk: lane = column bn + lane % 16, rows 4 (lane / 16) + r
+  unsigned long long e_ssq[4];
+  __half e_rh[4], e_rl[4];
+  float e_rf[4];
+  if (wave == 0) {
+    const int n = bn + (lane & 15), rsub = 4 * (lane >> 4);
+    const bool nok = FULL || n < g.N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = rsub + r;
+      const bool mok = m < Mlive;
+      e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
+      e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
+      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+    }
+  }
+  const __half* src[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    const int lrow = 16 * j + (lane >> 2);
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const bool is_a = j < 2, second = (j & 1) != 0;
+    const __half* base = is_a ? g.A : g.W;
+    const size_t plane = second ? (is_a ? g.a_ps : g.w_ps) : 0;
+    const int limit = is_a ? g.M : g.N;
+    const size_t ld = is_a ? (size_t)g.lda : (size_t)g.ldw;
+    int trow = (is_a ? 0 : bn) + (lane >> 2);
+    if (trow >= limit) trow = limit - 1;                 // activation rows past M: clamped, their outputs are never stored
+    src[j] = base + plane + (size_t)trow * ld + seg * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)(wsm + (size_t)buf * ROWS * HBK + 16 * j * HBK),
+                                       16, 0, 0);
+  };
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, kg = lane >> 4;
+  const int so = (kg ^ ((frow >> 2) & 3)) * 8;           // the lane's 8 k values of its row: one swizzled 16-byte segment
+  auto compute = [&](int buf) {
+    const __half* base = wsm + (size_t)buf * ROWS * HBK + frow * HBK + so;
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(base);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(base + BT * HBK);
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(base + 2 * BT * HBK);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(base + 3 * BT * HBK);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+  };
+  const int nkt = g.K / HBK;
+  const int mine = wave < nkt ? (nkt - wave + 3) / 4 : 0;         // K-tiles wave, wave + 4, ...
+  constexpr int KEEP = PIECES * (ST - 2);                         // pieces of the younger tiles that may be pending
+  constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | 0x0f70, WAIT_NONE = 0x0f70;
+#pragma unroll
+  for (int t = 0; t < ST - 1; ++t)
+    if (t < mine) stage(t, (wave + 4 * t) * HBK);
+  for (int i = 0; i < mine; ++i) {
+    if (i + ST - 2 < mine) __builtin_amdgcn_s_waitcnt(WAIT_KEEP); else __builtin_amdgcn_s_waitcnt(WAIT_NONE);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + ST - 1 < mine) stage((i + ST - 1) % ST, (wave + 4 * (i + ST - 1)) * HBK);   // buffer of tile i-1: its reads are done
+    compute(i % ST);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    acc[r] = ((red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane]) + red[(2 * 4 + r) * 64 + lane]) + red[(3 * 4 + r) * 64 + lane];
+  const int n = bn + (lane & 15), rsub = 4 * (lane >> 4);
+  const bool nok = FULL || n < g.N;
+  const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
+  float* outp = g.out[oi];
+  const int ldo = g.ldo[oi];
+  float ssr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = rsub + r;
+    const bool mok = m < Mlive, ok = nok && mok;
+    float v = acc[r] * acc_scale;
+    if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.resid && ok) v = e_rf[r] + v;
+    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
+    if (ok) {
+      if (g.out_h) {
+        __half hi, lo;
+        split_f16(v * g.plane_scale, hi, lo, g.sat);
+        g.out_h[(size_t)m * g.ldoh + n] = hi;
+        g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+        v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;
+      } else {
+        outp[out_off(g, oi, m, ldo, on)] = v;
+      }
+    }
+    ssr[r] = ok ? v * v : 0.f;
+  }
+  if (g.ssq_out) {   // the 16 lanes of a row group hold this block's 16 columns of rows rsub .. rsub + 3
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssr[r] += __shfl_xor(ssr[r], o, 64);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (rsub + r < Mlive) atomicAdd(g.ssq_out + rsub + r, ssq_to_fix(ssr[r]));
+    }
+  }
+}
+
 template <int BM, int BN, int WM = 2, int WN = 2, bool BF16 = false>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -892,7 +1030,14 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
   static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
+  static const int skinny16 = [] { const char* e = getenv("RPR_GEMM_SKINNY16"); return e ? atoi(e) : 1; }();
   auto launch_skinny = [&](const GemmH2Args& k) {
+    if (skinny16 && k.M <= 16 && (k.N & 15) == 0) {   // one query in flight: 16 x 16 tiles, all of K = 768 in flight
+      const int tiles_n = k.N / 16;
+      if (!k.m_dev) hipLaunchKernelGGL((gemm_h2_skinny16_kernel<true>), dim3(tiles_n), dim3(256), 0, s, k, tiles_n);
+      else hipLaunchKernelGGL((gemm_h2_skinny16_kernel<false>), dim3(tiles_n), dim3(256), 0, s, k, tiles_n);
+      return hipGetLastError();
+    }
     const int tiles_m = (k.M + 31) / 32, tiles_n = (k.N + 31) / 32;
     const bool full = (k.M % 32 == 0) && (k.N % 32 == 0) && !k.m_dev;
     if (full) hipLaunchKernelGGL((gemm_h2_skinny_kernel<true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, k, tiles_m, tiles_n);
