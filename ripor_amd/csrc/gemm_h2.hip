@@ -714,25 +714,26 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   }
 }
 
-// ---- skinny variant for at most 16 rows (ONE query in flight: the beams of a step, its encoder tokens) ------------------
+// ---- skinny variant for at most 32 rows (ONE query in flight: the beams of a step, its encoder tokens) ------------------
 // The 32-row skinny kernel gives a 768 x 768 weight 24 blocks, and a wave's ring holds three of its six K-tiles (8-KB
 // stages: 32 activation + 32 weight rows, two planes): two memory round trips per launch, 11 us, 413 launches = 85 % of a
 // single-query search. Here a block is a 16 x 16 output tile (v_mfma_f32_16x16x32_f16: a K-tile of 32 is ONE MFMA per
 // product term): twice the blocks, 4-KB stages, six stages per wave = all of K = 768 in flight at once (K = 3072: a ring of
-// six). Same K split over the four waves, same fixed-order reduction, same fused epilogue arithmetic as the 32-row kernel.
+// six). blockIdx.y = 16-row tile (one for a step's 10 beams, two for an encoder of 17 .. 32 tokens). Same K split over the
+// four waves, same fixed-order reduction, same fused epilogue arithmetic as the 32-row kernel.
 template <bool FULL>
 __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, int tiles_n) {
   const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
   constexpr int BT = 16, ST = 6, ROWS = 4 * BT, PIECES = ROWS / 16;   // 4 KB per stage: A hi, A lo, W hi, W lo x 16 rows
   __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];   // 96 KB
-  const int bn = blockIdx.x * BT;
+  const int bn = blockIdx.x * BT, bm = blockIdx.y * BT;
   int Mlive = g.M;
   if (g.m_dev) {
     const int md = *g.m_dev;
     if (g.live_hi > 0 && (md <= g.live_lo || md > g.live_hi)) return;
     Mlive = min(md, g.M);
   }
-  if (Mlive <= 0) return;
+  if (bm >= Mlive) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
     const bool nok = FULL || n < g.N;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = rsub + r;
+      const int m = bm + rsub + r;
       const bool mok = m < Mlive;
       e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
       e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
     const size_t plane = second ? (is_a ? g.a_ps : g.w_ps) : 0;
     const int limit = is_a ? g.M : g.N;
     const size_t ld = is_a ? (size_t)g.lda : (size_t)g.ldw;
-    int trow = (is_a ? 0 : bn) + (lane >> 2);
+    int trow = (is_a ? bm : bn) + (lane >> 2);
     if (trow >= limit) trow = limit - 1;                 // activation rows past M: clamped, their outputs are never stored
     src[j] = base + plane + (size_t)trow * ld + seg * 8;
   }
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
   float ssr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int m = rsub + r;
+    const int m = bm + rsub + r;
     const bool mok = m < Mlive, ok = nok && mok;
     float v = acc[r] * acc_scale;
     if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
     if ((lane & 15) == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (rsub + r < Mlive) atomicAdd(g.ssq_out + rsub + r, ssq_to_fix(ssr[r]));
+        if (bm + rsub + r < Mlive) atomicAdd(g.ssq_out + bm + rsub + r, ssq_to_fix(ssr[r]));
     }
   }
 }
@@ -1032,10 +1033,11 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
   static const int skinny16 = [] { const char* e = getenv("RPR_GEMM_SKINNY16"); return e ? atoi(e) : 1; }();
   auto launch_skinny = [&](const GemmH2Args& k) {
-    if (skinny16 && k.M <= 16 && (k.N & 15) == 0) {   // one query in flight: 16 x 16 tiles, all of K = 768 in flight
+    if (skinny16 && k.M <= 32 && (k.N & 15) == 0) {   // one query in flight: 16 x 16 tiles, all of K = 768 in flight
       const int tiles_n = k.N / 16;
-      if (!k.m_dev) hipLaunchKernelGGL((gemm_h2_skinny16_kernel<true>), dim3(tiles_n), dim3(256), 0, s, k, tiles_n);
-      else hipLaunchKernelGGL((gemm_h2_skinny16_kernel<false>), dim3(tiles_n), dim3(256), 0, s, k, tiles_n);
+      const dim3 grid(tiles_n, (k.M + 15) / 16);
+      if (!k.m_dev) hipLaunchKernelGGL((gemm_h2_skinny16_kernel<true>), grid, dim3(256), 0, s, k, tiles_n);
+      else hipLaunchKernelGGL((gemm_h2_skinny16_kernel<false>), grid, dim3(256), 0, s, k, tiles_n);
       return hipGetLastError();
     }
     const int tiles_m = (k.M + 31) / 32, tiles_n = (k.N + 31) / 32;
