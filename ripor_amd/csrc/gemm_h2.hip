@@ -225,6 +225,50 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     }
   }
 
+  if (BF16) {
+    // bf16 training GEMMs (fp32 output, optional fp32 residual and ReLU, nothing else fused: launch_gemm_h2 checks): the wave's
+    // (BM / WM) x (BN / WN) outputs go through a private LDS strip (the operand buffers are free) and leave row-wise with
+    // 16-byte accesses, every residual piece requested before the first store. Straight from the MFMA layout (below) a wave
+    // issued 64 four-byte stores per 32 x 32 block and as many residual loads, each batch waiting behind the stores before it.
+    constexpr int SH = BM / WM, SW = BN / WN;             // strip rows x columns (floats)
+    static_assert((size_t)BM * BN * sizeof(float) <= sizeof(smem), "the strips of all waves fit the operand buffers");
+    __syncthreads();                                      // every wave is done reading operand tiles
+    float* stg = reinterpret_cast<float*>(smem) + (size_t)wave * (SH * SW);
+    const int ncol_ = lane & 31, rsub_ = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[(i * 32 + (r & 3) + 8 * (r >> 2) + rsub_) * SW + j * 32 + ncol_] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI;   // lanes per staged row, rows per instruction, instructions
+    const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
+    const int mrow0 = bm + wm * SH, n0 = bn + wn * SW + rc4;
+    const bool ncol_ok = FULL || n0 < g.N;
+    float* outp = g.out[0] + (size_t)blockIdx.y * g.part_stride;   // split-K: this block's partial result
+    const int ldo = g.ldo[0];
+    const float relu_lo = g.relu ? 0.f : -INFINITY;
+    float4 res[NK];
+    if (g.resid) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {   // clamped, unconditional: a branch around a load brings the conservative vmcnt(0) back
+        const int m = min(mrow0 + k * RPI + rrow, g.M - 1), nc = ncol_ok ? n0 : 0;
+        res[k] = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + nc);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int rl = k * RPI + rrow, m = mrow0 + rl;
+      float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+      v.x = fmaxf(v.x * acc_scale, relu_lo); v.y = fmaxf(v.y * acc_scale, relu_lo);
+      v.z = fmaxf(v.z * acc_scale, relu_lo); v.w = fmaxf(v.w * acc_scale, relu_lo);
+      if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
+      if (ncol_ok && (FULL || m < g.M)) *reinterpret_cast<float4*>(outp + (size_t)m * ldo + n0) = v;
+    }
+    return;
+  }
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
   const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
 #pragma unroll
@@ -1066,7 +1110,9 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   if (a.bf16) {
     // one bf16 plane per operand (training GEMMs, RPR_PREC_BF16): fp32 output, optional residual / ReLU, split-K for the
     // long reductions into few tiles (weight gradients); K-tiles of 64 columns
-    if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63)) return hipErrorInvalidValue;
+    if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63) || (a.N & 3) || (a.ldo[0] & 3) ||
+        (a.resid && (a.ldr & 3)) || a.split_n < a.N)
+      return hipErrorInvalidValue;                       // (the bf16 kernels' epilogues store 16-byte pieces of ONE fp32 output)
     const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     // (A kernel with 128x128 wave tiles — 256x256 block, four waves, one per SIMD, 512 registers: two thirds of the LDS reads
     // per MFMA — was built and measured: 31-34 us per 256x256x768 tile against 23 us for this shape on the 128-row kernel
