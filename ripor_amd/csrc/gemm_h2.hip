@@ -39,6 +39,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// the LDS-transposed epilogue of the tile kernels (defined behind gemm_h2_dma_kernel)
+template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN>
+__device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave, int lane, int bm,
+                                                int bn, int wm, int wn, const float* rs_tile, float acc_scale);
+
 constexpr int HBK = 32;  // K-tile depth = halves per LDS row (64 B, unpadded)
 
 
@@ -74,6 +79,8 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   constexpr int PER_WAVE = NINST / NW;
   static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) __half smem[STAGES * ROWS * HBK];
+  __shared__ float rs_tile[BM];                      // fused RMSNorm: rsqrt(mean(x^2) + eps) of the tile's rows (split-precision launches)
+  static_assert(64 * WM * WN >= BM, "one thread per tile row fills rs_tile");
 
   int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -92,6 +99,10 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  if (!BF16 && g.row_ssq && tid < BM) {   // read by the epilogue, behind the K-loop's barriers
+    const int m = bm + tid;
+    rs_tile[tid] = (m < g.M) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
+  }
   // split-K (training weight gradients: few output tiles, K = thousands of rows): blockIdx.y walks its own range of
   // K-tiles and stores a partial result at out + blockIdx.y * part_stride; splitk_reduce_kernel adds them in order
   int nkt = g.K / KSTEP, kbeg = 0;
@@ -269,69 +280,13 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
     }
     return;
   }
-  const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mbase = bm + wm * (BM / WM) + i * 32 + rsub;
-    float rs[16], ssr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mbase + (r & 3) + 8 * (r >> 2);
-      ssr[r] = 0.f;
-      rs[r] = (g.row_ssq && (FULL || m < Mlim)) ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = bn + wn * (BN / WN) + j * 32 + ncol;
-      const bool nok = FULL || n < g.N;
-      const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
-      float* outp = g.out[oi] + (size_t)blockIdx.y * g.part_stride;
-      const int ldo = g.ldo[oi];
-      float res[16];
-      if (g.resid || g.resid_h) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          res[r] = 0.f;
-          if (nok && (FULL || m < Mlim))
-            res[r] = g.resid_h ? x_from_planes(g.resid_h[(size_t)m * g.ldrh + n], g.resid_h[g.r_ps + (size_t)m * g.ldrh + n])
-                               : g.resid[(size_t)m * g.ldr + n];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        const bool ok = nok && (FULL || m < Mlim);
-        float v = acc[i][j][r] * acc_scale;
-        if (g.row_ssq) v *= rs[r];
-        if (g.relu) v = fmaxf(v, 0.f);
-        if (g.resid || g.resid_h) v = res[r] + v;
-        if (ok) {
-          if (g.out_h) {
-            __half hi, lo;
-            split_f16(v * g.plane_scale, hi, lo, g.sat);
-            g.out_h[(size_t)m * g.ldoh + n] = hi;
-            g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
-            v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;   // the value the planes carry (row sums below)
-          } else {
-            outp[out_off(g, oi, m, ldo, on)] = v;
-          }
-          ssr[r] += v * v;
-        }
-      }
-    }
-    if (g.ssq_out) {   // this wave's part of every row's sum of squares: 32 lanes share a row
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float ss = ssr[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (ncol == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
-      }
-    }
-  }
+  // split-precision launches (a few hundred to a few thousand rows in flight; every fused extra of the search path): the
+  // LDS-transposed epilogue of the 256x256 kernels on this kernel's tile shape — 16-byte plane / fp32 stores, residual pieces
+  // requested before the first store, row scales from LDS. (Until round 4 this kernel stored straight from the MFMA result
+  // layout: two-byte plane stores and four-byte loads, 64 of each per 32 x 32 block.)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  h2_epilogue_256<FULL, TM, TN, WM, WN, BM, BN>(g, acc, smem, wave, lane_e, bm, bn, wm, wn, g.row_ssq ? rs_tile : nullptr, acc_scale);
 }
 
 // ---- shared epilogue of the 256x256 kernels: transpose through LDS, then row-wise 16-byte global accesses --
@@ -339,10 +294,10 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 // One strip (64 rows of a wave's 128 x 64 outputs) of the epilogue below. The strip index is a template parameter: the
 // accumulators are indexed with it, and a strip loop the compiler declines to unroll — it did once the output paths had
 // grown — puts all 128 of them into scratch.
-template <bool FULL, int TM, int TN, int WM, int WN, int strip>
+template <bool FULL, int TM, int TN, int WM, int WN, int strip, int BM = 256, int BN = 256>
 __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&acc)[TM][TN], float* stg, int lane, int bm, int bn,
                                                   int wm, int wn, const float* rs_tile, float acc_scale, int Mlim) {
-  constexpr int BM = 256, BN = 256, SH = 64, SW = TN * 32;
+  constexpr int SH = 64, SW = TN * 32;
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
     for (int ii = 0; ii < SH / 32; ++ii)
@@ -504,11 +459,11 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
 }
 
-template <bool FULL, int TM, int TN, int WM, int WN>
+template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
                                                 int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
                                                 float acc_scale) {
-  constexpr int BM = 256, BN = 256, SH = 64;
+  constexpr int SH = 64;
   // The MFMA C layout gives a lane one column and 16 scattered rows per tile, so a direct epilogue is
   // 128 dword stores (+128 dword residual loads) per lane in 16-load batches, each batch exposing a full
   // memory latency: ~12 us per tile without and ~30 us with the residual, against ~55 us of K-loop at
@@ -525,10 +480,10 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   constexpr int NS = TM * 32 / SH;                    // strips per wave
   float* stg = reinterpret_cast<float*>(smem) + wave * (SH * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
-  static_assert(NS == 2, "two strips of 64 rows per wave");
+  static_assert(NS == 1 || NS == 2, "one or two strips of 64 rows per wave");
   (void)ncol; (void)rsub;
-  h2_epilogue_strip<FULL, TM, TN, WM, WN, 0>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
-  h2_epilogue_strip<FULL, TM, TN, WM, WN, 1>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
+  h2_epilogue_strip<FULL, TM, TN, WM, WN, 0, BM, BN>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
+  if (NS == 2) h2_epilogue_strip<FULL, TM, TN, WM, WN, NS - 1, BM, BN>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
 }
 
 // ---- ping-pong 256x256 variant -------------------------------------------------------------------------
