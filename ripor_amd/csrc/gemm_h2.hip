@@ -994,6 +994,60 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmH2Args g, cons
   }
 }
 
+// The same epilogue with FOUR consecutive columns per thread (N % 256 == 0: a wave is 256 consecutive columns of one row):
+// 16-byte loads of the partials, 8-byte plane stores / 16-byte fp32 stores instead of one element per thread (2-byte plane
+// stores). Per element the same arithmetic in the same order; the row sums of squares add four columns before the wave's
+// butterfly.
+__global__ __launch_bounds__(256) void splitk_epilogue4_kernel(GemmH2Args g, const float* __restrict__ part, int ks, size_t stride) {
+  const size_t idx4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = g.N >> 2;
+  if (idx4 >= (size_t)g.M * n4) return;                  // N % 256 == 0: a wave is inside or outside as a whole
+  const int m = (int)(idx4 / n4), n = (int)(idx4 - (size_t)m * n4) * 4;
+  const size_t idx = (size_t)m * g.N + n;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < ks; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + idx);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
+  const float rsc = g.row_ssq ? ssq_rsqrt(g.row_ssq[m], g.inv_d_fix, g.eps) : 1.0f;
+  float v[4] = {a.x * acc_scale, a.y * acc_scale, a.z * acc_scale, a.w * acc_scale};
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.resid) { const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n); r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; }
+  if (g.resid_h) {
+    const uint2 hh = *reinterpret_cast<const uint2*>(g.resid_h + (size_t)m * g.ldrh + n);
+    const uint2 ll = *reinterpret_cast<const uint2*>(g.resid_h + g.r_ps + (size_t)m * g.ldrh + n);
+    const __half* h = reinterpret_cast<const __half*>(&hh); const __half* l = reinterpret_cast<const __half*>(&ll);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = x_from_planes(h[e], l[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (g.row_ssq) v[e] *= rsc;
+    if (g.relu) v[e] = fmaxf(v[e], 0.f);
+    if (g.resid || g.resid_h) v[e] = r[e] + v[e];
+  }
+  if (g.out_h) {
+    __half hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      split_f16(v[e] * g.plane_scale, hi[e], lo[e], g.sat);
+      v[e] = (__half2float(hi[e]) + __half2float(lo[e])) / g.plane_scale;   // the value the planes carry (row sums below)
+    }
+    *reinterpret_cast<uint2*>(g.out_h + (size_t)m * g.ldoh + n) = *reinterpret_cast<uint2*>(hi);
+    *reinterpret_cast<uint2*>(g.out_h + g.o_ps + (size_t)m * g.ldoh + n) = *reinterpret_cast<uint2*>(lo);
+  } else {
+    const int oi = n / g.split_n, on = n - oi * g.split_n;
+    *reinterpret_cast<float4*>(g.out[oi] + out_off(g, oi, m, g.ldo[oi], on)) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (g.ssq_out) {   // grid-uniform branch: all 64 lanes of the wave hold columns of row m
+    float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+  }
+}
+
 // Split-K through the 256x256 ping-pong kernel (weight gradients of the training step: dW[N, K] = dY^T X reduces over the
 // 8192 rows of the batch into 9 .. 36 output tiles): blockIdx.y = K range, partial tiles to the caller's scratch,
 // splitk_reduce_kernel adds them in split order (bitwise reproducible). Returns hipErrorNotSupported when the shape does
@@ -1144,7 +1198,10 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
       hipError_t e = launch_cfg<128, 64>(p, s);
       if (e != hipSuccess) return e;
       const size_t n = (size_t)a.M * a.N;
-      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, a.part, (int)ks, p.part_stride);
+      const bool vec4 = (a.N & 255) == 0 && (a.split_n & 3) == 0 && (a.ldo[0] & 3) == 0 && (a.ldo[1] & 3) == 0 && (a.ldo[2] & 3) == 0 &&
+                        (!a.resid || (a.ldr & 3) == 0) && (!a.resid_h || (a.ldrh & 3) == 0) && (!a.out_h || (a.ldoh & 3) == 0);
+      if (vec4) hipLaunchKernelGGL(splitk_epilogue4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a, a.part, (int)ks, p.part_stride);
+      else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, a.part, (int)ks, p.part_stride);
       return hipGetLastError();
     }
   }
