@@ -121,35 +121,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
 #undef RPR_GLOAD
 #undef RPR_LSTORE
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue: the MFMA result layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of a 32 x 32 block) is
+  // transposed through a private LDS strip per wave (the operand buffers are free) and leaves row-wise: a lane handles
+  // 16-byte pieces, every residual piece is requested before the first store (vmcnt counts loads and stores alike: a load
+  // waited for with stores in flight is a write-acknowledge round trip). Straight from the registers a 64 x 64 wave tile was
+  // 64 four-byte store instructions per 32 x 32 block and as many residual loads, batch by batch behind the stores before
+  // them (the epilogue all split-precision kernels had until round 4; gemm_h2.hip).
+  constexpr int SH = BM / 2, SW = BN / 2;                 // the wave's outputs: rows x columns
+  static_assert((size_t)BM * BN <= 2 * TILE, "the strips of the four waves fit the operand buffers");
+  __syncthreads();                                        // every wave is done reading operand tiles
+  float* stg = smem + (size_t)wave * (SH * SW);
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn + wn * (BN / 2) + j * 32 + ncol;
-    if (!FULL && n >= g.N) continue;
-    const int oi = n / g.split_n, on = n - oi * g.split_n;
-    float* outp = g.out[oi];
-    const int ldo = g.ldo[oi];
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mbase = bm + wm * (BM / 2) + i * 32 + rsub;
-      float res[16];
-      if (g.resid) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          res[r] = (FULL || m < g.M) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
-        }
-      }
+      for (int r = 0; r < 16; ++r) stg[(i * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SW + j * 32 + ncol] = acc[i][j][r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  constexpr int LPR = SW / 4, RPI = 64 / LPR, NK = SH / RPI;   // lanes per staged row, rows per instruction, instructions
+  const int rrow = lane / LPR, rc4 = (lane % LPR) * 4;
+  const int mrow0 = bm + wm * SH, n0 = bn + wn * SW + rc4;      // this lane's 4 consecutive output columns (N % 4 == 0)
+  const bool ncol_ok = FULL || n0 < g.N;
+  const int oi = ncol_ok ? n0 / g.split_n : 0, on = n0 - oi * g.split_n;   // split_n % 4 == 0: the 4 columns share an output
+  float* outp = oi == 0 ? g.out[0] : oi == 1 ? g.out[1] : g.out[2];
+  const int ldo = oi == 0 ? g.ldo[0] : oi == 1 ? g.ldo[1] : g.ldo[2];
+  const float relu_lo = g.relu ? 0.f : -INFINITY;
+  float4 res[NK];
+  if (g.resid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (FULL || m < g.M) {
-          float v = acc[i][j][r];
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.resid) v = res[r] + v;
-          outp[out_off(g, oi, m, ldo, on)] = v;
-        }
+    for (int k = 0; k < NK; ++k) {   // clamped, unconditional loads
+      const int m = min(mrow0 + k * RPI + rrow, g.M - 1), nc = (FULL || n0 + 3 < g.N) ? n0 : 0;   // (N % 4 == 0 with a residual)
+      res[k] = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + nc);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int rl = k * RPI + rrow, m = mrow0 + rl;
+    float4 v = *reinterpret_cast<const float4*>(stg + rl * SW + rc4);
+    v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+    if (g.resid) { v.x = res[k].x + v.x; v.y = res[k].y + v.y; v.z = res[k].z + v.z; v.w = res[k].w + v.w; }
+    if (ncol_ok && (FULL || m < g.M)) {
+      float* o = outp + out_off(g, oi, m, ldo, on);
+      if ((FULL || n0 + 3 < g.N) && (ldo & 3) == 0) *reinterpret_cast<float4*>(o) = v;
+      else {   // a decoder vocab size off the 4 grid in exact-fp32 mode (N, and possibly the row stride, not a multiple of 4):
+               // column by column
+        o[0] = v.x;
+        if (FULL || n0 + 1 < g.N) o[1] = v.y;
+        if (FULL || n0 + 2 < g.N) o[2] = v.z;
+        if (FULL || n0 + 3 < g.N) o[3] = v.w;
       }
     }
   }
@@ -169,6 +190,11 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % BK != 0 || a.K <= 0 || (a.lda & 3) || (a.ldw & 3)) return hipErrorInvalidValue;
+  // the epilogue stores 16-byte pieces where it can: with several outputs or a residual four consecutive columns must
+  // belong to one output and be 16-byte aligned in it (a single output with an odd width / row stride is stored by column)
+  if ((a.resid && ((a.N & 3) || (a.ldr & 3))) || (a.split_n < a.N && ((a.split_n & 3) || (a.ldo[0] & 3) || (a.ldo[1] & 3) || (a.ldo[2] & 3))) ||
+      (a.rm_B && ((a.rm_stride & 3) || (a.rm_slot & 3) || (a.rm_head & 3))))
+    return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   // 128x128 tiles unless that leaves the 256 CUs with less than ~1.5 blocks each
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
