@@ -118,13 +118,10 @@ int tensure(rpr_ctx* c, DevBuf& b, size_t bytes) {   // like ensure(), without t
 
 inline int pad32(int n) { return (n + 31) & ~31; }
 inline int pad64(int n) { return (n + 63) & ~63; }
-// row stride (elements) of the transposed bf16 operands [cols][pad64(rows)] of the weight-gradient products. RPR_TRAIN_XT_PAD=n
-// pads it by n elements: a stride of 8192 rows = 16 KB looked like a memory-channel hazard for the K-tiles (128-byte pieces
-// of 256 rows), but measured no different (27.4 ms per step unpadded, 27.6 with 64, 28.3 with 32): the default is unpadded.
-inline int ldT(int rows) {
-  static const int pad = [] { const char* e = getenv("RPR_TRAIN_XT_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v + 7) & ~7; }();
-  return pad64(rows) + pad;
-}
+// row stride (elements) of the transposed bf16 operands [cols][pad64(rows)] of the weight-gradient products. (Padding it off
+// the power of two — 8192 rows = 16 KB looked like a memory-channel hazard for K-tiles that are 128-byte pieces of 256 rows —
+// measured no different: 27.4 ms per step unpadded, 27.6 with 64 elements, 28.3 with 32; HISTORY.md.)
+inline int ldT(int rows) { return pad64(rows); }
 
 struct Dims {
   int bz, Lq, L, S, R, T, dm, inner, dff, H, ne, nd, V, xld, buckets;
