@@ -412,7 +412,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         DecCrossAttnArgs a{qb, xk, xk + inner, xld, sv.io.mask, attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
                            sv.io.last, sv.io.offs, 0, c->status, sv.nq_dev};
         Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ma * H * (double)Lq * DKV,
-               4.0 * ((double)Ma * inner * 2 + 2.0 * (Ma / Bt) * (double)Lq * inner), [&] { return launch_dec_cross_attn(a, s); });
+               4.0 * ((double)Ma * inner * 2 + 2.0 * (Ma / Bt) * (double)Lq * inner), [&] { return launch_step_cross_attn(a, s); });
       }
       linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
       if (!h2) norm(m->dec_ln2[i]);

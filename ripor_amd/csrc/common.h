@@ -210,6 +210,8 @@ struct EncAttnArgs {
                            //   forward; the search encoder keeps the summation order of enc_attn_kernel)
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
+// tail_kernels.hip: the search encoder's attention (<= 32 positions) on the fp32-MFMA tile; false = shape not taken
+bool launch_enc_attn_mfma_v2(const EncAttnArgs& a, hipStream_t s, hipError_t* err);
 // training forward, Lq <= 32, padded layout, fp32 output: one wave per (sequence, head) on fp32 MFMA tiles (tail_kernels.hip)
 hipError_t launch_train_self_attn_mfma(const EncAttnArgs& a, hipStream_t s);
 // its backward (Ls <= 32): dqkv and the per-(sequence, head) bias-gradient parts, as self_attn_bwd_kernel writes them
@@ -372,6 +374,8 @@ struct TailSelfAttnArgs {
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s);
 // cross-attention of the tail rows (a.B = rows per query): fp32-MFMA tiles for Lq <= 64, else the block kernel
 hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
+// cross-attention of a sequential step (a.B = beams per query): the MFMA tile kernel for Lq <= 32, else the block kernel
+hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 // gold[row] = <final RMSNorm of the row's stream (x post), E_out[p][token p]>, exact fp32 (as launch_gold_scores)
 hipError_t launch_tail_gold(const float* x, const float* ln, const float* out_embeds, const uint16_t* tokens, float* gold, int rows,
                             const int* rows_dev, int T, int L, int d, int V, float eps, float post, hipStream_t s,

@@ -259,6 +259,7 @@ hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
   static const bool mfma_off = [] { const char* e = getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (a.mfma && !mfma_off && a.Lq <= 32 && !a.offs && !a.out_h) return launch_train_self_attn_mfma(a, s);
+  if (!a.mfma) { hipError_t e; if (launch_enc_attn_mfma_v2(a, s, &e)) return e; }
   hipLaunchKernelGGL(enc_attn_kernel, dim3(a.Q * a.H), dim3(256), enc_attn_smem(a.Lq), s, a);
   return hipGetLastError();
 }

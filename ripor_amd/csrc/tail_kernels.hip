@@ -516,15 +516,440 @@ __global__ __launch_bounds__(256, 4) void tail_cross_attn_mfma_kernel(DecCrossAt
   store_o_tile(o, Vs, lane, i0, nrows, row_base, inner, h * DKV, a.out, a.out_h, a.o_ps, a.sat);
 }
 
+// ---- second generation of the fp32-MFMA attention tiles ----------------------------------------------------------------
+// On half of the chip (a lane of the search) the first generation is bound by instruction issue, not by memory: a wave
+// spends ~1300 VALU instructions (x 4 cycles) beside its 64 MFMAs (x 64 cycles) — per-lane 64-bit address arithmetic
+// (the wave index came from threadIdx, so nothing was known to be uniform), a branch and a flag store per value in the
+// plane split, V staged through LDS with its own address math, mask and bias applied value by value — and runs two waves
+// per SIMD (162 VGPRs). tools/tail_attn_probe.hip on 128 CUs: self 1503 us for 3.96 GB, cross 1009 us for 1.93 GB.
+// This generation produces the same bits with a fraction of the instructions:
+//  * the wave index goes through v_readfirstlane: sequence, head, query and every base pointer are scalars (SALU), the
+//    loads take the scalar-base + 32-bit-offset form;
+//  * V goes straight into the B operand of P.V (lane = (d, key slot): d is the contiguous index of a V row, 128
+//    contiguous bytes per lane half and instruction) — no LDS staging, no fragment reads;
+//  * the plane split is branch-free (one saturation test per lane at the end);
+//  * cross-attention: a wave keeps K and V of its (query, head) in registers and walks up to TPW row tiles; the key mask is
+//    the C operand of the first score MFMA (-inf + x = -inf), P.V skips the key slots beyond the query's length (a
+//    12-token query uses 8 of 16), K and the Q tiles come through LDS-DMA (global_load_lds_dwordx4: whole 256-byte row
+//    slices into an XOR-swizzled strip, conflict-free ds_read_b128 operand reads) with the next tile's Q in flight under
+//    the current tile's products.
+// x / d for a scalar x by multiplication: magic = 2^32 / d + 1 (host: div_magic), exact for x < 2^32 / d; d = 1 has no
+// 32-bit magic
+__device__ __forceinline__ int udiv_magic(unsigned x, int d, unsigned magic) { return d == 1 ? (int)x : (int)__umulhi(x, magic); }
+static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
+
+__device__ __forceinline__ void dma_rows16(const float* src, float* lds_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+}
+
+// operand pieces of this lane's row out of a swizzled strip: piece 2c + half of row `row` sits in slot piece ^ (row & 15)
+__device__ __forceinline__ void read_row_pieces(const float* strip, int row, int half, float4 (&r)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    r[c] = *reinterpret_cast<const float4*>(strip + row * 64 + (((2 * c + half) ^ (row & 15)) << 2));
+}
+
+// scores with the C operand of the first product given (zeros, or the additive key mask)
+__device__ __forceinline__ f32x16 mfma_scores_c(const float4 (&k)[8], const float4 (&q)[8], const f32x16& c0) {
+  f32x16 s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[0].x, q[0].x, c0, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[0].y, q[0].y, s, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[0].z, q[0].z, s, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[0].w, q[0].w, s, 0, 0, 0);
+#pragma unroll
+  for (int c = 1; c < 8; ++c) {
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].x, q[c].x, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].y, q[c].y, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].z, q[c].z, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k[c].w, q[c].w, s, 0, 0, 0);
+  }
+  return s;
+}
+
+__device__ __forceinline__ void mfma_pv_regs(const f32x16& p, const float (&v0)[16], const float (&v1)[16], int kk_end, f32x16 (&o)[2]) {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[0], v0[0], z, 0, 0, 0);
+  o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[0], v1[0], z, 0, 0, 0);
+#pragma unroll
+  for (int kk = 1; kk < 16; ++kk) {
+    if (kk < kk_end) {   // wave-uniform
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kk], v0[kk], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kk], v1[kk], o[1], 0, 0, 0);
+    }
+  }
+}
+
+// split_f16 of eight values, two at a time (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32) and without its branch: the
+// same planes for every input; lanes with a value outside the f16 range (or NaN) are collected in `bad` (a wave mask: SALU)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo, unsigned long long& bad) {
+  const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+  f16x2 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f32x2 v = x[e] * A_PLANE_SCALE;
+    bad |= __ballot(!(fabsf(v.x) <= 65504.f)) | __ballot(!(fabsf(v.y) <= 65504.f));
+    v.x = fminf(fmaxf(v.x, -65504.f), 65504.f);
+    v.y = fminf(fmaxf(v.y, -65504.f), 65504.f);
+    h[e] = __builtin_convertvector(v, f16x2);
+    l[e] = __builtin_convertvector(v - __builtin_convertvector(h[e], f32x2), f16x2);
+  }
+  hi = *reinterpret_cast<uint4*>(h); lo = *reinterpret_cast<uint4*>(l);
+}
+
+// store_o_tile with a scalar tile base (out_t / out_h_t point at row i0, column hcol of the head) and 32-bit offsets
+__device__ __forceinline__ void store_o_tile_v2(const f32x16 (&o)[2], float* strip, int lane, int nlive, int inner, float* out_t,
+                                                __half* out_h_t, size_t o_ps, unsigned long long& bad) {
+  const int d = lane & 31, half = lane >> 5;
+  __builtin_amdgcn_wave_barrier();
+  float* wr = strip + (4 * half) * 64 + d;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2);
+    wr[i * 64] = o[0][r];
+    wr[i * 64 + 32] = o[1][r];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = (lane & 7) * 8, il0 = lane >> 3;
+  const float* rd = strip + il0 * 64 + c8;
+  const int off0 = il0 * inner + c8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k * 8 + il0 < nlive) {                           // 8 rows per pass, 8 lanes per row
+      const float4 x0 = *reinterpret_cast<const float4*>(rd + k * 8 * 64);
+      const float4 x1 = *reinterpret_cast<const float4*>(rd + k * 8 * 64 + 4);
+      const int off = off0 + k * 8 * inner;
+      if (out_h_t) {
+        uint4 hi, lo;
+        split8(x0, x1, hi, lo, bad);
+        *reinterpret_cast<uint4*>(out_h_t + off) = hi;
+        *reinterpret_cast<uint4*>(out_h_t + o_ps + off) = lo;
+      } else {
+        *reinterpret_cast<float4*>(out_t + off) = x0;
+        *reinterpret_cast<float4*>(out_t + off + 4) = x1;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// expf(x) for x <= 0 (or -inf, or NaN): the library's algorithm — 2^(x log2 e) with a two-term product, v_exp_f32 of the
+// fraction, v_ldexp_f32 — without its overflow branch and with the underflow cut as the only select; same bits as expf.
+__device__ __forceinline__ float exp_nonpos(float x) {
+#pragma clang fp contract(off)   // ph - n must stay a subtraction of the ROUNDED product (contracted into an fma it is a different number)
+  const float C = __uint_as_float(0x3fb8aa3bu), CL = __uint_as_float(0x32a5705fu), THR = __uint_as_float(0xc2ce8ed0u);
+  const float ph = x * C;
+  float t = fmaf(x, C, -ph);
+  const float n = rintf(ph);
+  t = fmaf(x, CL, t);
+  const float r = (ph - n) + t;
+  const float y = ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+  return !(THR > x) ? y : 0.f;
+}
+
+// softmax_rows<1> with exp_nonpos (a masked score is -inf: x = -inf - max falls under the cut; at least one key of a row
+// is attended wherever this is called). Registers r >= r_end (wave-uniform, a multiple of 4) hold masked keys only: their
+// probability is 0 without an exponential.
+__device__ __forceinline__ void softmax_row16(f32x16& s, int r_end = 16) {
+  float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+  for (int q4 = 1; q4 < 4; ++q4)
+    if (q4 * 4 < r_end) mx = fmaxf(mx, fmaxf(fmaxf(s[q4 * 4], s[q4 * 4 + 1]), fmaxf(s[q4 * 4 + 2], s[q4 * 4 + 3])));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    if (q4 * 4 < r_end) {
+#pragma unroll
+      for (int r = q4 * 4; r < q4 * 4 + 4; ++r) {
+        const float e = exp_nonpos(s[r] - mx);
+        s[r] = e;
+        sum += e;
+      }
+    } else {
+#pragma unroll
+      for (int r = q4 * 4; r < q4 * 4 + 4; ++r) s[r] = 0.f;
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] *= inv;
+}
+
+// Tail self-attention for L = 32 and a fork depth T <= 8 (every search of the bench's kind; other shapes take the first
+// generation): one wave per (sequence, head); block = four heads of one sequence (blockIdx.x = sequence * HB + head
+// block, divided by multiplication). Per wave: one 8-KB strip — the reversed bias table, then the output tile. No
+// branches: every address is valid (rows of the padding lanes repeat a live row; their output is not stored).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSelfAttnArgs a, int HB, unsigned hb_magic, unsigned b_magic) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int L = 32;
+  const int H = a.H, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, half = lane >> 5, ln = lane & 31;
+  const int seq = udiv_magic(blockIdx.x, HB, hb_magic);
+  const int h = ((int)blockIdx.x - seq * HB) * 4 + wave;
+  if (h >= H || seq >= *a.nseq_dev) return;              // wave-uniform
+  float* Os = smem + wave * (32 * 64);
+  const int fi = udiv_magic((unsigned)seq, a.B, b_magic), b = seq - fi * a.B;
+  const int qi = a.flist[fi];
+  const uint16_t* ancr = a.anc + ((size_t)qi * a.B + b) * a.anc_ld;
+  const float* kc = a.kcache + (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
+  const float* vc = a.vcache + (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
+  const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * DKV;
+  float4 kreg[8], qreg[8];
+  {
+    const int slot = ancr[ln];                           // defined for positions < T only; the pointer built on it is not used elsewhere
+    const float* kr = ln < T ? kc + (size_t)ln * a.pos_stride + (size_t)slot * a.slot_stride : tbase + (ln - T) * ld + inner;
+    load_row_pieces(kr, half, kreg);
+    load_row_pieces(tbase + min(ln, Lt - 1) * ld, half, qreg);
+  }
+  // bias of distance n = query position - key position, reversed: Os[31 - n]; the mask / bias pass reads Os[31 - pq + j]
+  Os[lane < 32 ? 31 - lane : lane] = lane < 32 ? a.rel_bias[a.bucket[ln] * H + h] : 0.f;
+  float v0[16], v1[16];                                  // V[kappa(kk, half)][d], [d + 32]: the B operand of P.V
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {                       // keys 0..7: cache rows below T
+    const int j = kk + 4 * half;
+    const int slot = ancr[j];
+    const float* vr = j < T ? vc + (size_t)j * a.pos_stride + (size_t)slot * a.slot_stride : tbase + (j - T) * ld + 2 * inner;
+    v0[kk] = vr[ln]; v1[kk] = vr[ln + 32];
+  }
+  {
+    const int voff = 4 * half * ld + ln;
+#pragma unroll
+    for (int kk = 4; kk < 16; ++kk) {                    // keys >= 8 are rows of this pass in both halves
+      const float* sb = tbase + 2 * inner + (kappa(kk, 0) - T) * ld;
+      v0[kk] = sb[voff]; v1[kk] = sb[voff + 32];
+    }
+  }
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 sc = mfma_scores_c(kreg, qreg, z);
+  const int pq = T + min(ln, Lt - 1);
+  {
+    const float* brow = Os + (31 - pq + 4 * half);
+    const int jl = pq - 4 * half;                        // key kappa(r, 0) + 4 half is visible iff kappa(r, 0) <= jl
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j0 = kappa(r, 0);
+      sc[r] = j0 <= jl ? sc[r] + brow[j0] : -INFINITY;
+    }
+  }
+  softmax_row16(sc);
+  f32x16 o[2];
+  mfma_pv_regs(sc, v0, v1, 16, o);
+  unsigned long long bad = 0ull;
+  const size_t obase = (size_t)seq * Lt * inner + h * DKV;
+  store_o_tile_v2(o, Os, lane, Lt, inner, a.out ? a.out + obase : nullptr, a.out_h ? a.out_h + obase : nullptr, a.o_ps, bad);
+  if (bad != 0ull && a.sat && lane == 0) *a.sat = 1u;
+}
+
+// Cross-attention of the tail rows, Lq <= 32: one wave per (query, head, group of TPW row tiles); block = four heads
+// (blockIdx.x = (query * groups + group) * HB + head block). K, V and the key mask of the (query, head) stay in registers
+// for all of the wave's tiles; the next tile's Q rows are requested (into a second register set) before the current
+// tile's products. Per wave: one 8-KB output strip. (A version with K and Q through LDS-DMA strips was no faster: the
+// compiler fences every LDS read behind a pending LDS-DMA with vmcnt(0), which also waits for the tile's stores.)
+template <int TPW, int OCC>
+__global__ __launch_bounds__(256, OCC) void tail_cross_attn_mfma_v2_kernel(DecCrossAttnArgs a, int groups, int HB, unsigned hb_magic,
+                                                                         unsigned g_magic) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, inner = H * DKV, nrows = a.B;       // a.B = rows of one query (beams x tail positions)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, half = lane >> 5, ln = lane & 31;
+  const int qg = udiv_magic(blockIdx.x, HB, hb_magic);    // query * groups + group
+  const int h = ((int)blockIdx.x - qg * HB) * 4 + wave;
+  const int qi = udiv_magic((unsigned)qg, groups, g_magic), grp = qg - qi * groups;
+  if (h >= H || qi >= a.Q || (a.nq_dev && qi >= *a.nq_dev)) return;   // wave-uniform
+  int i0 = grp * TPW * 32;
+  if (i0 >= nrows) return;
+  float* Os = smem + wave * (32 * 64);
+  const int nk = min(a.last[qi], 32);
+  const size_t obase = (size_t)qi * nrows * inner + h * DKV;
+  unsigned long long bad = 0ull;
+  if (nk == 0) {   // query without a single attended token: zeros (as the block kernel; its packed encoder has no rows to read)
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    for (int t = 0; t < TPW && i0 < nrows; ++t, i0 += 32) {
+      const size_t ob = obase + (size_t)i0 * inner;
+      store_o_tile_v2(o, Os, lane, nrows - i0, inner, a.out ? a.out + ob : nullptr, a.out_h ? a.out_h + ob : nullptr, a.o_ps, bad);
+    }
+    return;
+  }
+  const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
+  const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;
+  const float* kb = a.xk + xrow0 * a.xld + h * DKV;
+  const float* vb = a.xv + xrow0 * a.xld + h * DKV;
+  const float* qb = a.q + (size_t)qi * nrows * inner + h * DKV;
+  float4 kreg[8], qreg[8];
+  load_row_pieces(kb + min(ln, nk - 1) * a.xld, half, kreg);          // unattended keys are masked below: any finite row will do
+  // this lane's pieces of row ibase + ln; rows past the end repeat the last one (their output is not stored)
+  auto q_load = [&](int ibase, float4 (&r)[8]) { load_row_pieces(qb + (size_t)ibase * inner + min(ln, nrows - 1 - ibase) * inner, half, r); };
+  q_load(i0, qreg);
+  const bool kok = ln < nk && mrow[min(ln, nk - 1)] != 0;
+  const unsigned okm = (unsigned)(__ballot(kok) & 0xffffffffull);   // bit j: key j is attended
+  // key slots kk >= kk_end hold keys >= nk in both halves (kappa(kk, 1) = kappa(kk, 0) + 4): their P is 0, skip them
+  const int kk_end = nk > 24 ? 16 : nk > 16 ? 12 : nk > 8 ? 8 : 4;
+  float v0[16], v1[16];
+  f32x16 negm;                                            // additive key mask = the C operand of the first score product
+  {
+    const unsigned okh = half ? okm >> 4 : okm;           // key kappa(kk, 0) + 4 half
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      if (q4 * 4 < kk_end) {                              // wave-uniform
+#pragma unroll
+        for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) {
+          const int j0 = kappa(kk, 0);
+          const bool live = (okh >> j0) & 1u;
+          const float* vr = vb + min(j0 + 4 * half, nk - 1) * a.xld;
+          const float x0 = vr[ln], x1 = vr[ln + 32];
+          negm[kk] = live ? 0.f : -INFINITY;
+          v0[kk] = live ? x0 : 0.f; v1[kk] = live ? x1 : 0.f;   // unattended keys: zero rows keep 0 * garbage out of the sum
+        }
+      } else {
+#pragma unroll
+        for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) { negm[kk] = -INFINITY; v0[kk] = 0.f; v1[kk] = 0.f; }
+      }
+    }
+  }
+#pragma unroll 1
+  for (int t = 0; t < TPW; ++t) {
+    const int inext = i0 + 32;
+    const bool more = t + 1 < TPW && inext < nrows;       // wave-uniform
+    float4 qnext[8];
+    if (more) q_load(inext, qnext);                       // next tile's Q rows under this tile's products
+    f32x16 sc = mfma_scores_c(kreg, qreg, negm);
+    softmax_row16(sc, kk_end);
+    f32x16 o[2];
+    mfma_pv_regs(sc, v0, v1, kk_end, o);
+    const size_t ob = obase + (size_t)i0 * inner;
+    store_o_tile_v2(o, Os, lane, nrows - i0, inner, a.out ? a.out + ob : nullptr, a.out_h ? a.out_h + ob : nullptr, a.o_ps, bad);
+    if (!more) break;
+    i0 = inext;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qreg[c] = qnext[c];
+  }
+  if (bad != 0ull && a.sat && lane == 0) *a.sat = 1u;
+}
+
+// Encoder self-attention of the search (bidirectional bias, key padding mask, packed or padded rows, <= 32 positions) on
+// the same tile: one wave per (query, head). The VALU block kernel (enc_attn_kernel: 64 v_readlane + 64 LDS reads + 64
+// FMAs per query row, half of the lanes idle at <= 32 keys) took 226 us per layer for a lane's 1075 packed queries.
+__global__ __launch_bounds__(256, 4) void enc_attn_mfma_v2_kernel(EncAttnArgs a, int HB, unsigned hb_magic) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, inner = H * DKV, ld = 3 * inner;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, half = lane >> 5, ln = lane & 31;
+  const int qi = udiv_magic(blockIdx.x, HB, hb_magic);
+  const int h = ((int)blockIdx.x - qi * HB) * 4 + wave;
+  if (h >= H) return;                                     // wave-uniform
+  const int nrow = a.offs ? a.lens[qi] : a.Lq;
+  if (nrow == 0) return;                                  // a query without a token has no rows
+  const size_t row0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;
+  const float* base = a.qkv + row0 * ld + h * DKV;
+  float* Os = smem + wave * (32 * 64);
+  const int lnc = min(ln, nrow - 1);                      // padding lanes repeat the last row (masked as keys, not stored as rows)
+  float4 kreg[8], qreg[8];
+  load_row_pieces(base + lnc * ld + inner, half, kreg);
+  load_row_pieces(base + lnc * ld, half, qreg);
+  // bias of rel = key - query in [-31, 31]: Os[rel + 31]
+  Os[lane] = lane < 63 ? a.rel_bias[a.bucket[lane - 31 + (MAX_LQ - 1)] * H + h] : 0.f;
+  const bool kok = ln < nrow && a.mask[(size_t)qi * a.Lq + lnc] != 0;
+  const unsigned okm = (unsigned)(__ballot(kok) & 0xffffffffull);   // bit j: key j is attended
+  const unsigned okh = half ? okm >> 4 : okm;             // key kappa(kk, 0) + 4 half
+  const int kk_end = nrow > 24 ? 16 : nrow > 16 ? 12 : nrow > 8 ? 8 : 4;
+  float v0[16], v1[16];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    if (q4 * 4 < kk_end) {                                // wave-uniform
+#pragma unroll
+      for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) {
+        const int j0 = kappa(kk, 0);
+        const float* vr = base + min(j0 + 4 * half, nrow - 1) * ld + 2 * inner;
+        const float x0 = vr[ln], x1 = vr[ln + 32];
+        const bool live = (okh >> j0) & 1u;
+        v0[kk] = live ? x0 : 0.f; v1[kk] = live ? x1 : 0.f;   // unattended keys: zero rows keep 0 * garbage out of the sum
+      }
+    } else {
+#pragma unroll
+      for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) { v0[kk] = 0.f; v1[kk] = 0.f; }
+    }
+  }
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 sc = mfma_scores_c(kreg, qreg, z);
+  {
+    const float* brow = Os + (31 - lnc + 4 * half);       // key j = kappa(r, 0) + 4 half: rel + 31 = j - i + 31
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j0 = kappa(r, 0);
+      sc[r] = ((okh >> j0) & 1u) ? sc[r] + brow[j0] : -INFINITY;
+    }
+  }
+  softmax_row16(sc, kk_end);
+  f32x16 o[2];
+  mfma_pv_regs(sc, v0, v1, kk_end, o);
+  unsigned long long bad = 0ull;
+  const size_t obase = row0 * inner + h * DKV;
+  store_o_tile_v2(o, Os, lane, nrow, inner, a.out ? a.out + obase : nullptr, a.out_h ? a.out_h + obase : nullptr, a.o_ps, bad);
+  if (bad != 0ull && a.sat && lane == 0) *a.sat = 1u;
+}
+
+// Which generation of the fp32-MFMA tail attention runs: 1 = direct K / Q loads and V through LDS, 2 = K (and Q) through
+// LDS-DMA, V direct (bit-identical results). RPR_TAIL_ATTN_GEN; tools/tail_attn_probe.hip switches it per launch.
+int g_tail_attn_gen = [] { const char* e = getenv("RPR_TAIL_ATTN_GEN"); return e ? atoi(e) : 2; }();
+int g_tail_attn_opt = [] { const char* e = getenv("RPR_TAIL_ATTN_OPT"); return e ? atoi(e) : 0; }();
+int g_tail_cross_tpw = [] { const char* e = getenv("RPR_TAIL_CROSS_TPW"); return e ? atoi(e) : 0; }();   // 0 = by size
+
+// the search encoder's attention on the MFMA tile (launch_enc_attn asks); false = not taken
+bool launch_enc_attn_mfma_v2(const EncAttnArgs& a, hipStream_t s, hipError_t* err) {
+  static const bool on = [] { const char* e = getenv("RPR_ENC_ATTN_MFMA"); return !e || atoi(e) != 0; }();
+  const int HB = (a.H + 3) / 4;
+  if (!on || g_tail_attn_gen != 2 || a.causal || !a.mask || a.Lq > 32 || a.buckets > 64 || (long)a.Q * HB >= (1l << 31) / HB) return false;
+  hipLaunchKernelGGL(enc_attn_mfma_v2_kernel, dim3((unsigned)(a.Q * HB)), dim3(256), 4 * (32 * 64) * sizeof(float), s, a, HB, div_magic(HB));
+  *err = hipGetLastError();
+  return true;
+}
+
 hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   static const bool off = [] { const char* e = getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (off || a.Lq > 64) return launch_dec_cross_attn(a, s);   // long queries: the block kernel (any Lq <= 256)
   const int tiles = (a.B + 31) / 32;
+  if (g_tail_attn_gen == 2 && a.Lq <= 32) {
+    // tiles per wave: many tiles -> a wave keeps K / V for nine of them (fewer, longer waves: better on a lane's half of
+    // the chip); few -> one tile per wave (more waves to fill the chip)
+    const int want = g_tail_cross_tpw > 0 ? g_tail_cross_tpw : ((long)a.Q * a.H * tiles >= 32768 ? 9 : 1);
+    const int tpw = want >= 9 ? 9 : want >= 3 ? 3 : 1;
+    const int groups = (tiles + tpw - 1) / tpw, HB = (a.H + 3) / 4;
+    const long blocks = (long)a.Q * groups * HB;
+    if (blocks < (1l << 31) / HB && (long)a.Q * groups < (1l << 32) / groups && (long)a.B * a.H * DKV < (1l << 29)) {   // udiv_magic / 32-bit offsets
+      const dim3 grid((unsigned)blocks), blk(256);
+      const size_t smem = 4 * (32 * 64) * sizeof(float);
+      const unsigned hm = div_magic(HB), gm = div_magic(groups);
+      const bool o3 = g_tail_attn_opt & 2;
+      if (tpw == 9 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<9, 3>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      else if (tpw == 9) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<9, 2>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      else if (tpw == 3 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<3, 3>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      else if (tpw == 3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<3, 2>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      else hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<1, 4>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      return hipGetLastError();
+    }
+  }
   const long waves = (long)a.Q * a.H * tiles;
   const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
   if (a.Lq <= 32) hipLaunchKernelGGL(tail_cross_attn_mfma_kernel<1>, grid, blk, 4 * 32 * 64 * sizeof(float), s, a, tiles);
   else hipLaunchKernelGGL(tail_cross_attn_mfma_kernel<2>, grid, blk, 4 * 64 * 64 * sizeof(float), s, a, tiles);
   return hipGetLastError();
+}
+
+// Cross-attention of a sequential step (a.B = the beams of a query). RPR_STEP_CROSS_MFMA=1 sends it to the fp32-MFMA tile
+// kernel (one wave per (query, head), the B rows in one 32-row tile) instead of the VALU block kernel: measured neutral at
+// beam 10 on the headline (4969-4974 vs 4983 queries/s same-box, 10 of a tile's 32 rows are live), so the block kernel
+// stays the default.
+hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("RPR_STEP_CROSS_MFMA"); return e && atoi(e) != 0; }();
+  if (on && g_tail_attn_gen == 2 && a.Lq <= 32) return launch_tail_cross_attn(a, s);
+  return launch_dec_cross_attn(a, s);
 }
 
 // Self-attention of the training forward (teacher-forced decoder: causal, bias by distance i - j; encoder: key padding
@@ -768,6 +1193,17 @@ hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
     const long waves = (long)a.nseq_cap * a.H;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     static const int occ = [] { const char* e = getenv("RPR_TAIL_ATTN_OCC"); return e ? atoi(e) : 2; }();
+    if (g_tail_attn_gen == 2 && a.L == 32 && a.T <= 8 && a.anc_ld >= 32) {
+      const int HB = (a.H + 3) / 4;
+      const long blocks = (long)a.nseq_cap * HB;
+      if (blocks < (1l << 31) / HB && (long)a.nseq_cap < (1l << 32) / a.B) {   // udiv_magic's exact range
+        const dim3 g2((unsigned)blocks);
+        const unsigned hm = div_magic(HB), bm = div_magic(a.B);
+        if (g_tail_attn_opt & 1) hipLaunchKernelGGL(tail_self_attn_mfma_v2_kernel<3>, g2, blk, 4 * (32 * 64) * sizeof(float), s, a, HB, hm, bm);
+        else hipLaunchKernelGGL(tail_self_attn_mfma_v2_kernel<4>, g2, blk, 4 * (32 * 64) * sizeof(float), s, a, HB, hm, bm);
+        return hipGetLastError();
+      }
+    }
     if (a.L <= 32 && occ == 3) hipLaunchKernelGGL((tail_self_attn_mfma_kernel<1, 3>), grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
     else if (a.L <= 32) hipLaunchKernelGGL(tail_self_attn_mfma_kernel<1>, grid, blk, 4 * (32 * 64 + 64) * sizeof(float), s, a);
     else hipLaunchKernelGGL(tail_self_attn_mfma_kernel<2>, grid, blk, 4 * (64 * 64 + 64 + 32 * 64) * sizeof(float), s, a);
