@@ -1,0 +1,49 @@
+"""The second-generation fp32-MFMA attention kernels (tail self / cross attention, search encoder attention;
+ripor_amd/csrc/tail_kernels.hip) against the kernels they replace, through the product path: the same searches in
+subprocesses that differ only in RPR_TAIL_ATTN_GEN / RPR_ENC_ATTN_MFMA / RPR_STEP_CROSS_MFMA (read once, when the library
+loads). The tail kernels issue the same MFMAs in the same order and must give the same bits; the encoder and the step
+cross-attention move from VALU sums to MFMA sums (fp32 rounding order changes): same ranked smtids, scores within 1e-5.
+Reference semantics: T5Attention inside t5_pretrainer/modeling/t5_generative_retriever.py (softmax(QK^T + bias) V in fp32)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _dump(tmp_path, name, beams, **env):
+    out = str(tmp_path / (name + ".npz"))
+    e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), **{k: str(v) for k, v in env.items()})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "attn_gen_dump.py"), out, str(beams)], cwd=REPO, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("beams", [10, 33])
+def test_tail_attention_generations_give_the_same_bits(tmp_path, beams):
+    old = _dump(tmp_path, "gen1", beams, RPR_TAIL_ATTN_GEN=1, RPR_ENC_ATTN_MFMA=0)
+    new = _dump(tmp_path, "gen2", beams, RPR_TAIL_ATTN_GEN=2, RPR_ENC_ATTN_MFMA=0)
+    assert old["auto_forks"].size and old["auto_forks"][:, 1].sum() > 0, "no query went through the tail pass"
+    for k in old:
+        assert old[k].shape == new[k].shape and old[k].tobytes() == new[k].tobytes(), k
+    for k in ("fork3", "fork5_7"):     # explicit forks inside the kernels' range (T <= 8) were taken
+        assert new[k + "_forks"][:, 1].sum() > 0, k
+
+
+def test_encoder_and_step_cross_attention_on_the_mfma_tile(tmp_path):
+    old = _dump(tmp_path, "valu", 10, RPR_ENC_ATTN_MFMA=0, RPR_STEP_CROSS_MFMA=0)
+    enc = _dump(tmp_path, "enc", 10, RPR_ENC_ATTN_MFMA=1, RPR_STEP_CROSS_MFMA=0)
+    both = _dump(tmp_path, "both", 10, RPR_ENC_ATTN_MFMA=1, RPR_STEP_CROSS_MFMA=1)
+    live = old["mask"] != 0
+    for new in (enc, both):
+        err = np.abs(new["encoder_out"] - old["encoder_out"])[live].max()
+        assert err < 2e-5, err
+        for k in ("auto", "fork3", "fork5_7"):
+            assert (new[k + "_tokens"] == old[k + "_tokens"]).all(), k
+            assert np.abs(new[k + "_scores"] - old[k + "_scores"]).max() < 1e-5, k
+    assert not np.array_equal(enc["encoder_out"], old["encoder_out"]), "the MFMA encoder attention did not run"
