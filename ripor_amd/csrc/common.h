@@ -233,6 +233,7 @@ struct DecSelfAttnArgs {
   __half* out_h; size_t o_ps;
   unsigned int* sat;
   const int* nq_dev;       // nullable: live query count on the device (compacted stage); queries past it are skipped
+  unsigned b_magic = 0, h_magic = 0;   // set by the launcher: reciprocals of B and H (kernel_utils.h udiv_magic)
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 

@@ -15,6 +15,25 @@ __device__ __forceinline__ void store_planes4(__half* out_h, size_t o_ps, size_t
   *reinterpret_cast<uint2*>(out_h + o_ps + idx) = *reinterpret_cast<uint2*>(l);
 }
 
+// x / d for a wave-uniform x by multiplication (SALU: s_mul_hi_u32) instead of the compiler's float-reciprocal sequence on the
+// VALU: magic = 2^32 / d + 1 (host: div_magic), exact for x < 2^32 / d; d = 1 has no 32-bit magic
+__device__ __forceinline__ int udiv_magic(unsigned x, int d, unsigned magic) { return d == 1 ? (int)x : (int)__umulhi(x, magic); }
+static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
+
+// expf(x) for x <= 0 (or -inf, or NaN): the library's algorithm — 2^(x log2 e) with a two-term product, v_exp_f32 of the
+// fraction, v_ldexp_f32 — without its overflow branch and with the underflow cut as the only select; same bits as expf.
+__device__ __forceinline__ float exp_nonpos(float x) {
+#pragma clang fp contract(off)   // ph - n must stay a subtraction of the ROUNDED product (contracted into an fma it is a different number)
+  const float C = __uint_as_float(0x3fb8aa3bu), CL = __uint_as_float(0x32a5705fu), THR = __uint_as_float(0xc2ce8ed0u);
+  const float ph = x * C;
+  float t = fmaf(x, C, -ph);
+  const float n = rintf(ph);
+  t = fmaf(x, CL, t);
+  const float r = (ph - n) + t;
+  const float y = ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+  return !(THR > x) ? y : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -10,6 +10,8 @@
 // (beam, head), cross-lane reductions with DPP/shuffles, no LDS staging of data that is read once.
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernel_utils.h"
 
@@ -396,12 +398,15 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
     const int q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7, k = bid >> 3;
     bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + k;
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave index through v_readfirstlane: beam, head, query and every base below are scalars (the divisions by B and H
+  // were float-reciprocal sequences on the VALU per lane: a third of the kernel's instructions at t <= 7)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int B = a.B, H = a.H, t = a.t;
   const int w = bid * 4 + wave;
   const int R = a.Q * B, inner = H * DKV;
   if (w >= R * H) return;
-  const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
+  const int qh = udiv_magic((unsigned)w, B, a.b_magic), b = w - qh * B;
+  const int qi = udiv_magic((unsigned)qh, H, a.h_magic), h = qh - qi * H;
   if (a.nq_dev && qi >= *a.nq_dev) return;
   const int r = qi * B + b;
   const int g = lane >> 4, li = lane & 15;
@@ -409,21 +414,26 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   const uint16_t* ancr = a.anc + (size_t)r * a.anc_ld;
 
   float4 kreg[SELF_MAXIT], vreg[SELF_MAXIT];
-  size_t off[SELF_MAXIT];
+  // scalar base of the (query, head) region + a 32-bit offset per lane (the region is depth * B * 64 floats)
+  const size_t hbase = (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
+  const float* kb = a.kcache + hbase;
+  const float* vb = a.vcache + hbase;
+  const int pstr = (int)a.pos_stride, sstr = (int)a.slot_stride;
+  int off[SELF_MAXIT];
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
     const int p = it * 4 + g;
     const int pc = p < nkeys ? p : t;
     const int slot = (pc == t) ? b : (int)ancr[pc];
-    off[it] = (size_t)qi * a.q_stride + (size_t)h * a.h_stride + (size_t)pc * a.pos_stride + (size_t)slot * a.slot_stride + li * 4;
+    off[it] = pc * pstr + slot * sstr + li * 4;
   }
-  const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * inner + h * DKV + li * 4);
+  const float4 q4 = *reinterpret_cast<const float4*>(a.q + ((size_t)r * inner + h * DKV) + li * 4);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) kreg[it] = ld_stream(a.kcache + off[it]);
+    if (it * 4 < nkeys) kreg[it] = ld_stream(kb + off[it]);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) vreg[it] = ld_stream(a.vcache + off[it]);
+    if (it * 4 < nkeys) vreg[it] = ld_stream(vb + off[it]);
 
   float sc[SELF_MAXIT];
   float mx = -INFINITY;
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   float sum = 0.f;
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
-    sc[it] = (sc[it] == -INFINITY) ? 0.f : expf(sc[it] - mx);
+    sc[it] = exp_nonpos(sc[it] - mx);   // the bits of expf; a masked score is -inf: 0 (mx is finite: key t is always there)
     sum += sc[it];
   }
   sum += __shfl_xor(sum, 16, 64);
@@ -475,8 +485,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   }
 }
 
-hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s) {
+hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a_in, hipStream_t s) {
+  DecSelfAttnArgs a = a_in;
+  a.b_magic = div_magic(a.B); a.h_magic = div_magic(a.H);
   const int items = a.Q * a.B * a.H;
+  if ((long)items >= (1l << 32) / std::max(a.B, a.H)) return hipErrorInvalidValue;   // udiv_magic's exact range
   const dim3 grid((items + 3) / 4), blk(256);
   const int nk = a.t + 1;
   if (nk <= 8) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<2>, grid, blk, 0, s, a); return hipGetLastError(); }

@@ -533,11 +533,6 @@ __global__ __launch_bounds__(256, 4) void tail_cross_attn_mfma_kernel(DecCrossAt
 //    12-token query uses 8 of 16), K and the Q tiles come through LDS-DMA (global_load_lds_dwordx4: whole 256-byte row
 //    slices into an XOR-swizzled strip, conflict-free ds_read_b128 operand reads) with the next tile's Q in flight under
 //    the current tile's products.
-// x / d for a scalar x by multiplication: magic = 2^32 / d + 1 (host: div_magic), exact for x < 2^32 / d; d = 1 has no
-// 32-bit magic
-__device__ __forceinline__ int udiv_magic(unsigned x, int d, unsigned magic) { return d == 1 ? (int)x : (int)__umulhi(x, magic); }
-static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
-
 __device__ __forceinline__ void dma_rows16(const float* src, float* lds_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
@@ -632,20 +627,6 @@ __device__ __forceinline__ void store_o_tile_v2(const f32x16 (&o)[2], float* str
     }
   }
   __builtin_amdgcn_wave_barrier();
-}
-
-// expf(x) for x <= 0 (or -inf, or NaN): the library's algorithm — 2^(x log2 e) with a two-term product, v_exp_f32 of the
-// fraction, v_ldexp_f32 — without its overflow branch and with the underflow cut as the only select; same bits as expf.
-__device__ __forceinline__ float exp_nonpos(float x) {
-#pragma clang fp contract(off)   // ph - n must stay a subtraction of the ROUNDED product (contracted into an fma it is a different number)
-  const float C = __uint_as_float(0x3fb8aa3bu), CL = __uint_as_float(0x32a5705fu), THR = __uint_as_float(0xc2ce8ed0u);
-  const float ph = x * C;
-  float t = fmaf(x, C, -ph);
-  const float n = rintf(ph);
-  t = fmaf(x, CL, t);
-  const float r = (ph - n) + t;
-  const float y = ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
-  return !(THR > x) ? y : 0.f;
 }
 
 // softmax_rows<1> with exp_nonpos (a masked score is -inf: x = -inf - max falls under the cut; at least one key of a row
