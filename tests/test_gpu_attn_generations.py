@@ -26,8 +26,9 @@ def _dump(tmp_path, name, beams, L=32, **env):
 
 @pytest.mark.parametrize("beams,L", [(10, 32), (33, 32), (10, 16), (7, 9)])
 def test_tail_attention_generations_give_the_same_bits(tmp_path, beams, L):
-    old = _dump(tmp_path, "gen1", beams, L, RPR_TAIL_ATTN_GEN=1, RPR_ENC_ATTN_MFMA=0)
-    new = _dump(tmp_path, "gen2", beams, L, RPR_TAIL_ATTN_GEN=2, RPR_ENC_ATTN_MFMA=0)
+    # (encoder and step cross-attention on their VALU kernels in both runs: those two change the summation order)
+    old = _dump(tmp_path, "gen1", beams, L, RPR_TAIL_ATTN_GEN=1, RPR_ENC_ATTN_MFMA=0, RPR_STEP_CROSS_MFMA=0)
+    new = _dump(tmp_path, "gen2", beams, L, RPR_TAIL_ATTN_GEN=2, RPR_ENC_ATTN_MFMA=0, RPR_STEP_CROSS_MFMA=0)
     for k in old:
         assert old[k].shape == new[k].shape and old[k].tobytes() == new[k].tobytes(), k
     for k in ("fork3", "fork5_7"):     # explicit forks inside the kernels' range (T <= 8) were taken
@@ -38,8 +39,11 @@ def test_encoder_and_step_cross_attention_on_the_mfma_tile(tmp_path):
     old = _dump(tmp_path, "valu", 10, RPR_ENC_ATTN_MFMA=0, RPR_STEP_CROSS_MFMA=0)
     enc = _dump(tmp_path, "enc", 10, RPR_ENC_ATTN_MFMA=1, RPR_STEP_CROSS_MFMA=0)
     both = _dump(tmp_path, "both", 10, RPR_ENC_ATTN_MFMA=1, RPR_STEP_CROSS_MFMA=1)
+    m16 = _dump(tmp_path, "m16", 10, RPR_ENC_ATTN_MFMA=0, RPR_STEP_CROSS_MFMA=2)   # the 16 x 16 tile kernel of the steps (default)
+    assert any(not np.array_equal(m16[k + "_scores"], old[k + "_scores"]) for k in ("auto", "fork3", "fork5_7")), \
+        "the 16 x 16 step cross-attention did not run"
     live = old["mask"] != 0
-    for new in (enc, both):
+    for new in (enc, both, m16):
         err = np.abs(new["encoder_out"] - old["encoder_out"])[live].max()
         assert err < 2e-5, err
         for k in ("auto", "fork3", "fork5_7"):

@@ -6,16 +6,16 @@ TAG=${1:-rXX}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-for cfg in "0" "1" "0" "1"; do
-  RPR_ENC_ATTN_MFMA=$cfg timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-fp32 --secondary "" \
+for cfg in "0" "2" "0" "2"; do
+  RPR_STEP_CROSS_MFMA=$cfg timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-fp32 --secondary "" \
     > $OUT/ab_enc$cfg.json 2>> $OUT/ab2.log
   python - <<PY
 import json
 d = json.loads(open("$OUT/ab_enc$cfg.json").read().strip().splitlines()[-1])
-print("enc-attn-mfma $cfg:", round(d["value"], 1), "q/s", round(d["ms_per_step"], 2), "ms", {k: round(v, 1) for k, v in d.get("kernel_breakdown_lanes_ms", {}).items()})
+print("step-cross-mfma $cfg:", round(d["value"], 1), "q/s", round(d["ms_per_step"], 2), "ms", {k: round(v, 1) for k, v in d.get("kernel_breakdown_lanes_ms", {}).items()})
 PY
 done
-for cfg in "0" "1"; do
+for cfg in "0" "2"; do
   RPR_STEP_CROSS_MFMA=$cfg timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-roofline --secondary "latency" \
     > $OUT/ab_lat$cfg.json 2>> $OUT/ab2.log
   python - <<PY
