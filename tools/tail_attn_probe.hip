@@ -60,6 +60,23 @@ static bool same(const __half* a, const __half* b, size_t n, const char* what) {
   return ok;
 }
 
+// planes -> values, largest difference (kernels that sum in a different order)
+static bool close_planes(const __half* a, const __half* b, size_t n_per_plane, const char* what, double tol) {
+  std::vector<__half> ha(2 * n_per_plane), hb(2 * n_per_plane);
+  CK(hipMemcpy(ha.data(), a, 2 * n_per_plane * sizeof(__half), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), b, 2 * n_per_plane * sizeof(__half), hipMemcpyDeviceToHost));
+  double worst = 0.0; size_t differ = 0;
+  for (size_t i = 0; i < n_per_plane; ++i) {
+    const double x = ((double)__half2float(ha[i]) + (double)__half2float(ha[n_per_plane + i])) / 16.0;
+    const double y = ((double)__half2float(hb[i]) + (double)__half2float(hb[n_per_plane + i])) / 16.0;
+    const double d = x > y ? x - y : y - x;
+    if (d > 0) ++differ;
+    if (!(d <= worst)) worst = d;
+  }
+  printf("  %-44s max |difference| %.3g (%zu of %zu values differ)%s\n", what, worst, differ, n_per_plane, worst <= tol ? "" : "  TOO LARGE");
+  return worst <= tol;
+}
+
 int main(int argc, char** argv) {
   const int Q = argc > 1 ? atoi(argv[1]) : 2150, B = 10, H = 12, T = 4, L = 32, Lt = L - T, inner = H * DKV, Lq = 32, ND = 12;
   const int nseq = Q * B; const size_t rows = (size_t)nseq * Lt;
