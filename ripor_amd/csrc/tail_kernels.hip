@@ -8,6 +8,7 @@
 // with exact ties in reverse slot order and stores float32 (:532-540). For a forced query every beam has exactly one
 // valid child per step, so the B winners of a step are those B candidates (fork_classify_kernel proves that no masked
 // candidate can reach them) and only their ORDER has to be replayed: tail_rank_kernel.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -894,8 +895,8 @@ __global__ __launch_bounds__(256, 4) void enc_attn_mfma_v2_kernel(EncAttnArgs a,
   if (bad != 0ull && a.sat && lane == 0) *a.sat = 1u;
 }
 
-// Cross-attention of a sequential step for at most 16 beams and 32 encoder positions on v_mfma_f32_16x16x4_f32: one wave
-// per (query, head). The 32 x 32 tile above spends 64 MFMAs of 64 cycles on the 10 live rows of a beam-10 step (neutral
+// Cross-attention of a sequential step for at most 32 encoder positions on v_mfma_f32_16x16x4_f32: one wave per (query,
+// head, group of 16-beam tiles). The 32 x 32 tile above spends 64 MFMAs of 64 cycles on the 10 live rows of a beam-10 step (neutral
 // against the VALU block kernel); a 16 x 16 tile is 16 + 16 MFMAs of 32 cycles for up to 16 keys. Layouts (lane l: c = l & 15,
 // ks = l >> 4): S^T = K Q^T with A = K (key c of the tile, dims 16 ks .. 16 ks + 15: MFMA i consumes component i, the same
 // k-slot freedom as above), B = Q (beam c, same dims); the result puts keys 4 ks + r (r = 0..3) of beam c in lane l, so a
@@ -905,52 +906,44 @@ __global__ __launch_bounds__(256, 4) void enc_attn_mfma_v2_kernel(EncAttnArgs a,
 // disjoint banks) and leaves as 16-byte plane stores.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCrossAttnArgs a, int HB, unsigned hb_magic) {
+__global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCrossAttnArgs a, int HB, unsigned hb_magic, int groups,
+                                                                      unsigned g_magic, int tpw) {
+  // one wave per (query, head, group of tpw 16-row tiles): blockIdx.x = (query * groups + group) * HB + head block; K, V and
+  // the key mask of the (query, head) stay in registers for all of the wave's tiles (beams > 16: 7 tiles at beam 100)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SLD = 68;
   const int H = a.H, inner = H * DKV, B = a.B;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, c = lane & 15, ks = lane >> 4;
-  const int qi = udiv_magic(blockIdx.x, HB, hb_magic);
-  const int h = ((int)blockIdx.x - qi * HB) * 4 + wave;
+  const int qg = udiv_magic(blockIdx.x, HB, hb_magic);
+  const int h = ((int)blockIdx.x - qg * HB) * 4 + wave;
+  const int qi = udiv_magic((unsigned)qg, groups, g_magic), grp = qg - qi * groups;
   if (h >= H || (a.nq_dev && qi >= *a.nq_dev)) return;    // wave-uniform
+  int i0 = grp * tpw * 16;
+  if (i0 >= B) return;
   float* Os = smem + wave * (16 * SLD);
   const int nk = min(a.last[qi], 32);
   const size_t obase = (size_t)qi * B * inner + h * DKV;
-  float* out_t = a.out ? a.out + obase : nullptr;
-  __half* out_h_t = a.out_h ? a.out_h + obase : nullptr;
   unsigned long long bad = 0ull;
-  f32x4 o[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (nk > 0) {   // (a query without a single attended token: zeros, as the block kernel)
+  // nk == 0 (a query without a single attended token): zeros, as the block kernel; nothing of its encoder is read
+  const int nkt = nk > 16 ? 2 : nk > 0 ? 1 : 0;           // key tiles of 16
+  const float* qb = a.q + (size_t)qi * B * inner + h * DKV + 16 * ks;
+  float4 kreg[2][4];
+  float vreg[2][4][4];                                    // [key tile][r][column tile]: V[16 kt + 4 ks + r][16 t + c]
+  f32x4 negm[2];                                          // additive key mask = the C operand of the first score product
+  if (nkt > 0) {
     const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
     const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;
     const float* kb = a.xk + xrow0 * a.xld + h * DKV;
     const float* vb = a.xv + xrow0 * a.xld + h * DKV;
-    const float* qb = a.q + (size_t)qi * B * inner + h * DKV;
-    const int nkt = nk > 16 ? 2 : 1;                      // key tiles of 16
     const bool kok = (lane & 31) < nk && mrow[min(lane & 31, nk - 1)] != 0;
     const unsigned okm = (unsigned)(__ballot(kok) & 0xffffffffull);   // bit j: key j is attended
-    float4 qreg[4], kreg[2][4];
-    {
-      const float* qr = qb + min(c, B - 1) * inner + 16 * ks;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) qreg[u] = *reinterpret_cast<const float4*>(qr + 4 * u);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        if (kt < nkt) {                                   // wave-uniform; unattended keys are masked: any finite row will do
-          const float* kr = kb + min(kt * 16 + c, nk - 1) * a.xld + 16 * ks;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) kreg[kt][u] = *reinterpret_cast<const float4*>(kr + 4 * u);
-        }
-      }
-    }
-    float vreg[2][4][4];                                  // [key tile][r][column tile]: V[16 kt + 4 ks + r][16 t + c]
-    f32x4 sc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      if (kt < nkt) {
+      if (kt < nkt) {                                     // wave-uniform; unattended keys are masked: any finite row will do
+        const float* kr = kb + min(kt * 16 + c, nk - 1) * a.xld + 16 * ks;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kreg[kt][u] = *reinterpret_cast<const float4*>(kr + 4 * u);
         const unsigned bits = (okm >> (16 * kt + 4 * ks)) & 0xfu;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -958,75 +951,96 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
           const float* vr = vb + min(16 * kt + 4 * ks + r, nk - 1) * a.xld + c;
 #pragma unroll
           for (int t = 0; t < 4; ++t) { const float x = vr[16 * t]; vreg[kt][r][t] = live ? x : 0.f; }
-          sc[kt][r] = live ? 0.f : -INFINITY;             // additive key mask = the C operand of the first product
-        }
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].x, qreg[u].x, sc[kt], 0, 0, 0);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].y, qreg[u].y, sc[kt], 0, 0, 0);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].z, qreg[u].z, sc[kt], 0, 0, 0);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].w, qreg[u].w, sc[kt], 0, 0, 0);
-        }
-      }
-    }
-    // softmax of beam c over its keys: 4 per key tile here, the others in lanes ^ 16, ^ 32
-    float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
-    if (nkt > 1) mx = fmaxf(mx, fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float e = exp_nonpos(sc[kt][r] - mx); sc[kt][r] = e; sum += e; }
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = sc[kt][r] * inv;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vreg[kt][r][t], o[t], 0, 0, 0);
+          negm[kt][r] = live ? 0.f : -INFINITY;
         }
       }
     }
   }
-  // o[t][r] = O[beam 4 ks + r][16 t + c] -> strip -> rows of 8 lanes x 8 columns
-  {
-    float* wr = Os + (4 * ks) * SLD + c;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r * SLD + 16 * t] = o[t][r];
-  }
-  __builtin_amdgcn_wave_barrier();
   const int c8 = (lane & 7) * 8, il0 = lane >> 3;
+#pragma unroll 1
+  for (int tl = 0; tl < tpw && i0 < B; ++tl, i0 += 16) {
+    f32x4 o[4];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int i = k * 8 + il0;
-    if (i < B) {
-      const float4 x0 = *reinterpret_cast<const float4*>(Os + i * SLD + c8);
-      const float4 x1 = *reinterpret_cast<const float4*>(Os + i * SLD + c8 + 4);
-      const int off = i * inner + c8;
-      if (out_h_t) {
-        uint4 hi, lo;
-        split8(x0, x1, hi, lo, bad);
-        *reinterpret_cast<uint4*>(out_h_t + off) = hi;
-        *reinterpret_cast<uint4*>(out_h_t + a.o_ps + off) = lo;
-      } else {
-        *reinterpret_cast<float4*>(out_t + off) = x0;
-        *reinterpret_cast<float4*>(out_t + off + 4) = x1;
+    for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nkt > 0) {
+      float4 qreg[4];
+      {
+        const float* qr = qb + (size_t)i0 * inner + min(c, B - 1 - i0) * inner;   // rows past the end repeat the last one (not stored)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qreg[u] = *reinterpret_cast<const float4*>(qr + 4 * u);
+      }
+      f32x4 sc[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (kt < nkt) {
+          sc[kt] = negm[kt];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].x, qreg[u].x, sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].y, qreg[u].y, sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].z, qreg[u].z, sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][u].w, qreg[u].w, sc[kt], 0, 0, 0);
+          }
+        }
+      }
+      // softmax of row c over its keys: 4 per key tile here, the others in lanes ^ 16, ^ 32
+      float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+      if (nkt > 1) mx = fmaxf(mx, fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float e = exp_nonpos(sc[kt][r] - mx); sc[kt][r] = e; sum += e; }
+        }
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = sc[kt][r] * inv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vreg[kt][r][t], o[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // o[t][r] = O[row 4 ks + r][16 t + c] -> strip -> rows of 8 lanes x 8 columns
+    __builtin_amdgcn_wave_barrier();
+    {
+      float* wr = Os + (4 * ks) * SLD + c;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r * SLD + 16 * t] = o[t][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const size_t ob = obase + (size_t)i0 * inner;
+    float* out_t = a.out ? a.out + ob : nullptr;
+    __half* out_h_t = a.out_h ? a.out_h + ob : nullptr;
+    const int nlive = B - i0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = k * 8 + il0;
+      if (i < nlive) {
+        const float4 x0 = *reinterpret_cast<const float4*>(Os + i * SLD + c8);
+        const float4 x1 = *reinterpret_cast<const float4*>(Os + i * SLD + c8 + 4);
+        const int off = i * inner + c8;
+        if (out_h_t) {
+          uint4 hi, lo;
+          split8(x0, x1, hi, lo, bad);
+          *reinterpret_cast<uint4*>(out_h_t + off) = hi;
+          *reinterpret_cast<uint4*>(out_h_t + a.o_ps + off) = lo;
+        } else {
+          *reinterpret_cast<float4*>(out_t + off) = x0;
+          *reinterpret_cast<float4*>(out_t + off + 4) = x1;
+        }
       }
     }
   }
@@ -1081,16 +1095,23 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
 }
 
 // Cross-attention of a sequential step (a.B = the beams of a query). RPR_STEP_CROSS_MFMA: 2 (default) = the 16 x 16 tile
-// kernel above for at most 16 beams and 32 encoder positions, else the VALU block kernel; 1 = the 32-row tile kernel of the
+// kernel above for at most 32 encoder positions, else the VALU block kernel; 1 = the 32-row tile kernel of the
 // tail (measured neutral at beam 10: 4969-4974 vs 4983 queries/s same-box, 10 of a tile's 32 rows are live); 0 = always the
 // block kernel.
 hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   static const int mode = [] { const char* e = getenv("RPR_STEP_CROSS_MFMA"); return e ? atoi(e) : 2; }();
   const int HB = (a.H + 3) / 4;
-  if (mode == 2 && g_tail_attn_gen == 2 && a.Lq <= 32 && a.B <= 16 && (long)a.Q * HB < (1l << 31) / HB) {
-    hipLaunchKernelGGL(step_cross_attn_mfma16_kernel, dim3((unsigned)(a.Q * HB)), dim3(256), 4 * (16 * 68) * sizeof(float), s, a, HB,
-                       div_magic(HB));
-    return hipGetLastError();
+  if (mode == 2 && g_tail_attn_gen == 2 && a.Lq <= 32 && (long)a.B * a.H * DKV < (1l << 29)) {
+    // 16-row tiles per wave: one while that gives the chip enough waves, else up to eight (K / V / mask loaded once per wave)
+    const int tiles = (a.B + 15) / 16;
+    const int tpw = (long)a.Q * a.H * tiles >= 32768 ? std::min(tiles, 8) : 1;
+    const int groups = (tiles + tpw - 1) / tpw;
+    const long blocks = (long)a.Q * groups * HB;
+    if (blocks < (1l << 31) / HB && (long)a.Q * groups < (1l << 32) / groups) {   // udiv_magic's exact range
+      hipLaunchKernelGGL(step_cross_attn_mfma16_kernel, dim3((unsigned)blocks), dim3(256), 4 * (16 * 68) * sizeof(float), s, a, HB,
+                         div_magic(HB), groups, div_magic(groups), tpw);
+      return hipGetLastError();
+    }
   }
   if (mode == 1 && g_tail_attn_gen == 2 && a.Lq <= 32) return launch_tail_cross_attn(a, s);
   return launch_dec_cross_attn(a, s);
