@@ -906,6 +906,7 @@ __global__ __launch_bounds__(256, 4) void enc_attn_mfma_v2_kernel(EncAttnArgs a,
 // disjoint banks) and leaves as 16-byte plane stores.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool MULTI>   // false: at most 16 beams — one tile, no tile loop (35.0 against 37.5 us per lane launch at beam 10)
 __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCrossAttnArgs a, int HB, unsigned hb_magic, int groups,
                                                                       unsigned g_magic, int tpw) {
   // one wave per (query, head, group of tpw 16-row tiles): blockIdx.x = (query * groups + group) * HB + head block; K, V and
@@ -917,9 +918,9 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
   const int lane = threadIdx.x & 63, c = lane & 15, ks = lane >> 4;
   const int qg = udiv_magic(blockIdx.x, HB, hb_magic);
   const int h = ((int)blockIdx.x - qg * HB) * 4 + wave;
-  const int qi = udiv_magic((unsigned)qg, groups, g_magic), grp = qg - qi * groups;
+  const int qi = MULTI ? udiv_magic((unsigned)qg, groups, g_magic) : qg, grp = MULTI ? qg - qi * groups : 0;
   if (h >= H || (a.nq_dev && qi >= *a.nq_dev)) return;    // wave-uniform
-  int i0 = grp * tpw * 16;
+  int i0 = MULTI ? grp * tpw * 16 : 0;
   if (i0 >= B) return;
   float* Os = smem + wave * (16 * SLD);
   const int nk = min(a.last[qi], 32);
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
   }
   const int c8 = (lane & 7) * 8, il0 = lane >> 3;
 #pragma unroll 1
-  for (int tl = 0; tl < tpw && i0 < B; ++tl, i0 += 16) {
+  for (int tl = 0; tl < (MULTI ? tpw : 1) && i0 < B; ++tl, i0 += 16) {
     f32x4 o[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1108,8 +1109,12 @@ hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
     const int groups = (tiles + tpw - 1) / tpw;
     const long blocks = (long)a.Q * groups * HB;
     if (blocks < (1l << 31) / HB && (long)a.Q * groups < (1l << 32) / groups) {   // udiv_magic's exact range
-      hipLaunchKernelGGL(step_cross_attn_mfma16_kernel, dim3((unsigned)blocks), dim3(256), 4 * (16 * 68) * sizeof(float), s, a, HB,
-                         div_magic(HB), groups, div_magic(groups), tpw);
+      if (tiles == 1)
+        hipLaunchKernelGGL(step_cross_attn_mfma16_kernel<false>, dim3((unsigned)blocks), dim3(256), 4 * (16 * 68) * sizeof(float), s, a, HB,
+                           div_magic(HB), 1, 0u, 1);
+      else
+        hipLaunchKernelGGL(step_cross_attn_mfma16_kernel<true>, dim3((unsigned)blocks), dim3(256), 4 * (16 * 68) * sizeof(float), s, a, HB,
+                           div_magic(HB), groups, div_magic(groups), tpw);
       return hipGetLastError();
     }
   }
