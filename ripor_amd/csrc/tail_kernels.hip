@@ -929,6 +929,15 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
   // nk == 0 (a query without a single attended token): zeros, as the block kernel; nothing of its encoder is read
   const int nkt = nk > 16 ? 2 : nk > 0 ? 1 : 0;           // key tiles of 16
   const float* qb = a.q + (size_t)qi * B * inner + h * DKV + 16 * ks;
+  // this lane's 16 dims of row ibase + c; rows past the end repeat the last one (not stored). The first tile's rows are
+  // requested before K and V (they are needed first), a later tile's while the previous one is stored.
+  float4 qreg[4];
+  auto q_load = [&](int ibase) {
+    const float* qr = qb + (size_t)ibase * inner + min(c, B - 1 - ibase) * inner;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qreg[u] = *reinterpret_cast<const float4*>(qr + 4 * u);
+  };
+  q_load(i0);
   float4 kreg[2][4];
   float vreg[2][4][4];                                    // [key tile][r][column tile]: V[16 kt + 4 ks + r][16 t + c]
   f32x4 negm[2];                                          // additive key mask = the C operand of the first score product
@@ -964,12 +973,6 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nkt > 0) {
-      float4 qreg[4];
-      {
-        const float* qr = qb + (size_t)i0 * inner + min(c, B - 1 - i0) * inner;   // rows past the end repeat the last one (not stored)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) qreg[u] = *reinterpret_cast<const float4*>(qr + 4 * u);
-      }
       f32x4 sc[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -1012,6 +1015,7 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
         }
       }
     }
+    if (MULTI && tl + 1 < tpw && i0 + 16 < B) q_load(i0 + 16);   // wave-uniform
     // o[t][r] = O[row 4 ks + r][16 t + c] -> strip -> rows of 8 lanes x 8 columns
     __builtin_amdgcn_wave_barrier();
     {
