@@ -334,7 +334,10 @@ def query_batches(collection: QueryCollection, tokenizer, indices: Sequence[int]
         sel = indices[s:s + batch_size]
         enc = tokenizer([collection.texts[i] for i in sel], add_special_tokens=True, padding="longest",
                         truncation="longest_first", max_length=max_length, return_attention_mask=True)
+        # "decoder_input_ids": the reference loader adds the rows' smtid lists, [-1] each for a query collection
+        # (dataset.py:296-305, dataloader.py:76); nothing on this path reads them, the key is kept for drop-in callers
         yield {"input_ids": torch.tensor(enc["input_ids"]), "attention_mask": torch.tensor(enc["attention_mask"]),
+               "decoder_input_ids": torch.full((len(sel), 1), -1, dtype=torch.long),
                "id": torch.tensor([int(collection.ids[i]) for i in sel], dtype=torch.long)}
 
 

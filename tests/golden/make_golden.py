@@ -822,6 +822,110 @@ def make_lngknp_data_case(name="c6_lngknp_data"):
     print(f"[golden] {name}: {len(cases)} cases -> {path} ({os.path.getsize(path) / 1e3:.1f} KB)")
 
 
+# ----------------------------------------------------------------------------- query front-end + truncate_run (row f3)
+def frontend_files(root):
+    """A checkpoint directory with an offline-trained SentencePiece tokenizer and a ``raw.tsv`` query collection that
+    exercises the reader: tabs inside the text, CRLF line ends, unicode line separators inside a line, trailing blanks,
+    a query longer than max_length (256) tokens, numeric ids that are not row numbers, and an empty last line."""
+    import random
+    import sentencepiece as spm
+    ckpt = os.path.join(root, "checkpoint")
+    qdir = os.path.join(root, "msmarco_frontend", "dev_queries")
+    os.makedirs(ckpt)
+    os.makedirs(qdir)
+    rnd = random.Random(11)
+    words = ["what", "is", "the", "how", "to", "of", "in", "a", "best", "price", "weather", "define"] + [f"w{i}" for i in range(150)]
+    corpus = os.path.join(root, "corpus.txt")
+    with open(corpus, "w") as f:
+        for _ in range(1500):
+            f.write(" ".join(rnd.choice(words) for _ in range(rnd.randint(3, 12))) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(ckpt, "spiece"), vocab_size=200, model_type="unigram",
+                                   pad_id=0, eos_id=1, unk_id=2, bos_id=-1, pad_piece="<pad>", eos_piece="</s>", unk_piece="<unk>",
+                                   hard_vocab_limit=False, minloglevel=2)
+    tok_cfg = {"tokenizer_class": "T5Tokenizer", "extra_ids": 0, "model_max_length": 512}
+    json.dump(tok_cfg, open(os.path.join(ckpt, "tokenizer_config.json"), "w"))
+    sent = lambda n: " ".join(rnd.choice(words) for _ in range(n))
+    lines = [f"1048585\t{sent(5)}\n",
+             f"2\t{sent(3)}\twith a tab\tand another\n",            # tabs inside the text -> joined by blanks
+             f"1102432\t  {sent(4)}  \r\n",                          # CRLF, leading / trailing blanks (kept by id_style row_id)
+             f"524332\t{sent(2)}\x0b{sent(2)}\u2028{sent(1)}\n",    # vertical tab / LINE SEPARATOR inside a line -> blanks
+             f"87181\t{sent(300)}\n",                                # > 256 tokens: truncated to max_length
+             f" 300674 \tUPPER case Query ? unknown-chars \u00e9\u4e2d\n",   # id with blanks; pieces outside the vocabulary
+             f"7\t{sent(1)}\n",
+             f"915593\t{sent(9)}\n",
+             f"264014\t{sent(6)}\n",
+             f"1\t{sent(7)}\n",
+             f"33\t\n",                                              # empty text: "query: " alone
+             "\n"]                                                   # a bare newline (len(line) <= 1) is skipped; only legal at the end
+    raw = "".join(lines)
+    with open(os.path.join(qdir, "raw.tsv"), "w", newline="") as f:   # newline="": the CRLF reaches the file as written
+        f.write(raw)
+    return ckpt, qdir, raw, open(os.path.join(ckpt, "spiece.model"), "rb").read(), tok_cfg
+
+
+def make_frontend_case(name="c8_frontend"):
+    """The reference's OWN query front-end (evaluate.py:461-468: CollectionDatasetWithDocIDPreLoad(id_style="row_id",
+    add_prefix=True, is_query=True) + CollectionDataWithDocIDLoader(max_length=256, sampler=DistributedSampler(shuffle=False)),
+    dataset/dataset.py:266-332, dataset/dataloader.py:62-79) on a small query file, and utils/metrics.py:9-15 ``truncate_run``
+    (imported with a stub pytrec_eval: the function is pure Python) on runs with score ties at and around the cut."""
+    import importlib
+    import importlib.machinery
+    import tempfile
+    from torch.utils.data.distributed import DistributedSampler
+    ds_mod = importlib.import_module("t5_pretrainer.dataset.dataset")
+    dl_mod = importlib.import_module("t5_pretrainer.dataset.dataloader")
+    if "pytrec_eval" not in sys.modules:
+        m_ = types.ModuleType("pytrec_eval")
+        m_.__spec__ = importlib.machinery.ModuleSpec("pytrec_eval", None)
+        m_.RelevanceEvaluator = object
+        sys.modules["pytrec_eval"] = m_
+    mt_mod = importlib.import_module("t5_pretrainer.utils.metrics")
+    for m_ in (ds_mod, dl_mod, mt_mod):
+        assert os.path.realpath(m_.__file__).startswith(REF + os.sep), m_.__file__
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        ckpt, qdir, raw, spiece, tok_cfg = frontend_files(root)
+        ds = ds_mod.CollectionDatasetWithDocIDPreLoad(data_dir=qdir, id_style="row_id", tid_to_smtid_path=None, add_prefix=True,
+                                                      is_query=True)
+        out["items"] = [list(ds[i]) for i in range(len(ds))]
+        loaders = {}
+        for W, bs in ((1, 4), (2, 3), (3, 2)):
+            for r in range(W):
+                # num_workers=0 and no pinned memory: the collate function is what is pinned here, not the worker plumbing
+                real_init = torch.utils.data.DataLoader.__init__
+                def _init(self, *a, **k):
+                    k["pin_memory"] = False
+                    real_init(self, *a, **k)
+                torch.utils.data.DataLoader.__init__ = _init
+                try:
+                    ld = dl_mod.CollectionDataWithDocIDLoader(dataset=ds, tokenizer_type=ckpt, max_length=256, batch_size=bs, num_workers=0,
+                                                              sampler=DistributedSampler(ds, num_replicas=W, rank=r, shuffle=False))
+                    batches = [{k: v.tolist() for k, v in b.items()} for b in ld]
+                finally:
+                    torch.utils.data.DataLoader.__init__ = real_init
+                loaders[f"w{W}_r{r}_bs{bs}"] = batches
+        out["loaders"] = loaders
+    # truncate_run: ties inside the top k, a tie straddling the cut (run-file order decides), fewer than k documents,
+    # integer and float scores, negative scores, k = 1
+    runs = {
+        "q_tie_at_cut": {"d1": 3.0, "d2": 5.0, "d3": 3.0, "d4": 3.0, "d5": 1.0},
+        "q_all_equal": {"b": 1.5, "a": 1.5, "c": 1.5},
+        "q_short": {"x": -2.0, "y": -1.0},
+        "q_mixed": {"m1": 2, "m2": 2.0, "m3": 10, "m4": -7.25, "m5": 2},
+        "q_empty": {},
+    }
+    out["truncate"] = {str(k): mt_mod.truncate_run(runs, k) for k in (1, 2, 3, 10)}
+    # key ORDER is part of the result (the evaluator and the json writer see it): stored as lists of pairs
+    out["truncate_order"] = {k: {q: list(d.items()) for q, d in v.items()} for k, v in out["truncate"].items()}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, raw_tsv=np.array(raw), spiece_model=np.frombuffer(spiece, dtype=np.uint8),
+                        tokenizer_config=np.array(json.dumps(tok_cfg)), runs=np.array(json.dumps(runs)),
+                        results=np.array(json.dumps(out)))
+    nb = sum(len(v) for v in out["loaders"].values())
+    print(f"[golden] {name}: {len(out['items'])} queries, {nb} batches over {len(out['loaders'])} loaders -> {path} "
+          f"({os.path.getsize(path) / 1e3:.1f} KB)")
+
+
 def make_beam_indices_case(gen, mod, utils, shim, name="c7_beam_indices"):
     """``beam_indices`` of the reference's output object (generation.py:521-522, :548-552) for two committed search fixtures
     (the ``scores`` tuple is already stored there as ``step_scores``): per returned slot the L parent indices q*B + slot."""
@@ -864,6 +968,8 @@ def main():
         make_lngknp_data_case()
     if not args.only or args.only in ("c7_beam_indices", "callers"):
         make_beam_indices_case(gen, mod, utils, shim)
+    if not args.only or args.only in ("c8_frontend", "callers"):
+        make_frontend_case()
 
 
 if __name__ == "__main__":
