@@ -709,7 +709,7 @@ def main():
                         kname = "rpr::gemm_h2_dma_kernel / rpr::gemm_h2_skinny_kernel"
                     note = ("achieved counts algorithmic 2MNK flops; the kernel issues 3 f16 MFMAs per product "
                             "(hi*hi + hi*lo + lo*hi), so peak = 2500 TF/s dense f16 / 3 at the nominal 2.4 GHz; the in-kernel "
-                            "s_memtime/s_memrealtime trace (tools/gemm_trace_pp.py) shows the chip sustaining 1.64-1.76 GHz "
+                            "s_memtime/s_memrealtime trace (tools/attic/gemm_trace_pp.py) shows the chip sustaining 1.64-1.76 GHz "
                             "under this kernel (DVFS), i.e. ~0.6 of the peak at the sustained clock")
                 peak = full_peak * cu_fraction
                 if cu_fraction != 1.0:

@@ -119,34 +119,6 @@ def test_docid_to_smtid_streaming_reader(lib, tmp_path):
 
 
 def test_hot_gemm_kernels_use_no_scratch():
-    """The ping-pong GEMM instantiations of the search path must not touch scratch memory: a register spill, or a
-    private copy of the by-value argument struct (what writing to one of its fields costs: 320 B/lane, +20 % per launch,
-    3470 -> 3059 queries/s), shows up as ScratchSize > 0 in the compiler's resource remarks long before a GPU run."""
-    import re
-    import subprocess
-    import tempfile
-    import __graft_entry__ as ge
-    src = os.path.join(ge.CSRC, "gemm_h2.hip")
-    with tempfile.TemporaryDirectory() as tmp:
-        r = subprocess.run([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
-                            os.path.join(tmp, "g.o"), "-Rpass-analysis=kernel-resource-usage"],
-                           capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    usage, name = {}, None
-    for line in r.stderr.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and name:
-            usage[name] = int(m.group(1))
-    hot = [k for k in usage if "gemm_h2_pp_kernelILb1E" in k or "gemm_h2_skinny" in k or
-           ("gemm_h2_dma_kernel" in k and "Lb1E" in k)]
-    assert len(hot) >= 5, sorted(usage)
-    assert all(usage[k] == 0 for k in hot), {k: usage[k] for k in hot if usage[k]}
-
-
-def test_hot_gemm_kernels_use_no_scratch():
     """The 256 x 256 ping-pong GEMM and the skinny GEMM must compile without scratch: twice in round 4 (and once in round 2)
     a harmless-looking edit made hipcc keep the accumulators or a private copy of the 336-byte argument struct in scratch —
     correct results, +20 % per launch, no warning. Cross-compiles gemm_h2.hip for gfx950 (no GPU needed, ~1 min)."""
@@ -169,6 +141,8 @@ def test_hot_gemm_kernels_use_no_scratch():
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name:
             seen[name] = int(m.group(1))
-    hot = {k: v for k, v in seen.items() if "gemm_h2_pp_kernel" in k or "gemm_h2_skinny_kernel" in k}
-    assert len(hot) >= 4, seen
+    # every ping-pong instantiation (search and grouped), the skinny kernels (32- and 16-row) and the FULL-tile instantiations
+    # of the 128-row LDS-DMA kernel (two definitions of this test once shadowed each other: the second one had dropped these)
+    hot = {k: v for k, v in seen.items() if "gemm_h2_pp_" in k or "gemm_h2_skinny" in k or ("gemm_h2_dma_kernel" in k and "Lb1E" in k)}
+    assert len(hot) >= 8 and any("skinny16" in k for k in hot) and any("gemm_h2_dma_kernel" in k for k in hot), sorted(seen)
     assert all(v == 0 for v in hot.values()), {k: v for k, v in hot.items() if v}
