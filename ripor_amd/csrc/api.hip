@@ -3,6 +3,7 @@
 // fused with the trie mask / top-B / beam expand, all enqueued on one HIP stream and replayed as a
 // hipGraph (no host synchronisation inside the search; the reference syncs >= 1 + 2*B*Q times per
 // step).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -317,6 +318,7 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
                           h2 ? P<__half>(w.enc_out_h) : nullptr, ps_d, live, c->status, h2 ? xs.x_h : nullptr, ps_d);
   });
   c->enc_rows_accounted = Ta;
+  Ln.account_live(nullptr, 0);
 }
 
 BeamState beam_state(DevBuf (&score)[2], DevBuf (&lo)[2], DevBuf (&hi)[2], DevBuf (&tokens)[2], DevBuf (&anc)[2], int i, int L) {
@@ -474,6 +476,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     }
     Ln.run(RPR_K_SELECT, 0, (double)Ma * V * 4 + (double)Ma * 40, [&] { return launch_select(sa, s); });
   }
+  Ln.account_live(nullptr, 0);   // the live counter of this stage scales THIS stage's records only (fork, tail, finalize follow)
 }
 
 // The fork after step T-1 of stage `sv`: which of its queries are forced (tail job `tb`), the others compacted into
@@ -618,6 +621,7 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
   TailRankArgs ra{sv.st[T & 1], P<int32_t>(tb.flist), P<int32_t>(tb.qmap), nf_dev, P<uint16_t>(tb.tokens), P<float>(tb.gold), Q, B, T, L,
                   P<int32_t>(w.o_tokens), P<float>(w.o_scores), P<int64_t>(w.o_lo), P<int64_t>(w.o_hi)};
   Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_tail_rank(ra, s); });
+  Ln.account_live(nullptr, 0);
 }
 
 // Everything between the staged inputs (ws.ids/ws.mask) and the staged outputs (ws.o_*).
@@ -1350,6 +1354,10 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
   RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
   RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
+  // the step self-attention splits its wave index (query, beam, head) by reciprocal multiplication, exact below
+  // 2^32 / max(B, H) (launch_dec_self_attn): said here, not as a launch error in the middle of a capture
+  RPR_REQUIRE((int64_t)Q * B * m->d.num_heads < ((int64_t)1 << 32) / std::max<int64_t>(B, m->d.num_heads),
+              "Q * num_beams * num_heads too large for this beam count: search fewer queries per call");
   RPR_REQUIRE(select_fits(B, m->Vp()), "num_beams * decoder vocab size too large for the select kernel (about 1600 beams at V=256)");
   RPR_REQUIRE(!taps || m->Vp() == m->d.V, "debug taps need a decoder vocab size that is a multiple of 64");
   RPR_HIP(hipSetDevice(c->device));

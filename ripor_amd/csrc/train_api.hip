@@ -656,6 +656,9 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
     return std::make_pair(lo, hi - lo);
   };
   const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff, H = D.H;
+  // a backward that aborted on Ln.err leaves collected-but-unflushed products behind: never carry them into this step's
+  // gradient buffer
+  w.grp.n = 0; w.grp_tiles = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0;
   Bwd B{Ln, c, w, D};
   const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
   const bool saved = xt.base != nullptr;   // the normalised inputs are only recomputed for their weight-gradient products

@@ -126,7 +126,16 @@ class Context:
         since the last clear must be recomputed in 'f32' precision; ``_lib.STATUS_EMPTY_QUERY``)."""
         out = C.c_uint32(0)
         check(self.lib.rpr_get_status(self.handle, _stream_ptr(self.device), C.byref(out), 1 if clear else 0), "rpr_get_status")
-        return int(out.value)
+        flags = int(out.value) | getattr(self, "_kept_status", 0)
+        if clear:
+            self._kept_status = 0
+        return flags
+
+    def keep_status(self, flags: int):
+        """Hand flags back that a caller read with ``status(clear=True)`` but does not own (the device words are gone):
+        the next ``status()`` reports them again. Used by side passes that must clear the device words around their own
+        run (tasks/generation.py ``_per_step_record``) without swallowing another search's unchecked flags."""
+        self._kept_status = getattr(self, "_kept_status", 0) | int(flags)
 
     # -- profiling (bench.py roofline leg) --
     def profile_enable(self, on: bool):

@@ -35,6 +35,9 @@ def get_args(argv=None):
     ap.add_argument("--max_steps", type=int, default=-1)
     ap.add_argument("--logging_steps", type=int, default=50)
     ap.add_argument("--save_steps", type=int, default=15_000)
+    ap.add_argument("--resume_from_checkpoint", default=None,
+                    help="an output_dir/checkpoint-<step> directory: weights, AdamW moments, step count and RNG states are restored "
+                         "and the loop continues at the recorded step (HF TrainingArguments.resume_from_checkpoint)")
     ap.add_argument("--task_names", default=None, help='JSON list, e.g. ["rank","rank_4"]')
     ap.add_argument("--ln_to_weight", default=None, help="JSON dict of task weights (only 1.0 is built)")
     ap.add_argument("--use_fp16", action="store_true", help="bf16 GEMM operands, like the reference (main.py:152 bf16=args.use_fp16)")
@@ -61,7 +64,7 @@ def main(argv=None):
                                                query_dir=args.queries_path, docid_to_smtid_path=args.docid_to_smtid_path,
                                                smtid_as_docid=args.smtid_as_docid)
     collator = LngKnpMarginMSEforT5SeqAQCollator(args.model_name_or_path, max_length=args.max_length)
-    model = T5SeqAQEncoderForLngKnpMarginMSE.from_pretrained(args.pretrained_path)
+    model = T5SeqAQEncoderForLngKnpMarginMSE.from_pretrained(args.resume_from_checkpoint or args.pretrained_path)
     model.to(local_rank)
     targs = LngKnpTrainingArgs(output_dir=args.output_dir, learning_rate=args.learning_rate, warmup_ratio=args.warmup_ratio,
                                per_device_train_batch_size=args.per_device_train_batch_size, num_train_epochs=args.epochs,
@@ -74,7 +77,7 @@ def main(argv=None):
         print(f"lng_knp fine-tune: {len(dataset)} examples, {trainer.world} rank(s) x {targs.per_device_train_batch_size}, "
               f"{trainer.max_steps} steps ({trainer.warmup_steps} warm-up), lr {targs.learning_rate}, "
               f"{'bf16' if targs.bf16 else 'fp32-equivalent'} GEMMs")
-    trainer.train()
+    trainer.train(resume_from_checkpoint=args.resume_from_checkpoint or None)
     trainer.save_torch_model_and_tokenizer(collator.tokenizer)
     if dist.is_initialized():
         dist.barrier()

@@ -72,15 +72,22 @@ def _per_step_record(em, trie, input_ids, attention_mask, B, L, K, log_softmax):
     """``scores`` and ``beam_indices`` of the reference's output object from one tapped search (see the class above)."""
     ctx = em.ctx
     saved = ctx.get_precision()
-    res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
-    torch.cuda.synchronize(ctx.device)
-    if ctx.status(clear=True) & E._lib.STATUS_SATURATED and saved != "f32":
-        ctx.set_precision("f32")
-        try:
-            res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
-            torch.cuda.synchronize(ctx.device)
-        finally:
-            ctx.set_precision(saved)
+    # the sticky words of the shared ctx may hold flags of a search nobody has checked yet (deferred guards): read and clear
+    # them before the tapped run (a stale SATURATED bit would trigger a needless fp32 rerun), hand them back afterwards
+    before = ctx.status(clear=True)
+    try:
+        res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
+        torch.cuda.synchronize(ctx.device)
+        if ctx.status(clear=True) & E._lib.STATUS_SATURATED and saved != "f32":
+            ctx.set_precision("f32")
+            try:
+                res = E.search(em, trie, input_ids, attention_mask, B, L, apply_log_softmax_for_scores=log_softmax, taps=True)
+                torch.cuda.synchronize(ctx.device)
+                ctx.status(clear=True)
+            finally:
+                ctx.set_precision(saved)
+    finally:
+        ctx.keep_status(before)
     t = res.taps
     Q, V = input_ids.shape[0], em.V
     logits = t["step_logits"].view(L, Q * B, V)                                  # fp32, row = q*B + slot of the step's beams
@@ -248,6 +255,11 @@ def generate_for_constrained_prefix_beam_search(
     if output_scores and em.V % 64 == 0:   # (the debug taps need a vocab size on the 64 grid)
         ids_keep, mask_keep, ls = input_ids, attention_mask, bool(apply_log_softmax_for_scores)
         record = lambda: _per_step_record(em, trie, ids_keep, mask_keep, B, L, K, ls)   # noqa: E731  (run on first access)
+    elif output_scores:
+        def record():   # the reference always returns them: fail loudly on access instead of handing out None
+            raise NotImplementedError(f".scores / .beam_indices need a decoder vocab size that is a multiple of 64 (got {em.V}): the "
+                                      "per-step taps of rpr_search are laid out on 64-token words; .sequences and .sequences_scores "
+                                      "do not depend on it")
     return BeamSearchEncoderDecoderOutput(
         sequences=seqs,
         sequences_scores=res.scores[:, :K].reshape(Q * K) if output_scores else None,

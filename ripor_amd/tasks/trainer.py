@@ -10,7 +10,9 @@ libripor_hip.so (``T5SeqAQEncoderForLngKnpMarginMSE.training_step``):
   "linear")`` instantiates it (main.py:135-137; full_lng_knp_train_pipline.sh:80-99: lr 1e-4, warmup_ratio 0.04);
 * every step: loss = sum of the task losses (``ln_to_weight`` 1 each), gradient all-reduce across the ranks overlapped with
   the backward (RCCL, engine.GradExchange), ``clip_grad_norm_(1.0)``, AdamW(betas (0.9, 0.999), eps 1e-8, weight_decay 0);
-* checkpoints every ``save_steps`` under ``output_dir/checkpoint-<step>`` (at most ``save_total_limit``) and the final
+* checkpoints every ``save_steps`` under ``output_dir/checkpoint-<step>`` (at most ``save_total_limit``), resumable like HF
+  ``Trainer`` checkpoints (``optimizer.pt``: the AdamW moments and step count, ``rng_state.pth``, ``trainer_state.json``;
+  ``train(resume_from_checkpoint=…)`` continues at the recorded step of the recorded epoch's shuffle), and the final
   model under ``output_dir/checkpoint`` in the layout ``T5SeqAQEncoder.from_pretrained`` reads (config.json +
   pytorch_model.bin under the reference's tensor names + tokenizer files), like ``save_torch_model_and_tokenizer``.
 """
@@ -57,7 +59,8 @@ class LngKnpTrainingArgs:
     adam_beta1: float = 0.9
     adam_beta2: float = 0.999
     adam_epsilon: float = 1e-8
-    bf16: bool = True               # --use_fp16 in the reference's scripts means bf16 autocast (main.py:152)
+    bf16: bool = False              # --use_fp16 in the reference's scripts means bf16 autocast (main.py:152); off unless asked, like
+                                    # TrainingArguments.bf16 and main.py's flag
     task_names: Optional[List[str]] = None
     ln_to_weight: Dict[str, float] = field(default_factory=dict)
 
@@ -81,43 +84,58 @@ class LngKnpTrainer:
     def lr_at(self, step: int) -> float:
         return self.args.learning_rate * linear_schedule_with_warmup(step, self.warmup_steps, self.max_steps)
 
-    def _loader(self, epoch: int):
+    def _loader(self, epoch: int, skip_batches: int = 0):
         from torch.utils.data import DataLoader
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(self.dataset, num_replicas=self.world, rank=self.rank, shuffle=True, seed=self.args.seed)
         sampler.set_epoch(epoch)
-        return DataLoader(self.dataset, batch_size=self.args.per_device_train_batch_size, sampler=sampler,
+        # resume: the batches of this epoch that were consumed before the checkpoint are dropped from the INDEX list, so
+        # no item is fetched for them (the dataset draws negatives from Python's RNG, whose state the checkpoint restored)
+        indices = list(sampler)[skip_batches * self.args.per_device_train_batch_size:]
+        return DataLoader(self.dataset, batch_size=self.args.per_device_train_batch_size, sampler=indices,
                           collate_fn=self.collator, drop_last=False)
 
-    def train(self):
+    def train(self, resume_from_checkpoint: Optional[str] = None):
         import random
         a = self.args
         random.seed(a.seed)          # the dataset draws its negatives from Python's RNG (dataset.py:479-483)
         torch.manual_seed(a.seed)
-        if a.bf16:                   # the reference's autocast: every GEMM operand of the step rounded to bf16, fp32 accumulation
-            self.model.base_model.engine_model().ctx.set_precision("bf16")
-        t0, epoch, window = time.time(), 0, []
-        while self.global_step < self.max_steps:
-            for batch in self._loader(epoch):
-                if self.global_step >= self.max_steps:
-                    break
-                lr = self.lr_at(self.global_step)
-                losses = self.model.training_step(lr=lr, max_grad_norm=a.max_grad_norm, betas=(a.adam_beta1, a.adam_beta2),
-                                                  eps=a.adam_epsilon, weight_decay=a.weight_decay, **batch)
-                self.global_step += 1
-                window.append(losses)
-                if self.global_step % a.logging_steps == 0 or self.global_step == self.max_steps:
-                    mean = {k: float(torch.stack([w[k] for w in window]).mean()) for k in window[0]}   # one sync per log line
-                    rec = dict(step=self.global_step, epoch=self.global_step / self.steps_per_epoch, learning_rate=lr,
-                               loss=sum(mean.values()), **mean, elapsed_s=time.time() - t0)
-                    self.history.append(rec)
-                    if self.rank == 0:
-                        self.log(json.dumps(rec))
-                    window = []
-                if a.save_steps > 0 and self.global_step % a.save_steps == 0 and self.rank == 0:
-                    self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
-                    self._rotate()
-            epoch += 1
+        ctx = self.model.base_model.engine_model().ctx
+        saved_prec = ctx.get_precision() if hasattr(ctx, "get_precision") else None
+        skip = 0
+        if resume_from_checkpoint:
+            skip = self.load_checkpoint_state(resume_from_checkpoint)
+        try:
+            if a.bf16:               # the reference's autocast: every GEMM operand of the step rounded to bf16, fp32 accumulation
+                ctx.set_precision("bf16")
+            t0, epoch, window = time.time(), self.global_step // self.steps_per_epoch, []
+            while self.global_step < self.max_steps:
+                for batch in self._loader(epoch, skip):
+                    if self.global_step >= self.max_steps:
+                        break
+                    lr = self.lr_at(self.global_step)
+                    losses = self.model.training_step(lr=lr, max_grad_norm=a.max_grad_norm, betas=(a.adam_beta1, a.adam_beta2),
+                                                      eps=a.adam_epsilon, weight_decay=a.weight_decay, **batch)
+                    self.global_step += 1
+                    window.append(losses)
+                    if self.global_step % a.logging_steps == 0 or self.global_step == self.max_steps:
+                        mean = {k: float(torch.stack([w[k] for w in window]).mean()) for k in window[0]}   # one sync per log line
+                        rec = dict(step=self.global_step, epoch=self.global_step / self.steps_per_epoch, learning_rate=lr,
+                                   loss=sum(mean.values()), **mean, elapsed_s=time.time() - t0)
+                        self.history.append(rec)
+                        if self.rank == 0:
+                            self.log(json.dumps(rec))
+                        window = []
+                    if a.save_steps > 0 and self.global_step % a.save_steps == 0 and self.rank == 0:
+                        self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
+                        self._rotate()
+                epoch += 1
+                skip = 0
+        finally:
+            # the ctx is shared with the search / evaluation paths of the same process: a training run must not leave them
+            # on bf16 GEMM operands (also when a step raises)
+            if a.bf16 and saved_prec is not None:
+                ctx.set_precision(saved_prec)
         return self.history
 
     # ---- checkpoints ------------------------------------------------------------------------------------------------
@@ -134,7 +152,39 @@ class LngKnpTrainer:
             tokenizer.save_pretrained(path)
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump(dict(global_step=self.global_step, max_steps=self.max_steps, warmup_steps=self.warmup_steps,
-                           learning_rate=self.args.learning_rate, log_history=self.history), f, indent=1)
+                           learning_rate=self.args.learning_rate, steps_per_epoch=self.steps_per_epoch, world=self.world,
+                           log_history=self.history), f, indent=1)
+        # what HF Trainer's optimizer.pt / rng_state.pth carry (tasks/trainer.py of the reference inherits them): the AdamW
+        # moments and step count of the flat device buffers, and the RNG states the data order and the negatives depend on
+        import random
+        st = self.model.train_state() if hasattr(self.model, "train_state") else None
+        if st is not None:
+            torch.save(dict(exp_avg=st.exp_avg.cpu(), exp_avg_sq=st.exp_avg_sq.cpu(), step=int(st.step), total=int(st.total)),
+                       os.path.join(path, "optimizer.pt"))
+        torch.save(dict(python=random.getstate(), torch=torch.get_rng_state()), os.path.join(path, "rng_state.pth"))
+
+    def load_checkpoint_state(self, path: str) -> int:
+        """Restore what ``save_checkpoint`` wrote beside the weights (the caller loads those: ``from_pretrained(path)``):
+        global step, log history, AdamW moments, RNG states. Returns the number of batches of the current epoch to skip."""
+        import random
+        with open(os.path.join(path, "trainer_state.json")) as f:
+            ts = json.load(f)
+        if ts.get("steps_per_epoch", self.steps_per_epoch) != self.steps_per_epoch or ts.get("world", self.world) != self.world:
+            raise ValueError(f"{path}: written with {ts.get('world')} rank(s) x {ts.get('steps_per_epoch')} steps per epoch, "
+                             f"this run has {self.world} x {self.steps_per_epoch}: the data order would not continue")
+        self.global_step, self.history = int(ts["global_step"]), list(ts.get("log_history", []))
+        opt = os.path.join(path, "optimizer.pt")
+        if os.path.exists(opt) and hasattr(self.model, "train_state"):
+            o = torch.load(opt, map_location="cpu")
+            st = self.model.train_state()
+            if int(o["total"]) != int(st.total):
+                raise ValueError(f"{opt}: {o['total']} parameters, the model has {st.total}")
+            st.exp_avg.copy_(o["exp_avg"]); st.exp_avg_sq.copy_(o["exp_avg_sq"]); st.step = int(o["step"])
+        rng = os.path.join(path, "rng_state.pth")
+        if os.path.exists(rng):
+            r = torch.load(rng, map_location="cpu", weights_only=False)
+            random.setstate(r["python"]); torch.set_rng_state(r["torch"])
+        return self.global_step % self.steps_per_epoch
 
     def _rotate(self):
         lim = self.args.save_total_limit

@@ -114,11 +114,17 @@ class _Recorder:
     class _Base:
         class _EM:
             class ctx:
-                prec = None
+                prec = "f16x2"
+                seen = []
 
                 @classmethod
                 def set_precision(cls, p):
                     cls.prec = p
+                    cls.seen.append(p)
+
+                @classmethod
+                def get_precision(cls):
+                    return cls.prec
 
             def export_state_dict(self):
                 return {"w": torch.ones(2)}
@@ -147,7 +153,8 @@ def test_loop_schedule_steps_and_logging(tmp_path):
     tr = T.LngKnpTrainer(rec, ds, coll, args, log=logs.append)
     assert tr.steps_per_epoch == 3 and tr.max_steps == 12 and tr.warmup_steps == 3      # 5 examples, batches of 2, 4 epochs
     hist = tr.train()
-    assert rec.base_model._EM.ctx.prec == "bf16"
+    # bf16 operands for the duration of the run only: the ctx is shared with the search path of the process
+    assert rec.base_model._EM.ctx.seen[-2:] == ["bf16", "f16x2"] and rec.base_model._EM.ctx.prec == "f16x2"
     assert len(rec.calls) == 12 and [c_["n"] for c_ in rec.calls[:3]] == [2, 2, 1]       # the ragged last batch is kept
     want = [1e-4 * T.linear_schedule_with_warmup(i, 3, 12) for i in range(12)]
     assert [c_["lr"] for c_ in rec.calls] == want and want[0] == 0.0 and abs(want[3] - 1e-4) < 1e-18 and want[-1] > 0
@@ -173,3 +180,84 @@ def test_checkpoint_rotation(tmp_path):
     tr.train()
     assert saved == ["checkpoint-2", "checkpoint-4", "checkpoint-6"]
     assert sorted(os.listdir(args.output_dir)) == ["checkpoint-4", "checkpoint-6"]
+
+
+def test_training_restores_the_ctx_precision_when_a_step_raises(tmp_path):
+    c = CASES["L8_smtid"]
+    _write(tmp_path, c["files"])
+    ds = LngKnpMarginMSEforT5SeqAQDataset(str(tmp_path / "examples.jsonl"), None, str(tmp_path / "queries"), None, True)
+    rec = _Recorder()
+    rec.base_model._EM.ctx.prec = "f32"
+
+    def boom(**kw):
+        raise RuntimeError("device step failed")
+
+    rec.training_step = boom
+    tr = T.LngKnpTrainer(rec, ds, LngKnpMarginMSEforT5SeqAQCollator(WordTokenizer(), 16),
+                         T.LngKnpTrainingArgs(output_dir=str(tmp_path / "o"), max_steps=3, bf16=True), log=lambda s: None)
+    with pytest.raises(RuntimeError):
+        tr.train()
+    assert rec.base_model._EM.ctx.prec == "f32"
+    assert T.LngKnpTrainingArgs(output_dir="x").bf16 is False     # off unless --use_fp16, like main.py and TrainingArguments
+
+
+class _State:
+    def __init__(self, n=6):
+        self.total, self.step = n, 0
+        self.exp_avg, self.exp_avg_sq = torch.zeros(n), torch.zeros(n)
+
+
+def test_resume_continues_the_interrupted_run(tmp_path):
+    """A run stopped after a checkpoint and resumed from it feeds the device step exactly what the uninterrupted run fed it
+    from that step on (same batches: epoch shuffle + the negatives drawn from Python's RNG; same learning rates), with the
+    AdamW moments and step count restored."""
+    c = CASES["L8_smtid"]
+    _write(tmp_path, c["files"])
+    ds = LngKnpMarginMSEforT5SeqAQDataset(str(tmp_path / "examples.jsonl"), None, str(tmp_path / "queries"), None, True)
+    coll = LngKnpMarginMSEforT5SeqAQCollator(WordTokenizer(), 16)
+
+    def make(out, max_steps):
+        rec = _Recorder()
+        rec._st = _State()
+        rec.train_state = lambda: rec._st
+        rec.base_model.save_pretrained = lambda path: None
+        step = rec.training_step
+
+        def stepping(**kw):                      # the moments move with every step, like the device optimizer's
+            rec._st.step += 1
+            rec._st.exp_avg += 1.0
+            rec._st.exp_avg_sq += 0.5
+            d = step(**kw)
+            rec.calls[-1]["neg"] = kw["neg_doc_encoding"].tolist()
+            return d
+
+        rec.training_step = stepping
+        args = T.LngKnpTrainingArgs(output_dir=str(tmp_path / out), per_device_train_batch_size=2, max_steps=max_steps, save_steps=4,
+                                    logging_steps=3, warmup_ratio=0.25)
+        os.makedirs(args.output_dir, exist_ok=True)
+        return rec, T.LngKnpTrainer(rec, ds, coll, args, log=lambda s: None)
+
+    import ripor_amd.modeling.t5_generative_retriever as M
+    real = M.expected_keys
+    M.expected_keys = lambda cfg: ["w"]
+    _Recorder._Base.config = None
+    try:
+        full, tr_full = make("full", 10)
+        tr_full.train()
+        part, tr_part = make("part", 10)
+        tr_part.max_steps = 5                      # the run dies after step 5; its last checkpoint is checkpoint-4
+        tr_part.train()
+        ck = str(tmp_path / "part" / "checkpoint-4")
+        assert sorted(os.listdir(ck)) == ["optimizer.pt", "rng_state.pth", "trainer_state.json"]
+        res, tr_res = make("part", 10)
+        tr_res.train(resume_from_checkpoint=ck)
+    finally:
+        M.expected_keys = real
+    assert tr_res.global_step == 10 and len(res.calls) == 6
+    assert res.calls == full.calls[4:]             # steps 4..9: same lr, same examples, same sampled negatives
+    assert res._st.step == full._st.step == 10 and torch.equal(res._st.exp_avg, full._st.exp_avg)
+    assert [h["step"] for h in tr_res.history] == [h["step"] for h in tr_full.history]
+    with pytest.raises(ValueError):                # another batch size: the data order would not continue
+        r2, t2 = make("part", 10)
+        t2.steps_per_epoch += 1
+        t2.train(resume_from_checkpoint=ck)
