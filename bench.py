@@ -39,6 +39,17 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (2:1-sparsity figures 
 PEAK_HBM_TBS = 8.0
 
 
+def _build_id():
+    """sha256 prefix of the sources libripor_hip.so was built from (the stamp __graft_entry__.build() writes beside the library)."""
+    try:
+        return open(os.path.join(REPO, "ripor_amd", "libripor_hip.so.srchash")).read().strip()[:16]
+    except OSError:
+        return "unknown"
+
+
+BUILD_ID = _build_id()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -111,7 +122,7 @@ def cpu_baseline(sd, dims, B, L, n_queries=16, trie_docs=10_000):
     pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
     model = t5_ref.T5Ref(sd, dims)
     ids, mask = synth.make_queries(n_queries + 1, vocab_size=dims.vocab_size, seed=77)
-    best_t, best_dt = None, None
+    best_t, best_dt, probe = None, None, {}
     for th in [t for t in (8, 16, 32, 64) if t <= host_cores] or [host_cores]:
         torch.set_num_threads(th)
         beam_ref.beam_search_ref(model, pm, ids[:1], mask[:1], B, 2)  # thread-pool spin-up
@@ -119,6 +130,7 @@ def cpu_baseline(sd, dims, B, L, n_queries=16, trie_docs=10_000):
         beam_ref.beam_search_ref(model, pm, ids[:1], mask[:1], B, min(L, 6))
         dt = time.time() - t0
         log(f"[bench] cpu_baseline probe: {th} threads -> {dt:.2f}s (1 query, {min(L, 6)} steps)")
+        probe[str(th)] = round(dt, 3)
         if best_dt is None or dt < best_dt:
             best_t, best_dt = th, dt
     torch.set_num_threads(best_t)
@@ -133,7 +145,9 @@ def cpu_baseline(sd, dims, B, L, n_queries=16, trie_docs=10_000):
     dt1 = (time.time() - t1) / 3
     log(f"[bench] cpu_baseline at batch 1: {dt1:.2f}s per query")
     return {"value": n_queries / dt, "unit": "queries/s", "cores": best_t, "kind": "port",
-            "value_batch1": 1.0 / dt1,
+            "value_batch1": 1.0 / dt1, "host_cores": host_cores,
+            "thread_probe_s": probe,   # seconds for 1 query x min(L, 6) steps at each thread count tried; `cores` = the fastest
+
             "sample": f"{n_queries} queries in one batch, t5-base dims fp32, beams={B}, len={L}, "
                       f"{trie_docs}-doc dict+CSR trie (the reference's dict structure for 8.8M docs does not fit "
                       f"host RAM), full-prefix decoder recompute like the reference (no KV cache); "
@@ -286,6 +300,43 @@ def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
         (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, beams, L, steps, warmup=2))
         out[f"beams{beams}"] = {"value": dt * 1e3, "forks_last_step": ctx.last_fork_stats(), "leftover_fallback_taken": fb,
                                 "valid_leaves": f"{int((r.row_hi > r.row_lo).sum().item())}/{beams}"}
+    return out
+
+
+def secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L, steps=8):
+    """the regime north_star's "fraction of the HBM roofline" is about — 1, 8 and 64 queries in flight
+    (the reference script's literal setting is batch 1). Per batch size: queries/s, ms per search, and a `roofline` object
+    of bound "hbm": achieved = SURVEY §8(d)'s algorithmic bytes per query at this Q x queries/s against the 8 TB/s peak
+    (`achieved_forced_tail`: the bytes of the forced-tail algorithm actually run, first fork from the search itself), plus
+    the GEMM launches' share of the search from one event-timed eager pass (`gemm_ms`, `launches`)."""
+    out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams={B}, len={L}, Q queries per search, hipGraph replay", "unit": "queries/s"}
+    for Q in (1, 8, 64):
+        batches = _query_batches(synth, dims, Q, 4, dev, seed=404 + Q)
+        Lq = int(batches[0][0].shape[1])
+        lq_mean = float(sum(float(b[1].sum()) for b in batches) / (len(batches) * Q))
+        (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, B, L, steps, warmup=2))
+        forks = ctx.last_fork_stats()
+        T = forks[0]["depth"] if forks else L
+        by_8d = algorithmic_bytes_per_query(dims, Q, B, L, lq_mean)
+        by_ft, fl_ft = algorithmic_forced_tail_per_query(dims, Q, B, L, lq_mean, T)
+        stats = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], B, L, use_graph=False))
+        n_launch = sum(int(v["launches"]) for v in stats.values())
+        gemm_ms = stats["gemm"]["total_ms"] + stats["gemm_small"]["total_ms"]
+        qps = Q / dt
+        out[f"q{Q}"] = {
+            "value": qps, "ms_per_search": dt * 1e3, "padded_len": Lq, "mean_query_tokens": lq_mean,
+            "forks_last_search": forks, "leftover_fallback_taken": fb, "launches_per_search": n_launch,
+            "gemm_ms_event_timed": gemm_ms,
+            "roofline": {"bound": "hbm", "achieved": by_8d * qps / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                         "frac": by_8d * qps / 1e12 / PEAK_HBM_TBS, "traffic": None,
+                         "algorithmic_bytes_per_query": by_8d,
+                         "achieved_forced_tail": by_ft * qps / 1e9, "frac_forced_tail": by_ft * qps / 1e12 / PEAK_HBM_TBS,
+                         "algorithmic_bytes_per_query_forced_tail": by_ft,
+                         "flops_per_query_forced_tail": fl_ft,
+                         "mfma_frac_forced_tail": fl_ft * qps / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0),
+                         "note": "whole-search figure (the path at this batch size is a chain of dependent launches, no single "
+                                 "kernel dominates): bytes = SURVEY 8(d) per query at this Q (weights once per step per batch, "
+                                 "fp32-sized operands) / the forced-tail algorithm's own bytes; traffic not collected for this leg"}}
     return out
 
 
@@ -453,7 +504,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary exact-fp32 timing")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,v1024",
+    ap.add_argument("--train-steps", type=int, default=5, dest="train_steps", help="timed steps of the secondary train legs")
+    ap.add_argument("--train-bz", type=int, default=128, dest="train_bz", help="examples per GPU and step of the secondary train legs")
+    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,small_batch,v1024",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
                          "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
@@ -557,6 +610,8 @@ def main():
         ids, mask, _ = batches[i]
         return E.search(model, trie, ids, mask, B, L, use_graph=not args.no_graph, apply_log_softmax_for_scores=args.log_softmax)
 
+    gathered = {"bytes": 0}
+
     def timed_region():
         for i in range(W):
             res = run_step(i)
@@ -575,6 +630,7 @@ def main():
             sc_all = torch.empty((world * sc.shape[0],) + tuple(sc.shape[1:]), dtype=sc.dtype, device=dev)
             dist.all_gather_into_tensor(tok_all, tok)
             dist.all_gather_into_tensor(sc_all, sc)
+            gathered["bytes"] = int(tok_all.numel() * tok_all.element_size() + sc_all.numel() * sc_all.element_size())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -612,6 +668,12 @@ def main():
         status_flags = ctx.status(clear=True)   # sticky saturation / empty-query word over everything run so far
         return elapsed, elapsed_pcie, status_flags, results, (tok if world > 1 else None), (sc if world > 1 else None)
 
+    distinct_shards = 1
+    if world > 1:   # every rank works on its own shard of the query pool: the first timed query of each must differ
+        first = torch.tensor([sels[W][0]], dtype=torch.int64, device=dev)
+        lst = [torch.zeros_like(first) for _ in range(world)]
+        dist.all_gather(lst, first)
+        distinct_shards = len({int(x.item()) for x in lst})
     elapsed, elapsed_pcie, status_flags, results, tok, sc = timed_region()
     tail_mode = args.forced_tail
     leftover = bool(status_flags & 4)
@@ -652,6 +714,7 @@ def main():
             "value_pcie_inclusive": world * Q * K / elapsed_pcie,
             "rccl_world_size": dist.get_world_size() if world > 1 else 1,
             "gather_bytes_per_rank": int(tok.numel() * tok.element_size() + sc.numel() * sc.element_size()) if world > 1 else 0,
+            "gathered_bytes_total": gathered["bytes"], "distinct_shards": distinct_shards,
             "saturated": bool(status_flags & 1), "model_f32_only": bool(model.f32_only),
             "forced_tail": {"mode": {0: "off (step-by-step loop)", 1: "exact", 2: "optimistic"}[tail_mode],
                             "forks_last_step": fork_stats,
@@ -728,8 +791,11 @@ def main():
                         if key:
                             # KB per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM)
                             traffic = (2.0 * pmc["FETCH_SIZE"][key[0]]["mean"] + pmc["WRITE_SIZE"][key[0]]["mean"]) * 1024.0
+                            pmc_build = pmc.get("_meta", {}).get("build")
                             traffic_src = ("profiles/latest_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
-                                           "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
+                                           "passes, mean per launch of " + key[0] + ", bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
+                                           f"counters of build {pmc_build if pmc_build else 'r04n (no build id recorded)'}, "
+                                           f"this run is build {BUILD_ID}")
                             # the counters come from an earlier profiled run of tools/profile_round.sh: refuse them when that
                             # run's launch count per step no longer matches this build's (kernels changed since)
                             kn = "gemm_h2_pp_kernel" if args.precision != "f32" else "gemm_f32_kernel"
@@ -752,7 +818,12 @@ def main():
                         if rows:
                             us = float(rows[0]["AverageNs"]) / 1e3
                             mine = g["total_ms"] * 1e3 / max(1, g["launches"])
+                            try:
+                                trace_build = json.load(open(os.path.join(REPO, "profiles", "latest_kernel_stats.meta.json")))["build"]
+                            except Exception:
+                                trace_build = "r04r (no build id recorded)"
                             src = {"file": "profiles/latest_kernel_stats.csv", "row": rows[0]["Name"].split("(")[0],
+                                   "trace_build": trace_build, "this_build": BUILD_ID,
                                    "calls": int(rows[0]["Calls"]), "rocprof_avg_launch_us": us,
                                    "this_run_over_rocprof": mine / us,
                                    "note": "rocprofv3 --kernel-trace --stats of the graph-replayed timed region of an earlier run of "
@@ -862,12 +933,13 @@ def main():
             sec[name] = {"error": repr(e)}
         if rank == 0:
             log(f"[bench] secondary {name}: {time.time() - t0:.1f}s -> "
-                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000")}))
+                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000", "q1", "q8", "q64")}))
 
     if "train" in legs:
-        leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank))
-        if ctx.has_bf16():
-            leg("train_step_bf16", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, precision="bf16"))
+        leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, bz=args.train_bz, steps=args.train_steps))
+        if ctx.has_bf16() and "train_f16x2_only" not in legs:
+            leg("train_step_bf16", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, bz=args.train_bz, steps=args.train_steps,
+                                                                precision="bf16"))
     if world == 1:
         if "f2" in legs:
             leg("f2", lambda: secondary_f2(E, synth, ctx, model, trie, dims, dev))
@@ -877,6 +949,8 @@ def main():
             leg("v1024", lambda: secondary_v1024(E, synth, ctx, dev, args.docs, B, Q))
         if "latency" in legs and args.model == "t5-base":
             leg("latency", lambda: secondary_latency(E, synth, ctx, model, trie, dims, dev, L))
+        if "small_batch" in legs and args.model == "t5-base":
+            leg("small_batch", lambda: secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L))
         if "config4" in legs and args.model == "t5-base":
             leg("config4", lambda: secondary_config4(E, synth, ctx, trie, dev, L))
     if rank == 0:

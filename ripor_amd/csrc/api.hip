@@ -1535,6 +1535,7 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   struct PrecGuard { rpr_ctx* c; int saved; ~PrecGuard() { c->precision = saved; } } guard{c, c->precision};
   if (c->precision == RPR_PREC_BF16) c->precision = RPR_PREC_F16X2;
   if (c->precision == RPR_PREC_F16X2) {  // test hook: split the operands on the fly
+    { const int pe = ensure(c, c->ws.part, (size_t)9 << 20 << 2); if (pe) return pe; }   // split-K scratch, as a search has it
     RPR_HIP(At.alloc((size_t)M * K * 2 * sizeof(__half)));
     RPR_HIP(Wt.alloc((size_t)N * K * 2 * sizeof(__half)));
     RPR_HIP(launch_split_planes(A, At.as<__half>(), (size_t)M * K, (size_t)M * K, s, 1.0f, nullptr, 0, c->status));

@@ -852,6 +852,247 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
   }
 }
 
+// ---- wave-split tiles for a few dozen to ~1500 rows (round 5) ------------------------------------------------------------------
+// The skinny kernel's scheme (four waves split K, private LDS rings, no block barrier in the K walk, fixed-order reduction
+// through LDS) on larger output tiles: (32 TM) x (32 TN) per block. Why: such a launch is bound by what ONE CU can keep in
+// flight between L2 and its LDS (ring bytes / memory latency ~ 60-85 GB/s per CU), and with 32 x 32 tiles every column tile
+// re-streams its activation rows and every row tile the weights: a 280 x 3072 x 768 product moved 165 MB through LDS-DMA
+// (24 us per launch, 121 launches = the tail pass of a single-query search), 640 rows went to 128 x 64 tiles with split-K
+// over blocks plus a separate epilogue launch (17 + 6 us). 64 x 32 and 64 x 64 tiles move 1/2 .. 1/3 of the bytes with the
+// same number of bytes in flight per CU: ST stages of 2 (BM + BN) rows x 64 B per wave = 144 KB (64 x 32, three stages) or
+// 128 KB (64 x 64, two stages) per block. The waves of quadrant (i, j) run the fused epilogue of their 32 x 32 part (the
+// skinny kernel's arithmetic, in the same order: bit-identical results for every tile shape).
+// blockIdx.y = K range of a split-K launch (ksplit > 1: raw partial sums to out[0] + y * part_stride, the caller runs
+// splitk_epilogue*_kernel behind it).
+template <bool FULL, int TM, int TN, int ST>
+__global__ __launch_bounds__(256, 1) void gemm_h2_wsplit_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
+  const float acc_scale = g.dyn_a ? 1.0f / (dyn_plane_scale(*g.dyn_a) * dyn_plane_scale(*g.dyn_b)) : g.acc_scale;
+  constexpr int BM = 32 * TM, BN = 32 * TN, ROWS = 2 * (BM + BN), PIECES = ROWS / 16, NQ = TM * TN;
+  static_assert(NQ <= 4, "one epilogue wave per 32 x 32 quadrant");
+  static_assert((size_t)4 * NQ * 16 * 64 * sizeof(float) <= (size_t)4 * ST * ROWS * HBK * sizeof(__half), "the partial tiles fit the rings");
+  __shared__ __attribute__((aligned(16))) __half smem[4 * ST * ROWS * HBK];
+  const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int bm = tm * BM, bn = tn * BN;
+  int Mlive = g.M;
+  if (g.m_dev) {
+    const int md = *g.m_dev;
+    if (g.live_hi > 0 && (md <= g.live_lo || md > g.live_hi)) return;
+    Mlive = min(md, g.M);
+  }
+  if (bm >= Mlive) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
+  const int qi = wave / TN, qj = wave - qi * TN;            // the quadrant this wave finishes (waves >= NQ: none)
+  const bool fused = g.ksplit <= 1;                          // split-K launches store raw partial sums
+  // epilogue operands of the quadrant waves, requested before the K walk (see gemm_h2_skinny_kernel)
+  unsigned long long e_ssq[16];
+  __half e_rh[16], e_rl[16];
+  float e_rf[16];
+  if (wave < NQ && fused) {
+    const int n = bn + 32 * qj + (lane & 31), rsub = bm + 32 * qi + 4 * (lane >> 5);
+    const bool nok = FULL || n < g.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = rsub + (r & 3) + 8 * (r >> 2);
+      const bool mok = m < Mlive;
+      e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
+      e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
+      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
+      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+    }
+  }
+  // K range of this block, then K-tiles wave, wave + 4, ... of it
+  int nkt = g.K / HBK, kbeg = 0;
+  if (g.ksplit > 1) {
+    const int per = (nkt + g.ksplit - 1) / g.ksplit;
+    kbeg = blockIdx.y * per;
+    nkt = min(per, nkt - kbeg);
+  }
+  // LDS rows of a stage: [A hi: BM][A lo: BM][W hi: BN][W lo: BN]; piece j = rows 16 j .. 16 j + 15
+  const __half* src[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    const int lrow = 16 * j + (lane >> 2);
+    const int seg = (lane & 3) ^ ((lrow >> 2) & 3);
+    const __half* base;
+    int trow, limit;
+    size_t ld;
+    if (lrow < BM) { base = g.A; trow = bm + lrow; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM) { base = g.A + g.a_ps; trow = bm + lrow - BM; limit = g.M; ld = g.lda; }
+    else if (lrow < 2 * BM + BN) { base = g.W; trow = bn + lrow - 2 * BM; limit = g.N; ld = g.ldw; }
+    else { base = g.W + g.w_ps; trow = bn + lrow - 2 * BM - BN; limit = g.N; ld = g.ldw; }
+    if (!FULL && trow >= limit) trow = limit - 1;
+    src[j] = base + (size_t)trow * ld + seg * 8 + (size_t)kbeg * HBK;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                       (__attribute__((address_space(3))) void*)(wsm + (size_t)buf * ROWS * HBK + 16 * j * HBK),
+                                       16, 0, 0);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, sw = (lane >> 2) & 3, hf = lane >> 5;
+  auto compute = [&](int buf) {
+    const __half* base = wsm + (size_t)buf * ROWS * HBK;
+#pragma unroll
+    for (int c = 0; c < HBK / 16; ++c) {
+      const int so = ((2 * c + hf) ^ sw) * 8;
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(base + (32 * i + frow) * HBK + so);
+        al[i] = *reinterpret_cast<const f16x8*>(base + (BM + 32 * i + frow) * HBK + so);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(base + (2 * BM + 32 * j + frow) * HBK + so);
+        bl[j] = *reinterpret_cast<const f16x8*>(base + (2 * BM + BN + 32 * j + frow) * HBK + so);
+      }
+      // per accumulator the skinny kernel's order of the three terms (lo x hi, hi x lo, hi x hi)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int mine = wave < nkt ? (nkt - wave + 3) / 4 : 0;
+  constexpr int KEEP = PIECES * (ST - 2);                         // pieces of the younger tiles that may be pending
+  static_assert(KEEP <= 63, "vmcnt is a 6-bit counter");
+  constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | 0x0f70, WAIT_NONE = 0x0f70;
+#pragma unroll
+  for (int t = 0; t < ST - 1; ++t)
+    if (t < mine) stage(t, (wave + 4 * t) * HBK);
+  for (int i = 0; i < mine; ++i) {
+    if (i + ST - 2 < mine) __builtin_amdgcn_s_waitcnt(WAIT_KEEP); else __builtin_amdgcn_s_waitcnt(WAIT_NONE);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + ST - 1 < mine) stage((i + ST - 1) % ST, (wave + 4 * (i + ST - 1)) * HBK);   // buffer of tile i-1: its reads are done
+    compute(i % ST);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the four waves' partial tiles through LDS (the rings are idle now): quadrant-major, added in the fixed order 0..3
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((i * TN + j) * 4 + wave) * 16 + r) * 64 + lane] = acc[i][j][r];
+  __syncthreads();
+  if (wave >= NQ) return;
+  f32x16 sum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* q = red + ((size_t)(wave * 4) * 16 + r) * 64 + lane;
+    sum[r] = ((q[0] + q[16 * 64]) + q[2 * 16 * 64]) + q[3 * 16 * 64];
+  }
+  const int n = bn + 32 * qj + (lane & 31), rsub = bm + 32 * qi + 4 * (lane >> 5);
+  const bool nok = FULL || n < g.N;
+  if (!fused) {
+    float* outp = g.out[0] + (size_t)blockIdx.y * g.part_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = rsub + (r & 3) + 8 * (r >> 2);
+      if (nok && m < Mlive) outp[(size_t)m * g.ldo[0] + n] = sum[r];
+    }
+    return;
+  }
+  const int oi = nok ? n / g.split_n : 0, on = n - oi * g.split_n;
+  float* outp = g.out[oi];
+  const int ldo = g.ldo[oi];
+  float ssr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = rsub + (r & 3) + 8 * (r >> 2);
+    const bool mok = m < Mlive, ok = nok && mok;
+    float v = sum[r] * acc_scale;
+    if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.resid && ok) v = e_rf[r] + v;
+    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
+    if (ok) {
+      if (g.out_h) {
+        __half hi, lo;
+        split_f16(v * g.plane_scale, hi, lo, g.sat);
+        g.out_h[(size_t)m * g.ldoh + n] = hi;
+        g.out_h[g.o_ps + (size_t)m * g.ldoh + n] = lo;
+        v = (__half2float(hi) + __half2float(lo)) / g.plane_scale;
+      } else {
+        outp[out_off(g, oi, m, ldo, on)] = v;
+      }
+    }
+    ssr[r] = ok ? v * v : 0.f;
+  }
+  if (g.ssq_out) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ssr[r] += __shfl_xor(ssr[r], o, 64);
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = rsub + (r & 3) + 8 * (r >> 2);
+        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int ST>
+static hipError_t launch_wsplit_cfg(const GemmH2Args& k, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  const int tiles_m = (k.M + BM - 1) / BM, tiles_n = (k.N + BN - 1) / BN;
+  const bool full = (k.M % BM == 0) && (k.N % BN == 0) && !k.m_dev;
+  const dim3 grid(tiles_m * tiles_n, k.ksplit > 1 ? k.ksplit : 1);
+  if (full) hipLaunchKernelGGL((gemm_h2_wsplit_kernel<true, TM, TN, ST>), grid, dim3(256), 0, s, k, tiles_m, tiles_n);
+  else hipLaunchKernelGGL((gemm_h2_wsplit_kernel<false, TM, TN, ST>), grid, dim3(256), 0, s, k, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
+// Tile shape and K split of a wave-split launch. These launches are latency-bound by LDS capacity: a block keeps at most its
+// rings in flight (64-96 KB) against a loaded L2 / Infinity-Cache latency of ~3 us, i.e. 40-50 GB/s per CU whatever the tile
+// (tools/fill_probe.hip: the LDS-DMA path itself sustains > 100 GB/s per CU from L2), one block per CU (128-144 KB of LDS).
+// Model fitted to tools/wsplit_bench.sh on MI355X (profiles/r05d_wsplit_gemm_bench.txt): launch = 5 us + rounds of blocks over
+// the CUs x (3 us + KB per block / rate), + one reduction launch for a K split over blocks.
+// cfg 0: 32 x 32 (four stages), 1: 64 x 32 (three), 2: 64 x 64 (two).
+struct WsplitChoice { int cfg, ks; double us; long rounds; };
+static WsplitChoice choose_wsplit(int M, int N, int K, int cus, bool can_split, size_t part_cap) {
+  static const double lat_us = [] { const char* e = getenv("RPR_WSPLIT_LAT_US"); return e ? atof(e) : 3.0; }();
+  static const double split_us = [] { const char* e = getenv("RPR_WSPLIT_SPLIT_US"); return e ? atof(e) : 4.5; }();
+  const int bm[3] = {32, 64, 64}, bn[3] = {32, 32, 64};
+  const double rate_gbs[3] = {48.0, 48.0, 41.0};
+  WsplitChoice best{0, 1, 1e30, 1};
+  for (int c = 0; c < 3; ++c) {
+    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+    for (int ks = 1; ks <= 4; ++ks) {
+      if (ks > 1 && (!can_split || K / ks < 256 || (size_t)M * N * ks > part_cap)) break;
+      const int nkt = K / HBK;
+      if (ks > 1 && (ks - 1) * ((nkt + ks - 1) / ks) >= nkt) continue;
+      const long blocks = tiles * ks, rounds = (blocks + cus - 1) / cus;
+      const double kb = (double)(bm[c] + bn[c]) * ((double)K / ks) * 4.0 * 1e-3;
+      const double us = 5.0 + rounds * (lat_us + kb / rate_gbs[c]) + (ks > 1 ? split_us : 0.0);
+      if (us < best.us) best = {c, ks, us, rounds};
+    }
+  }
+  return best;
+}
+
 template <int BM, int BN, int WM = 2, int WN = 2, bool BF16 = false>
 static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -1175,6 +1416,39 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
+  // 33 .. ~1500 rows (a handful to ~150 queries in flight, the tail pass of one query, beam 1000 at batch 1): wave-split tiles,
+  // shape and K split from choose_wsplit (RPR_WSPLIT_CFG / RPR_WSPLIT_KS force them; RPR_GEMM_WSPLIT_MAX = 0: the routes below)
+  static const int wsplit_max = [] { const char* e = getenv("RPR_GEMM_WSPLIT_MAX"); return e ? atoi(e) : 768; }();
+  static const int wsplit_cfg = [] { const char* e = getenv("RPR_WSPLIT_CFG"); return e ? atoi(e) : -1; }();
+  static const int wsplit_ks = [] { const char* e = getenv("RPR_WSPLIT_KS"); return e ? atoi(e) : 0; }();
+  if (force == 0 && a.M > 32 && a.M <= wsplit_max) {
+    const bool can_split = a.part && a.mid_split && !a.m_dev && (a.N & 63) == 0;
+    WsplitChoice ch = choose_wsplit(a.M, a.N, a.K, a.cus > 0 ? a.cus : 256, can_split, a.part_cap);
+    // beyond the skinny kernel's old range the 128 x 64 split-K route is as fast once the best wave-split shape needs a second
+    // round of blocks (measured at 640 rows: N = 2304 / 3072 27.8 / 28.9 us against 28.9 / 30.0): those launches stay where they were
+    const bool take = a.M <= skinny || ch.rounds <= 1 || wsplit_cfg >= 0;
+    if (wsplit_cfg >= 0 && wsplit_cfg <= 2) ch.cfg = wsplit_cfg;
+    if (wsplit_ks > 0 && (wsplit_ks == 1 || (can_split && (size_t)a.M * a.N * wsplit_ks <= a.part_cap && a.K / wsplit_ks >= 64))) ch.ks = wsplit_ks;
+    auto go = [&](const GemmH2Args& k) {
+      return ch.cfg == 0 ? launch_wsplit_cfg<1, 1, 4>(k, s) : ch.cfg == 1 ? launch_wsplit_cfg<2, 1, 3>(k, s) : launch_wsplit_cfg<2, 2, 2>(k, s);
+    };
+    if (take && ch.ks <= 1) return ch.cfg == 0 ? launch_skinny(a) : go(a);
+    if (take) {
+    GemmH2Args p = a;
+    p.ksplit = ch.ks; p.part_stride = (size_t)a.M * a.N;
+    p.out[0] = p.out[1] = p.out[2] = a.part; p.ldo[0] = p.ldo[1] = p.ldo[2] = a.N; p.split_n = a.N;
+    p.out_h = nullptr; p.resid = nullptr; p.resid_h = nullptr; p.relu = 0; p.row_ssq = nullptr; p.ssq_out = nullptr;
+    p.rm_B = 0; p.acc_scale = 1.0f; p.dyn_a = p.dyn_b = nullptr;
+    hipError_t e = go(p);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)a.M * a.N;
+    const bool vec4 = (a.N & 255) == 0 && (a.split_n & 3) == 0 && (a.ldo[0] & 3) == 0 && (a.ldo[1] & 3) == 0 && (a.ldo[2] & 3) == 0 &&
+                      (!a.resid || (a.ldr & 3) == 0) && (!a.resid_h || (a.ldrh & 3) == 0) && (!a.out_h || (a.ldoh & 3) == 0);
+    if (vec4) hipLaunchKernelGGL(splitk_epilogue4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a, a.part, ch.ks, p.part_stride);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, a.part, ch.ks, p.part_stride);
+    return hipGetLastError();
+    }
+  }
   if (force == 0 && a.M <= skinny) return launch_skinny(a);   // (with m_dev: row tiles past the live rows exit)
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   // A few hundred to a few thousand rows in flight (beam 1000 with one query, beam 100 with a dozen, beam 10 with

@@ -396,7 +396,14 @@ def ddp_setup():
     import torch.distributed as dist
     if "RANK" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        # RPR_DIST_BACKEND: test hook (an 8-rank rehearsal on the one GPU of a test box runs over gloo; RCCL needs a GPU per rank)
+        dist.init_process_group(backend=os.environ.get("RPR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"))
+
+
+def _device_index(local_rank: int) -> int:
+    """The HIP device of this rank: its local rank, like the reference (``model.to(args.local_rank)``). RPR_EVAL_DEVICE: test hook
+    that puts every rank on one device (tests/test_gpu_cli.py: 8 ranks on the single GPU of the test box)."""
+    return int(os.environ.get("RPR_EVAL_DEVICE", local_rank))
 
 
 def _list_flag(v):
@@ -421,24 +428,25 @@ def t5seq_aq_retrieve_docids(args):
     if len(set(model.config.decoder_vocab_sizes)) != 1:
         raise ValueError("not valid decoder_vocab_size")
     max_new_token = args.max_new_token_for_docid
+    device = _device_index(local_rank)
     processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], max_new_token,
-                                        device=local_rank)
+                                        device=device)
     if rank == 0:
         print("max_new_token: ", max_new_token)
         os.makedirs(args.out_dir, exist_ok=True)
     tokenizer = AutoTokenizer.from_pretrained(args.pretrained_path)
-    model.to(local_rank)
+    model.to(device)
     model.base_model.config.decoding = True
     for data_dir in _list_flag(args.q_collection_paths):
         coll = QueryCollection(data_dir)
         out_dir = os.path.join(args.out_dir, get_dataset_name(data_dir))
         print("out_dir: ", out_dir)
         os.makedirs(out_dir, exist_ok=True)  # every rank: removes the reference's mkdir race
-        qbs = search_batch_size(model.config, args.batch_size, args.topk, max_new_token, args.search_batch_size, local_rank)
+        qbs = search_batch_size(model.config, args.batch_size, args.topk, max_new_token, args.search_batch_size, device)
         if rank == 0:
             print(f"queries per search call: {qbs} (--batch_size={args.batch_size})")
         loader = query_batches(coll, tokenizer, shard_indices(len(coll), world, rank), qbs, 256)
-        constrained_decode_doc(model.base_model, loader, processor, table, max_new_token, device=local_rank,
+        constrained_decode_doc(model.base_model, loader, processor, table, max_new_token, device=device,
                                out_dir=out_dir, local_rank=local_rank, topk=args.topk,
                                apply_log_softmax_for_scores=args.apply_log_softmax_for_scores,
                                gather=bool(args.gather_results))

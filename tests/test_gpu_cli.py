@@ -141,6 +141,61 @@ def test_bench_two_ranks_on_one_gpu_through_gloo():
     print("[bench x2 gloo]", d["value"], d["forced_tail"])
 
 
+def test_eight_rank_rehearsal_of_the_scaling_bench_and_the_cli(tmp_path):
+    """the driver's SCALE command (`bench.py --gpus 8`) and an 8-rank `evaluate` run with the RCCL gather must
+    work the first time an 8-GPU node exists. Rehearsed here with 8 gloo ranks sharing the one GPU of the test box
+    (RPR_BENCH_DEVICE / RPR_EVAL_DEVICE hooks; reference evaluate.py:181-182, :468, :503-520): 8 distinct query shards, the
+    end-of-run gather carries 8 x the per-rank bytes, the train leg's bucketed gradient exchange runs over the 8 ranks, and the
+    CLI's gathered run.json equals the single-process one."""
+    import socket
+    repo = REPO
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    # 1. bench.py --gpus 8, search + one f16x2 train step of 8 examples per rank (a gloo all-reduce of 0.94 GB per step)
+    env = dict(os.environ, RPR_BENCH_BACKEND="gloo", RPR_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+           "--batch", "64", "--docs", "200000", "--no-roofline", "--no-cpu-baseline", "--no-exact-fp32",
+           "--secondary", "train,train_f16x2_only", "--train-steps", "1", "--train-bz", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["rccl_world_size"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["queries_per_step_per_gpu"] == 64 and d["value"] > 0
+    per_rank = 64 * 10 * 32 * 4 + 64 * 10 * 4                       # tokens int32 [Q, B, L] + scores f32 [Q, B], one timed step
+    assert d["gather_bytes_per_rank"] == per_rank and d["gathered_bytes_total"] == 8 * per_rank
+    assert d["distinct_shards"] == 8, d.get("distinct_shards")
+    tr = d["secondary"]["train_step"]
+    assert "error" not in tr, tr
+    assert tr["n_gpus"] == 8 and tr["allreduce_bytes_per_step_per_rank"] > 8e8 and tr["value"] > 0
+    print("[bench x8 gloo]", round(d["value"], 1), "q/s;", "train", round(tr["ms_per_step"], 1), "ms/step over gloo")
+
+    # 2. the evaluate CLI: 8 ranks + --gather_results=1 against one process
+    ckpt, d2s_path, qdir, codes, queries, dims = _make_world(str(tmp_path))
+    B, L = 5, 8
+    _run(["-m", "t5_pretrainer.aq_preprocess.build_list_smtid_to_nextids", "--docid_to_smtid_path", d2s_path])
+    common = [f"--pretrained_path={ckpt}", "--task=t5seq_aq_retrieve_docids", f"--docid_to_smtid_path={d2s_path}",
+              "--q_collection_paths=" + json.dumps([qdir]), "--batch_size=2", f"--max_new_token_for_docid={L}", f"--topk={B}"]
+    out1, out8 = os.path.join(str(tmp_path), "out1"), os.path.join(str(tmp_path), "out8")
+    _run(["-m", "t5_pretrainer.evaluate", f"--out_dir={out1}", "--gather_results=1"] + common)
+    _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+          "-m", "t5_pretrainer.evaluate", f"--out_dir={out8}", "--gather_results=1"] + common,
+         env={"RPR_DIST_BACKEND": "gloo", "RPR_EVAL_DEVICE": "0"})
+    files8 = sorted(os.listdir(os.path.join(out8, "MSMARCO")))
+    assert files8 == ["run.json"], files8                            # rank 0 wrote the merged file, no per-rank parts
+    run1 = json.load(open(os.path.join(out1, "MSMARCO", [f for f in os.listdir(os.path.join(out1, "MSMARCO")) if f.startswith("run")][0])))
+    run8 = json.load(open(os.path.join(out8, "MSMARCO", "run.json")))
+    assert set(run8) == set(run1) == set(queries)                    # 11 queries over 8 ranks: wrap-around duplicates merged away
+    for q in run1:
+        assert set(run8[q]) == set(run1[q]), q
+        for doc, sc in run1[q].items():
+            assert abs(run8[q][doc] - sc) < 1e-4, (q, doc)
+
+
 @pytest.mark.gpu
 def test_randomised_parity_sweep():
     """tools/fuzz_parity.py, 16 seeded random cases (trie size, length, beams, V, skew, duplicates, log-softmax, explicit forks,

@@ -212,3 +212,53 @@ def test_bench_configuration_matches_plain_fp32_loop(world):
         ctx.set_precision("f16x2")
         ctx.set_forced_tail(saved_mode)
         ctx.set_lane_split(saved_split)
+
+
+def test_mid_size_trie_against_the_kv_cached_oracle():
+    """between "3000 docs against the reference" (the goldens) and "8.8 M docs against the library itself"
+    (the tests above) — t5-base dims, a 100 000-doc trie, beam 10, len 32, automatic forks (first fork at depth >= 3: the forced
+    tail, the compacted stage and the fork kernels all run), six queries, against the CPU oracle (KV-cached variant of the
+    restatement, oracle/t5_ref.py T5RefCached + oracle/beam_ref.py with the reference's dict-of-strings mask; pinned to the
+    reference by tests/test_oracle_golden.py). Same comparator as the goldens' (`_same_ranked`: the set of smtids, scores
+    within 1e-4, identical tokens wherever the oracle's neighbouring scores are > 2e-4 apart), plus the docid fan-out."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    N, B, nq = 100_000, 10, 6
+    ctx = E.Context.get(0)
+    ctx.set_precision("f16x2")
+    dims = synth.t5_base_dims(L=L, V=V)
+    sd = synth.make_state_dict(dims)
+    codes = synth.make_codes(N, L, V, seed=31)
+    ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=9)
+    # oracle (CPU): the reference's trie dicts for 100 k docs take ~25 s and ~3 GB to build, the search ~20 s
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    d2s = synth.codes_to_docid_to_smtid(codes)
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(d2s), V)
+    ref_model = t5_ref.T5RefCached(sd, dims)
+    seqs, scores = beam_ref.beam_search_ref(ref_model, pm, ids, mask, B, L, use_kv_cache=True)[:2]
+    ref_tok = np.asarray(seqs).reshape(nq, B, L + 1)[:, :, 1:]
+    ref_sc = np.asarray(scores, dtype=np.float64).reshape(nq, B)
+    del pm
+    # HIP path
+    model = E.DeviceModel(ctx, sd, dims)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    ctx.status(clear=True)
+    for mode in (2, 1):                                   # optimistic (repeat exactly if a query was left over), then exact
+        ctx.set_forced_tail(mode)
+        res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+        torch.cuda.synchronize()
+        forks = ctx.last_fork_stats()
+        if mode == 2 and ctx.status(clear=True) & 4:
+            continue
+        assert forks and forks[0]["depth"] >= 3, forks
+        tok, sc = res.tokens.cpu().numpy(), res.scores.cpu().numpy().astype(np.float64)
+        lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
+        for q in range(nq):
+            _same_ranked(tok[q], sc[q], ref_tok[q], ref_sc[q], f"mode {mode} query {q}")
+            for b in range(B):
+                docs = sorted(int(r) for r in trie.perm[lo[q, b]:hi[q, b]])
+                want = sorted(i for i in np.flatnonzero((codes == tok[q, b][None, :]).all(1)))
+                assert docs == want and docs, (q, b)
+    ctx.set_forced_tail(2)
+    print(f"[mid-size] {N} docs, forks {forks}: {nq} queries == KV-cached oracle")

@@ -9,6 +9,8 @@ margin is > 2e-3, tests/test_oracle_golden.py::test_fixture_margins_are_comforta
 match within 1e-4; the tokens at a rank must be identical whenever the reference's score at that rank is more than
 2e-4 away from both neighbours. The counts of checked / near-tie ranks are printed per fixture.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,7 @@ LOGIT_TOL = 5e-4     # fp32 logits O(10..100) through 12-24 layers; reference-vs
                      # split-precision GEMMs by <= ~1e-4 from exact fp32 (tools/precision_probe.py)
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -317,6 +320,61 @@ def test_gemm_kernels_are_repeatable_bitwise(engine, M, N, K):
     assert (first.double() - ref).abs().max().item() < 5e-5
     for _ in range(8):
         assert torch.equal(ctx.linear(A, W, R), first)
+
+
+_WSPLIT_SCRIPT = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, %r)
+from ripor_amd import engine as E
+ctx = E.Context.get(0)
+out = {}
+for (M, N, K, relu, resid) in [(40, 768, 768, False, True), (280, 2304, 768, False, False), (333, 256, 768, True, False),
+                               (640, 768, 3072, False, True), (70, 96, 64, True, True), (129, 1024, 1024, False, True), (700, 3072, 768, True, False)]:
+    torch.manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * K ** -0.5
+    R = torch.randn(M, N, device="cuda") if resid else None
+    first = ctx.linear(A, W, R, relu)
+    for _ in range(3):
+        assert torch.equal(ctx.linear(A, W, R, relu), first), "not repeatable"
+    ref = A.double() @ W.double().t()
+    ref = torch.relu(ref) if relu else ref
+    ref = ref + R.double() if resid else ref
+    out[f"{M}x{N}x{K}"] = {"err": (first.double() - ref).abs().max().item(), "scale": max(1.0, ref.abs().max().item()),
+                           "sha": hashlib.sha256(first.cpu().numpy().tobytes()).hexdigest()}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _wsplit_run(env):
+    import json
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, "-c", _WSPLIT_SCRIPT % REPO], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_wave_split_gemm_tiles_agree_with_each_other_and_with_fp64():
+    """Round 5: gemm_h2_wsplit_kernel (64 x 32 and 64 x 64 tiles next to the 32 x 32 skinny tile, optional K split over blocks
+    with the fused reduction launch) for 33 .. 768 rows. Forced through RPR_WSPLIT_CFG / RPR_WSPLIT_KS in subprocesses (the
+    route is read once per process): every shape within the split-precision bar of the fp64 product and repeatable; without a
+    K split over blocks the three tile shapes sum every output in the same order and must agree BIT FOR BIT (ragged M / N,
+    residual, ReLU included); the automatic choice must be one of them."""
+    base = _wsplit_run({"RPR_WSPLIT_CFG": "0", "RPR_WSPLIT_KS": "1"})
+    for cfg in ("1", "2"):
+        got = _wsplit_run({"RPR_WSPLIT_CFG": cfg, "RPR_WSPLIT_KS": "1"})
+        for k, v in got.items():
+            assert v["err"] < 2e-5 * v["scale"], (cfg, k, v)
+            assert v["sha"] == base[k]["sha"], f"tile shape {cfg} differs from the 32 x 32 tile on {k}"
+    for cfg, ks in (("0", "2"), ("1", "2"), ("2", "4")):
+        got = _wsplit_run({"RPR_WSPLIT_CFG": cfg, "RPR_WSPLIT_KS": ks})
+        for k, v in got.items():
+            assert v["err"] < 2e-5 * v["scale"], (cfg, ks, k, v)
+    auto = _wsplit_run({})
+    old = _wsplit_run({"RPR_GEMM_WSPLIT_MAX": "0"})
+    for k, v in auto.items():
+        assert v["err"] < 2e-5 * v["scale"] and old[k]["err"] < 2e-5 * old[k]["scale"], (k, v, old[k])
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if "b100" in n])

@@ -33,8 +33,13 @@ for name, f in (("FETCH_SIZE", "$OUT/pmc_fetch/p_counter_collection.csv"), ("WRI
         if r["Counter_Name"] == name and "rpr::" in r["Kernel_Name"]:
             agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     out[name] = {k: {"launches": len(v), "sum": sum(v), "mean": sum(v) / len(v)} for k, v in agg.items()}
-out["_meta"] = {"steps_in_pmc_pass": 2, "note": "bench.py --steps 1 --warmup 0 runs the step twice (resident-input loop + PCIe-inclusive loop); launches = dispatches counted over both"}
+import sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+import __graft_entry__ as ge
+build = {"tag": "$TAG", "source_hash": ge.source_hash()[:16]}   # which build of libripor_hip.so the counters / the trace belong to
+out["_meta"] = {"steps_in_pmc_pass": 2, "build": build, "note": "bench.py --steps 1 --warmup 0 runs the step twice (resident-input loop + PCIe-inclusive loop); launches = dispatches counted over both"}
 json.dump(out, open("$OUT/hbm_pmc.json", "w"), indent=1)
+json.dump({"build": build, "command": "$B --no-cpu-baseline --no-exact-fp32 --no-roofline --secondary ''"}, open("$OUT/kernel_stats.meta.json", "w"), indent=1)
 # MFMA pass: per kernel mean counter values per launch + mean duration of the same dispatches (kernel trace of that pass)
 try:
     dur = collections.defaultdict(dict)
