@@ -340,6 +340,32 @@ def secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L, steps=8):
     return out
 
 
+def secondary_heavy_tail(E, synth, ctx, trie, dims, dev, B, L, Q, steps=4, target=1e5):
+    """the headline configuration on weights with the activation statistics of trained T5 checkpoints
+    (synth.make_state_dict(outliers=1e5): residual channels of ~5e4 from the embedding to the last block) instead of N(0, sigma)
+    weights: queries/s, whether any activation left the f16 planes, and how many of the timed batches the guard of the
+    reference-shaped entry point would have repeated in exact fp32."""
+    sd = synth.make_state_dict(dims, outliers=target, logit_scale=3.0)
+    model = E.DeviceModel(ctx, sd, dims)
+    batches = _query_batches(synth, dims, Q, 2, dev, seed=505)
+    repeated = 0
+    ctx.status(clear=True)
+    for b in batches:                                     # warm-up (graphs) + one flag check per batch
+        E.search(model, trie, b[0], b[1], B, L)
+        if ctx.status(clear=True) & 1:
+            repeated += 1
+    (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, B, L, steps, warmup=0))
+    sat = bool(ctx.status(clear=True) & 1)
+    out = {"value": Q / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "workload": f"t5-base dims with heavy-tailed weights (outlier channels ~{target:g}), {trie.N}-doc trie, beams={B}, len={L}, {Q} queries/step",
+           "saturated": sat, "model_f32_only": bool(model.f32_only), "batches_checked": len(batches),
+           "batches_the_guard_would_repeat_in_fp32": repeated, "leftover_fallback_taken": fb,
+           "valid_leaves": f"{int((r.row_hi > r.row_lo).sum().item())}/{Q * B}"}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_f2(E, synth, ctx, model, trie, dims, dev, queries=214, steps=5):
     """the training-data generation callers (evaluate.py:134-178; full_evaluate_t5seq_aq_encoder.sh:117-147):
     the same search at max_new_token 4 / 8 / 16 with topk = 100."""
@@ -506,7 +532,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5, dest="train_steps", help="timed steps of the secondary train legs")
     ap.add_argument("--train-bz", type=int, default=128, dest="train_bz", help="examples per GPU and step of the secondary train legs")
-    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,small_batch,v1024",
+    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,small_batch,heavy_tail,v1024",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
                          "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
@@ -933,7 +959,7 @@ def main():
             sec[name] = {"error": repr(e)}
         if rank == 0:
             log(f"[bench] secondary {name}: {time.time() - t0:.1f}s -> "
-                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000", "q1", "q8", "q64")}))
+                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000", "q1", "q8", "q64", "saturated")}))
 
     if "train" in legs:
         leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, bz=args.train_bz, steps=args.train_steps))
@@ -949,6 +975,8 @@ def main():
             leg("v1024", lambda: secondary_v1024(E, synth, ctx, dev, args.docs, B, Q))
         if "latency" in legs and args.model == "t5-base":
             leg("latency", lambda: secondary_latency(E, synth, ctx, model, trie, dims, dev, L))
+        if "heavy_tail" in legs and args.model == "t5-base":
+            leg("heavy_tail", lambda: secondary_heavy_tail(E, synth, ctx, trie, dims, dev, B, L, Q))
         if "small_batch" in legs and args.model == "t5-base":
             leg("small_batch", lambda: secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L))
         if "config4" in legs and args.model == "t5-base":

@@ -372,9 +372,9 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
           for (int e = 0; e < 4; ++e) {
             f32x2 x = v[e] * sc;
             if (g.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); }
-            if (RES) {   // X_PLANE_SCALE == 1
-              x += __builtin_convertvector(reinterpret_cast<const f16x2*>(&rh[RES ? kb + k : 0])[e], f32x2) +
-                   __builtin_convertvector(reinterpret_cast<const f16x2*>(&rl_[RES ? kb + k : 0])[e], f32x2);   // hi + lo is exact in fp32
+            if (RES) {   // the residual from its planes: (hi + lo) / X_PLANE_SCALE, both steps exact in fp32
+              x += (__builtin_convertvector(reinterpret_cast<const f16x2*>(&rh[RES ? kb + k : 0])[e], f32x2) +
+                    __builtin_convertvector(reinterpret_cast<const f16x2*>(&rl_[RES ? kb + k : 0])[e], f32x2)) * (1.0f / X_PLANE_SCALE);
             }
             ss2 += x * x;
             f32x2 xs = x * ps;

@@ -121,13 +121,21 @@ def mini_dims(L: int = 8, V: int = 256, enc_layers: int = 2, d_ff: int = 256,
                      decoder_vocab_sizes=[V] * L, **kw)
 
 
-def make_state_dict(dims: ModelDims, seed: int = SEED, logit_scale: float = 0.35) -> Dict[str, np.ndarray]:
+def make_state_dict(dims: ModelDims, seed: int = SEED, logit_scale: float = 0.35, outliers: float = 0.0) -> Dict[str, np.ndarray]:
     """Seeded weights under the reference's state-dict key names (float32 numpy arrays).
 
     Scales follow HF's T5 init factors so activations stay O(1); layer-norm weights are
     perturbed around 1 and the relative-bias tables are O(1) so that a kernel that drops
     either is caught by the parity tests. ``logit_scale`` sets the output-codebook spread
     (logits come out O(10), like a trained model's dot-product scores).
+
+    ``outliers`` > 0: the activation statistics trained T5 checkpoints are known for (the reason HF clamps fp16 T5), which the
+    N(0, sigma) weights above do not have — (1) three residual-stream channels of about ``outliers`` (e.g. 1e5) in both stacks:
+    large embedding columns, and feed-forward output rows of one sign on those channels whose size rises geometrically with
+    depth; (2) layer-norm weights that are tiny on the outlier channels and spread up to ~8 elsewhere;
+    (3) four hidden units per feed-forward block with 150 x larger input weights (the most the f16 weight planes carry) against
+    tiny output weights. The residual stream then carries |x| of 0.4-0.6 x ``outliers`` from the embedding to the last block.
+    The model is still an ordinary T5 state dict: the CPU oracle and the exact-fp32 path run it unchanged.
     """
     d, inner, dff = dims.d_model, dims.inner, dims.d_ff
     sd: Dict[str, np.ndarray] = {}
@@ -175,7 +183,42 @@ def make_state_dict(dims: ModelDims, seed: int = SEED, logit_scale: float = 0.35
         if not dims.shared_output_input_embeds:
             u(f"list_output_embeds.{i}.weight", (V, d), logit_scale)
     u("start_token_embed", (1, 1, d), 1.0)
+    if outliers > 0.0:
+        _add_outliers(sd, dims, float(outliers), seed)
     return sd
+
+
+def _add_outliers(sd: Dict[str, np.ndarray], dims: ModelDims, target: float, seed: int) -> None:
+    """See make_state_dict(outliers=...). In place."""
+    d, dff = dims.d_model, dims.d_ff
+    chans = np.array([17 % d, 301 % d, 642 % d])
+    base = 0.15 * target                                     # outlier size right after the embedding (massive from the start,
+                                                             # as in trained T5 stacks; the blocks below grow it ~4 x)
+    for name in ["shared.weight", "start_token_embed"] + [f"list_decoder_embeds.{i}.weight" for i in range(len(dims.decoder_vocab_sizes))]:
+        w = sd[name]
+        w[..., chans] = np.abs(w[..., chans]) * base + base
+    lnw = 0.5 + 7.5 * (uniform_f32("outlier/ln", (d,), 0.5, seed) + 0.5) ** 3      # most weights ~1, a tail up to ~8
+    lnw[chans] = 0.02
+    for stack, n, ff in (("encoder", dims.num_layers, 1), ("decoder", dims.num_decoder_layers, 2)):
+        prev = base * 1.5
+        for i in range(n):
+            p = f"{stack}.block.{i}.layer"
+            for k in range(ff + 1):
+                sd[f"{p}.{k}.layer_norm.weight"] = (lnw * (1.0 + 0.1 * uniform_f32(f"outlier/{stack}{i}{k}", (d,), 1.0, seed))).astype(np.float32)
+            wi, wo = sd[f"{p}.{ff}.DenseReluDense.wi.weight"], sd[f"{p}.{ff}.DenseReluDense.wo.weight"]
+            # residual outliers: this block adds (next - prev) to the outlier channels — its ReLU output u >= 0 meets output
+            # rows of one sign; sum_j |wo[c, j]| u_j ~ 0.3 * 0.8 * dff^-0.5 * dff * rms(u) per unit of row scale
+            nxt = base * 1.5 * (target / (base * 1.5)) ** ((i + 1) / n)
+            g = (nxt - prev) / (0.24 * dff ** 0.5 * 0.12)     # 0.12: measured rms of the ReLU output behind the squashed norm
+            wo[chans, :] = np.minimum(np.abs(wo[chans, :]) * g, 200.0)   # (the f16 weight planes carry |w| < 255)
+            prev = nxt
+            # a few hidden units with large pre-activations and tiny output weights (as large as the f16 weight planes allow:
+            # |w x layer-norm weight| < 255, common.h): the FF intermediate's own range is exercised by test_gpu_edges.py
+            units = (np.arange(4) * 769 + 31 * i) % dff
+            wi[units, :] *= 150.0
+            wo[:, units] *= 1e-3
+    for name in ("encoder.final_layer_norm.weight", "decoder.final_layer_norm.weight"):
+        sd[name] = lnw.astype(np.float32).copy()
 
 
 # --------------------------------------------------------------------------- docid codes

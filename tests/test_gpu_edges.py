@@ -233,6 +233,52 @@ def test_ff_intermediate_beyond_f16_range(setup):
     np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("target", [1e4, 1e5, 1e6])
+def test_heavy_tailed_residual_stream_needs_no_fp32_fallback(setup, target):
+    """trained T5 checkpoints carry a few residual channels of 1e3 .. 1e5 (synth.make_state_dict(outliers=...)
+    models them: |x| of 0.4-0.6 x target from the embedding to the last block). The residual planes are scaled by 2^-4 since
+    round 5 (|x| < 1.05e6; round 4: unscaled, |x| < 65504 — every batch of such a model was repeated on the exact-fp32 path).
+    The split-precision search must (1) not raise the saturation flag, (2) return the oracle's ranking (fp32 CPU) within the
+    usual bars, (3) agree with the library's exact-fp32 mode."""
+    from oracle import beam_ref, t5_ref
+    E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
+    L, V, N, B, Q = 8, 256, 1000, 4, 5
+    dims = synth.mini_dims(L=L, V=V, enc_layers=2, d_ff=128, vocab_size=512)
+    sd = synth.make_state_dict(dims, seed=91, outliers=target, logit_scale=3.0)
+    codes = synth.make_codes(N, L, V, seed=91)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=92, max_len=12)
+    ref = t5_ref.T5RefCached(sd, dims)
+    enc = ref.encode(torch.from_numpy(ids).long(), torch.from_numpy(mask).long())
+    x0 = torch.from_numpy(sd["shared.weight"])[torch.from_numpy(ids[0]).long()]
+    assert 0.1 * target < float(x0.abs().max()) < 1.05e6, float(x0.abs().max())       # the premise: the stream really is that large
+    pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
+    seqs, sc = beam_ref.beam_search_ref(ref, pm, ids, mask, B, L, use_kv_cache=True)
+    exp_tok, exp_sc = seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:], sc.numpy().reshape(Q, B).astype(np.float64)
+    model = E.DeviceModel(ctx, sd, dims)
+    assert not model.f32_only
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    out = {}
+    for prec in ("f16x2", "f32"):
+        ctx.set_precision(prec)
+        ctx.status(clear=True)
+        res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+        torch.cuda.synchronize()
+        flags = ctx.status(clear=True)
+        assert not (flags & E._lib.STATUS_SATURATED), f"{prec}: an activation left the plane range at |x| ~ {target:g}"
+        out[prec] = (res.tokens.cpu().numpy(), res.scores.cpu().numpy().astype(np.float64))
+    ctx.set_precision("f16x2")
+    for prec, (tok, scs) in out.items():
+        for q in range(Q):
+            got = {tuple(t): s for t, s in zip(tok[q].tolist(), scs[q])}
+            want = {tuple(t): s for t, s in zip(exp_tok[q].tolist(), exp_sc[q])}
+            assert got.keys() == want.keys(), (prec, q)
+            for k in want:
+                assert abs(got[k] - want[k]) <= 1e-4, (prec, q, got[k], want[k])
+    assert np.abs(out["f16x2"][1] - out["f32"][1]).max() <= 5e-5
+    print(f"[heavy-tail] target {target:g}: max |score(f16x2) - score(f32)| = {np.abs(out['f16x2'][1] - out['f32'][1]).max():.2e}, "
+          f"vs oracle {max(np.abs(out['f16x2'][1] - exp_sc).max(), 0):.2e}")
+
+
 def test_long_docids_beyond_the_register_attention_path(setup):
     """L = 40 positions: self-attention depths 33..36 run the largest register instantiation and 37..40 the generic
     LDS kernel (the reference's docids have 32 or 16 positions; the library accepts up to 64)."""
