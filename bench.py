@@ -925,6 +925,11 @@ def main():
         if world == 1 and not args.no_roofline:
             try:
                 out["board_power"] = board_power_under(lambda: run_step(W))
+                if out["board_power"]:
+                    # energy per query from the sampled mean board power and this run's rate (a change
+                    # that saves watts at equal queries/s must be visible): J = W x s per step / queries per step
+                    out["board_power"]["energy_j_per_query"] = out["board_power"]["power_w_mean"] * (elapsed / K) / Q
+                    out["board_power"]["energy_note"] = "power_w_mean x ms_per_step / queries per step (sampled power, not an energy counter)"
             except Exception as e:
                 out["board_power"] = {"error": repr(e)}
         if world == 1 and args.precision != "f32" and not args.no_exact_fp32:

@@ -448,6 +448,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     SelectArgs sa{};
     sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
     sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = Vp; sa.Vreal = V; sa.t = t;
+    if (tr->lvl_V == tr->V) { sa.lvl0 = tr->lvl0; sa.lvl1 = tr->lvl1; sa.lvl_V = tr->lvl_V; }
     sa.log_softmax = (sd.flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
     sa.shared0 = (Bt != B) ? 1 : 0;
     sa.nq_dev = sv.nq_dev;
@@ -1002,6 +1003,34 @@ static int upload_trie(rpr_ctx* c, std::unique_ptr<rpr_trie>& t) {
   RPR_HIP(hipSetDevice(c->device));
   RPR_HIP(hipMalloc(&t->codes, t->host_sorted.size() * sizeof(uint16_t)));
   RPR_HIP(hipMemcpy(t->codes, t->host_sorted.data(), t->host_sorted.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  // child arrays of the first two levels (see rpr_trie): one pass over the sorted rows
+  static const bool levels_on = [] { const char* e = getenv("RPR_SELECT_LEVELS"); return !(e && atoi(e) == 0); }();
+  if (levels_on && t->N < ((int64_t)1 << 31) - 1) {
+    const int V = t->V, L = t->L;
+    const int64_t N = t->N;
+    const uint16_t* c = t->host_sorted.data();
+    std::vector<int32_t> l0((size_t)V + 1, (int32_t)N);
+    {
+      int next = 0;                                   // tokens < next have their lower bound
+      for (int64_t r = 0; r < N; ++r) {
+        const int v = c[(size_t)r * L];
+        while (next <= v) l0[(size_t)next++] = (int32_t)r;
+      }
+    }
+    RPR_HIP(hipMalloc(&t->lvl0, l0.size() * 4));
+    RPR_HIP(hipMemcpy(t->lvl0, l0.data(), l0.size() * 4, hipMemcpyHostToDevice));
+    if (L >= 2 && V <= 1024) {
+      std::vector<int32_t> l1((size_t)V * V + 1, (int32_t)N);
+      int64_t next = 0;
+      for (int64_t r = 0; r < N; ++r) {
+        const int64_t v = (int64_t)c[(size_t)r * L] * V + c[(size_t)r * L + 1];
+        while (next <= v) l1[(size_t)next++] = (int32_t)r;
+      }
+      RPR_HIP(hipMalloc(&t->lvl1, l1.size() * 4));
+      RPR_HIP(hipMemcpy(t->lvl1, l1.data(), l1.size() * 4, hipMemcpyHostToDevice));
+    }
+    t->lvl_V = V;
+  }
   return RPR_OK;
 }
 
@@ -1152,6 +1181,7 @@ int rpr_trie_set_vocab(rpr_trie* t, int32_t V) {
   uint16_t mx = 0;
   for (uint16_t v : t->host_sorted) mx = v > mx ? v : mx;
   RPR_REQUIRE((int)mx < V, "a code of the trie is >= the requested vocab size");
+  if (V != t->V) t->lvl_V = 0;   // the level tables are indexed with the vocab size they were built for: searches fall back to the probes
   t->V = V;
   return RPR_OK;
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   for (int item = tid; item < items; item += 4 * 256) {
     // four (beam, token) pairs per thread advance their binary searches in lockstep: the four probes of a step
     // are independent loads (one search at a time was one dependent L2/HBM latency per probe)
-    int lo4[4], hi4[4], end4[4], c4[4];
+    int lo4[4], hi4[4], end4[4], c4[4], tab4[4], nxt4[4];
     bool act[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -141,6 +141,17 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       const bool narrow = hi - lo <= NARROW;           // wave-uniform: a wave covers 64 tokens of one beam
       act[u] = in && !narrow && it < search_items;
       lo4[u] = lo; hi4[u] = (act[u] && t < Lc) ? hi : lo; end4[u] = hi; c4[u] = c;
+      tab4[u] = -1;
+      if (act[u] && t < Lc && c < a.lvl_V) {
+        // levels 0 / 1: the lower bound of (prefix, c) and of its successor straight from the trie's child arrays
+        // (the range of this beam is [lvl0[c0], lvl0[c0 + 1]) at step 1: its rows share code 0 = c0)
+        if (t == 0 && a.lvl0) { tab4[u] = a.lvl0[c]; nxt4[u] = a.lvl0[c + 1]; hi4[u] = lo; }
+        else if (t == 1 && a.lvl1) {
+          const int c0 = a.cur.tokens[(size_t)(r0 + b) * a.cur.ld];
+          const int32_t* row = a.lvl1 + (size_t)c0 * a.lvl_V + c;
+          tab4[u] = row[0]; nxt4[u] = row[1]; hi4[u] = lo;
+        }
+      }
     }
     for (;;) {
       int v4[4];
@@ -166,8 +177,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int it = item + u * 256;
       if (!act[u]) continue;                           // wave-uniform
-      const int l = lo4[u];
-      const bool ok = t < Lc && l < end4[u] && (int)a.codes[(size_t)l * Lc + t] == c4[u];
+      const bool tab = tab4[u] >= 0;                   // (per lane: tokens >= the trie's vocab size have no table entry)
+      const int l = tab ? tab4[u] : lo4[u];
+      const bool ok = tab ? nxt4[u] > l : (t < Lc && l < end4[u] && (int)a.codes[(size_t)l * Lc + t] == c4[u]);
       lb_q[it] = l;
       const unsigned long long m = __ballot(ok);
       if (lane == 0) valid[it >> 6] = m;

@@ -122,6 +122,7 @@ struct GemmH2Args {
   int bf16;                                // 1: A and W are single bf16 planes (training GEMMs, RPR_PREC_BF16); fp32 output only
   int prefer_pp;                           // 1: the 256x256 ping-pong kernel whatever the tile count, one K-loop per tile (weight gradients:
                                            // few tiles, thousands of K rows, several launches side by side on separate streams)
+  int band;                                // 256x256 kernel: row panels per band of the tile walk (set by the launcher; <= 1: row-major)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 
@@ -275,6 +276,9 @@ struct SelectArgs {
   int Lc;                    // row stride of codes (trie depth)
   BeamState cur, nxt;
   int32_t* lb_scratch;       // [R, V] lower bounds found by the mask phase
+  const int32_t* lvl0;       // nullable: child arrays of trie levels 0 / 1 (rpr_trie::lvl0 / lvl1), row stride lvl_V
+  const int32_t* lvl1;
+  int lvl_V;
   int Q, B, V, t;            // V: width of the token axis = the model's vocab rounded up to 64 (logits row stride)
   int Vreal;                 // the model's decoder vocab size (0 = V): tokens >= Vreal are padding and never selectable
   int log_softmax;

@@ -65,11 +65,18 @@ struct rpr_trie {
   int64_t N;
   int L, V;
   uint16_t* codes = nullptr;  // [dev] sorted [N, L]
+  // [dev] child arrays of the first two trie levels (round 5): lvl0[c] = first sorted row whose code 0 is >= c (V + 1 entries,
+  // lvl0[V] = N), lvl1[c0 * V + c1] = first row >= (c0, c1) (V * V + 1 entries; only for V <= 1024, L >= 2). The selection
+  // kernel reads a child's row range from them at steps 0 and 1 instead of walking 23 / 16 dependent probes of a binary
+  // search over the code matrix. Built for the trie's V at upload; dropped by rpr_trie_set_vocab.
+  int32_t* lvl0 = nullptr;
+  int32_t* lvl1 = nullptr;
+  int lvl_V = 0;
   std::vector<int64_t> perm;
   std::vector<uint16_t> host_sorted;
   std::string keys;           // docid strings in original row order, '\n'-joined (only when loaded from a file that has them)
   std::map<int, std::vector<double>> single_frac;   // per search length L: trie_single_frac (lazily, first search of that length)
-  ~rpr_trie() { if (codes) (void)hipFree(codes); }
+  ~rpr_trie() { if (codes) (void)hipFree(codes); if (lvl0) (void)hipFree(lvl0); if (lvl1) (void)hipFree(lvl1); }
 };
 
 struct rpr_d2s {

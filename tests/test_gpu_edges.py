@@ -4,10 +4,13 @@ num_beams=1, the oracle treats it as the degenerate case), single query, L=1, lo
 multi-chunk attention paths), masks that are not a prefix (left padding, holes), ragged batches whose
 row count is not a multiple of any GEMM tile, exact-fp32 precision mode."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -448,3 +451,47 @@ def test_lane_split_gives_the_results_of_one_call(setup):
         ctx.set_precision("f16x2")
     finally:
         ctx.set_lane_split(saved if saved else 10240)
+
+
+_LEVELS_SCRIPT = r"""
+import hashlib, json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from ripor_amd import engine as E
+from ripor_amd.utils import synth
+ctx = E.Context.get(0)
+out = {}
+for (N, V, L, B, zipf) in [(300_000, 256, 8, 10, 0.0), (120_000, 200, 6, 4, 1.0), (50_000, 1024, 4, 10, 0.0), (40_000, 2048, 4, 3, 0.0)]:
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, vocab_size=512)
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims, seed=5), dims)
+    codes = synth.make_codes(N, L, V, seed=6, zipf=zipf) if zipf else synth.make_codes(N, L, V, seed=6)
+    trie = E.DeviceTrie.from_codes(ctx, codes, V)
+    ids, mask = synth.make_queries(7, vocab_size=512, seed=7, max_len=10)
+    for forks in (None, [1]):
+        ctx.set_fork_depths(forks)
+        r = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for x in (r.tokens, r.scores, r.row_lo, r.row_hi):
+            h.update(x.cpu().numpy().tobytes())
+        out[f"{N}_{V}_{L}_{B}_{forks}"] = h.hexdigest()
+        assert bool((r.row_hi > r.row_lo).all())
+    ctx.set_fork_depths(None)
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_trie_level_tables_change_nothing():
+    """Round 5: the selection kernel reads the child ranges of steps 0 and 1 from the trie's level tables (rpr_trie::lvl0 / lvl1,
+    built at upload) instead of binary-searching the code matrix. Same searches with RPR_SELECT_LEVELS = 1 / 0 in two processes:
+    tokens, scores and row ranges identical bit for bit — uniform and Zipf codes, a vocab off the 64 grid, V = 1024 (level-1
+    table of 1 M entries) and V = 2048 (no level-1 table), a stage that starts at step 1 (explicit fork at depth 1)."""
+    import json
+    import subprocess
+    import sys
+    got = {}
+    for lv in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", _LEVELS_SCRIPT % REPO], env=dict(os.environ, RPR_SELECT_LEVELS=lv), capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        got[lv] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert got["1"] == got["0"] and len(got["1"]) == 8
