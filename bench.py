@@ -521,7 +521,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="queries in flight per step per GPU; default 2150 = two lanes of 1075 queries (10 750 rows = 42 row tiles of 256: 126 / 378 / 504 GEMM tiles = whole rounds of a lane's 128 CUs), 2176 with --no-lanes (85 row tiles: 255 / 765 / 1020 tiles on 256 CUs)")
+    ap.add_argument("--batch", type=int, default=None, help="queries in flight per step per GPU; default 2150 = two lanes of 1075 queries (10 750 rows = 42 row tiles of 256: 126 / 378 / 504 GEMM tiles = whole rounds of a lane's 128 CUs), 2176 with --no-lanes (85 row tiles: 255 / 765 / 1020 tiles on 256 CUs); 4300 / 6450 (two / three times the rows: 82 / 123 GiB of workspace) measured +1.0 / +1.7 % same-box in round 5 and are not the default: with the exact-fp32 leg, the plain-loop parity test of this configuration and the secondary legs beside it 6450 exhausts the 288 GB")
     ap.add_argument("--beams", type=int, default=10)
     ap.add_argument("--len", type=int, default=32, dest="L")
     ap.add_argument("--docs", type=int, default=MSMARCO_DOCS)

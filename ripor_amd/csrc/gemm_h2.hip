@@ -1116,10 +1116,7 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 
 // 256x256 tile, 8 waves (2x4) of 128x64, ping-pong schedule: half the staged bytes per MFMA of the 128x128 tile;
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
-static hipError_t launch_256(const GemmH2Args& a_in, hipStream_t s) {
-  static const int band = [] { const char* e = getenv("RPR_GEMM_BAND"); return e ? atoi(e) : 4; }();
-  GemmH2Args a = a_in;
-  a.band = a.ksplit > 1 ? 0 : band;
+static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
   // persistent blocks: one per CU of the stream (a whole number per XCD), fewer when the launch has fewer tiles
