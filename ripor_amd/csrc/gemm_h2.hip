@@ -1067,7 +1067,7 @@ static hipError_t launch_wsplit_cfg(const GemmH2Args& k, hipStream_t s) {
 
 // Tile shape and K split of a wave-split launch. These launches are latency-bound by LDS capacity: a block keeps at most its
 // rings in flight (64-96 KB) against a loaded L2 / Infinity-Cache latency of ~3 us, i.e. 40-50 GB/s per CU whatever the tile
-// (tools/fill_probe.hip: the LDS-DMA path itself sustains > 100 GB/s per CU from L2), one block per CU (128-144 KB of LDS).
+// (tools/attic/fill_probe.hip: the LDS-DMA path itself sustains > 100 GB/s per CU from L2), one block per CU (128-144 KB of LDS).
 // Model fitted to tools/wsplit_bench.sh on MI355X (profiles/r05d_wsplit_gemm_bench.txt): launch = 5 us + rounds of blocks over
 // the CUs x (3 us + KB per block / rate), + one reduction launch for a K split over blocks.
 // cfg 0: 32 x 32 (four stages), 1: 64 x 32 (three), 2: 64 x 64 (two).

@@ -2,9 +2,9 @@
 # via gpurun: kernel-boundary / grid-barrier price list of this box + the single-query search under runtime knobs
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-launch_probe}; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 120 tools/launch_probe > $O/probe_default.txt 2>&1
-HIP_FORCE_DEV_KERNARG=1 timeout 120 tools/launch_probe > $O/probe_devkernarg.txt 2>&1
-HIP_FORCE_DEV_KERNARG=0 timeout 120 tools/launch_probe > $O/probe_hostkernarg.txt 2>&1
+timeout 120 tools/attic/launch_probe > $O/probe_default.txt 2>&1
+HIP_FORCE_DEV_KERNARG=1 timeout 120 tools/attic/launch_probe > $O/probe_devkernarg.txt 2>&1
+HIP_FORCE_DEV_KERNARG=0 timeout 120 tools/attic/launch_probe > $O/probe_hostkernarg.txt 2>&1
 B="python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-exact-fp32 --no-roofline --secondary ''"
 run() { local tag=$1; shift; env "$@" bash -c "$B" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],3), 'ms')"; }
 {
