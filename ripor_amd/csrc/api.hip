@@ -104,6 +104,7 @@ struct LinOut {                                                              // 
   __half* h; size_t ps; int ldh;                                             //   or f16 planes (next GEMM's input)
   const float* resid; int relu;
   int rm_B; size_t rm_stride, rm_slot, rm_head;                              //   KV-cache element map (common.h)
+  int rm_dshift;                                                             //   log2(d_kv) of the map (0 = 6)
   float plane_scale;                                                         //   scale of the planes written to h (0 = 1)
   const __half* resid_h; unsigned long long* ssq_out;                        //   fused RMSNorm producer: residual read from the
 };                                                                           //   planes h (in place), row sums accumulated
@@ -128,7 +129,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.split_n = O.split_n; g.out_h = O.h; g.o_ps = O.ps; g.ldoh = O.ldh;
     g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
     g.trace = L.c->trace_buf;
-    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
+    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head; g.rm_dshift = O.rm_dshift;
     g.m_dev = m_dev; g.acc_scale = 1.0f / (W_PLANE_SCALE * A.scale); g.plane_scale = O.plane_scale;
     g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
     g.resid_h = O.resid_h; g.r_ps = O.ps; g.ldrh = O.ldh; g.ssq_out = O.ssq_out;
@@ -146,7 +147,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.A = A.f; g.lda = A.ld; g.W = W.f; g.ldw = W.K; g.resid = O.resid; g.ldr = O.ldo[0];
     for (int i = 0; i < 3; ++i) { g.out[i] = O.f[i]; g.ldo[i] = O.ldo[i]; }
     g.split_n = O.split_n; g.M = M; g.N = W.N; g.K = W.K; g.relu = O.relu;
-    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head;
+    g.rm_B = O.rm_B; g.rm_stride = O.rm_stride; g.rm_slot = O.rm_slot; g.rm_head = O.rm_head; g.rm_dshift = O.rm_dshift;
     g.m_dev = m_dev;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm(g, s); });
   }
@@ -303,7 +304,8 @@ void enqueue_encoder(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int Q, int Lq
            out_f32(qkv, 3 * inner, 3 * inner), live, Ta);
     EncAttnArgs a{qkv, P<int32_t>(w.mask), d.enc_rel_bias, m->enc_bucket, attn, Q, Lq, d.num_heads, d.rel_buckets,
                   h2 ? attn_h : nullptr, ps_i, offs, P<int32_t>(w.last), c->status, 0};
-    Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * DKV * ((double)Ta / T) * ((double)Ta / T), 4.0 * Ta * 4 * inner,
+    a.dkv = d.d_kv;
+    Ln.run(RPR_K_ENC_ATTN, 4.0 * Q * d.num_heads * (double)Lq * Lq * d.d_kv * ((double)Ta / T) * ((double)Ta / T), 4.0 * Ta * 4 * inner,
            [&] { return launch_enc_attn(a, s); });
     linear(Ln, in_attn, {m->enc_o[i], m->h_enc_o[i], dm, inner}, T, h2 ? xs.out(2 * i + 1) : out_f32(x, dm, dm, x), live, Ta);
     if (!h2) norm(m->enc_ln1[i]);
@@ -339,7 +341,8 @@ struct StageView {
   int depth;                       //   contiguous depth*B*256-B region and the B rows of a position are adjacent
   BeamState st[2];                 // ping-pong by step parity
   size_t kv_q(int B, int inner) const { return (size_t)depth * B * inner; }
-  size_t kv_h(int B) const { return (size_t)depth * B * DKV; }
+  int dkv = DKV;                   // head dim of the caches (64; 128 = t5-3b, which runs without forks)
+  size_t kv_h(int B) const { return (size_t)depth * B * dkv; }
   size_t kv_layer(int B, int inner) const { return (size_t)Qcap * depth * B * inner; }
 };
 
@@ -368,7 +371,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         *logits = P<float>(w.logits);
   __half *attn_h = P<__half>(w.attn_h), *ff_h = P<__half>(w.ff_h);
   const size_t ps_d = (size_t)R * dm, ps_i = (size_t)R * inner, ps_f = (size_t)R * dff;
-  const size_t layer_stride = sv.kv_layer(B, inner), kv_q = sv.kv_q(B, inner), kv_h = sv.kv_h(B), kv_pos = (size_t)B * DKV, kv_slot = DKV;
+  const size_t layer_stride = sv.kv_layer(B, inner), kv_q = sv.kv_q(B, inner), kv_h = sv.kv_h(B), kv_pos = (size_t)B * sv.dkv, kv_slot = sv.dkv;
   int Rt = R, Bt = B;   // rows / beams per query of the current step's decoder pass
   const int Racc = live_count(Ln, sv.nrows_dev, R);   // rows the profile accounts for
   const float post = d.scaleup_output_hidden ? (float)pow((double)dm, -0.5) : 1.0f;
@@ -397,13 +400,14 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         LinOut o{};
         o.f[0] = qb; o.f[1] = kc + (size_t)t * kv_pos; o.f[2] = vc + (size_t)t * kv_pos;
         o.ldo[0] = o.ldo[1] = o.ldo[2] = inner; o.split_n = inner;
-        o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h;
+        o.rm_B = Bt; o.rm_stride = kv_q; o.rm_slot = kv_slot; o.rm_head = kv_h; o.rm_dshift = sv.dkv == 128 ? 7 : 6;
         linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, Rt, o, sv.nrows_dev, Ma);
       }
       {
         DecSelfAttnArgs a{qb, kc, vc, kv_q, kv_h, kv_pos, kv_slot, cur.anc, L, d.dec_rel_bias, m->dec_bucket, attn, Q, Bt, H, t,
                           h2 ? attn_h : nullptr, ps_i, c->status, sv.nq_dev};
-        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Ma * H * (double)(t + 1) * DKV,
+        a.dkv = d.d_kv;
+        Ln.run(RPR_K_DEC_SELF_ATTN, 4.0 * Ma * H * (double)(t + 1) * d.d_kv,
                4.0 * ((double)Ma * inner * 2 + 2.0 * Ma * (double)(t + 1) * inner), [&] { return launch_dec_self_attn(a, s); });
       }
       linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
@@ -413,7 +417,8 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
         const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
         DecCrossAttnArgs a{qb, xk, xk + inner, xld, sv.io.mask, attn, Q, Bt, H, Lq, h2 ? attn_h : nullptr, ps_i,
                            sv.io.last, sv.io.offs, 0, c->status, sv.nq_dev};
-        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ma * H * (double)Lq * DKV,
+        a.dkv = d.d_kv;
+        Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ma * H * (double)Lq * d.d_kv,
                4.0 * ((double)Ma * inner * 2 + 2.0 * (Ma / Bt) * (double)Lq * inner), [&] { return launch_step_cross_attn(a, s); });
       }
       linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, Rt, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), sv.nrows_dev, Ma);
@@ -663,7 +668,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   StageView sv{};
   sv.Qcap = Q;
   sv.io = StageIO{nullptr, packed ? P<int32_t>(w.offs) : nullptr, P<int32_t>(w.last), P<int32_t>(w.mask)};
-  sv.kcache = P<float>(w.kcache); sv.vcache = P<float>(w.vcache); sv.depth = forks.empty() ? L : forks[0];
+  sv.kcache = P<float>(w.kcache); sv.vcache = P<float>(w.vcache); sv.depth = forks.empty() ? L : forks[0]; sv.dkv = d.d_kv;
   for (int i = 0; i < 2; ++i) sv.st[i] = beam_state(w.score, w.lo, w.hi, w.tokens, w.anc, i, L);
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(sv.st[0], Q, B, tr->N, s); });
 
@@ -888,7 +893,7 @@ int rpr_get_precision(const rpr_ctx* c) { return c ? c->precision : -1; }
 
 int rpr_load_model(rpr_ctx* c, const rpr_model_desc* d, rpr_model** out) {
   RPR_REQUIRE(c && d && out, "NULL argument");
-  RPR_REQUIRE(d->d_kv == DKV, "only d_kv == 64 is supported (t5-base / t5-large)");
+  RPR_REQUIRE(d->d_kv == DKV || d->d_kv == 128, "d_kv must be 64 (t5-base / t5-large) or 128 (t5-3b)");
   RPR_REQUIRE(d->d_model % 32 == 0 && d->d_ff % 32 == 0, "d_model and d_ff must be multiples of 32");
   RPR_REQUIRE(d->V >= 2 && d->V <= 65536, "decoder vocab size out of range (2..65536)");
   RPR_REQUIRE(d->L >= 1 && d->L <= MAX_DEC_LEN, "decoder length out of range");
@@ -1266,6 +1271,7 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   std::vector<int> forks;
   *drop_last = false;
   if (!c->forced_tail || taps || L < 3 || !std::isfinite(m->logit_bound)) return forks;
+  if (m->d.d_kv != DKV) return forks;   // 128-dim heads (t5-3b): the tail kernels are written for 64; the plain loop runs
   const double per_step = 2.0 * (double)m->logit_bound + ((flags & RPR_FLAG_LOG_SOFTMAX) ? log((double)m->d.V) : 0.0);
   if (1e8 - L * per_step <= 1e7) return forks;   // logits too large for the masked-candidate proof
   if (c->n_fork_override >= 0) {
@@ -1501,6 +1507,7 @@ int rpr_lngknp_forward(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const
   RPR_REQUIRE(bz >= 1 && Lq >= 1 && Lq <= MAX_LQ, "bz or Lq out of range");
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= MAX_LQ, "smtid length exceeds the model's decoder length");
   RPR_REQUIRE(n_docs >= 1 && (int64_t)bz * n_docs * L < ((int64_t)1 << 24), "n_docs out of range");
+  RPR_REQUIRE(m->d.d_kv == DKV, "the teacher-forced kernels are written for d_kv == 64 (t5-base / t5-large)");
   RPR_REQUIRE(n_prefix >= 0 && n_prefix <= 8, "n_prefix out of range (0..8)");
   RPR_REQUIRE(n_prefix == 0 || (n_docs == 2 && teacher_pos && teacher_neg && prefix_lens && out_losses),
               "the margin losses need n_docs == 2 (positive, negative), teacher scores, prefix lengths and out_losses");

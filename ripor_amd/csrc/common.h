@@ -12,7 +12,8 @@ namespace rpr {
 constexpr int WAVE = 64;
 constexpr int MAX_LQ = 256;          // encoder tokens per query supported by the attention kernels
 constexpr int MAX_DEC_LEN = 64;      // decoder positions supported (reference uses 32 or 16)
-constexpr int DKV = 64;              // head dim the attention kernels are written for (t5-base/large)
+constexpr int DKV = 64;              // head dim the fast attention kernels are written for (t5-base/large); d_kv = 128 (t5-3b) runs
+                                     // on the generic kernels enc_attn_kernel<128> / dec_attn_kernel<., 128> without the forced tail
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -75,8 +76,9 @@ struct GemmArgs {
   int M, N, K;
   int relu;
   // KV-cache element map for the outputs 1 and 2 (rm_B == 0: plain [M, ldo] rows): element (m, n) goes to
-  // out[i] + (m / rm_B) * rm_stride + (m % rm_B) * rm_slot + (n / 64) * rm_head + n % 64   
+  // out[i] + (m / rm_B) * rm_stride + (m % rm_B) * rm_slot + (n / d_kv) * rm_head + n % d_kv   
   int rm_B; size_t rm_stride, rm_slot, rm_head;
+  int rm_dshift;                           // log2(d_kv) of the map above (0 = 6)
   const int* m_dev;             // nullable: number of live rows on the device (packed encoder); tiles past it exit
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
@@ -92,6 +94,7 @@ struct GemmH2Args {
   int relu;
   unsigned long long* trace;               // diagnostic cycle stamps of block 0 (nullptr in production)
   int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
+  int rm_dshift;                           // log2(d_kv) of that map (0 = 6)
   const int* m_dev;                        // nullable: live row count on the device (see GemmArgs)
   // Power-of-two scaling of the f16 planes (exact; see W_/A_/FF_PLANE_SCALE below): the accumulators are multiplied
   // by acc_scale = 1 / (scale of A's planes * scale of W's planes); planes written by the epilogue (out_h) are
@@ -144,7 +147,8 @@ template <class G>
 __device__ __forceinline__ size_t out_off(const G& g, int oi, int m, int ldo, int on) {
   if (g.rm_B && oi) {
     const int qi = m / g.rm_B;
-    return (size_t)qi * g.rm_stride + (size_t)(m - qi * g.rm_B) * g.rm_slot + (size_t)(on >> 6) * g.rm_head + (on & 63);
+    const int sh = g.rm_dshift ? g.rm_dshift : 6;   // log2 of the head dim: 6 (t5-base / large), 7 (t5-3b, d_kv = 128)
+    return (size_t)qi * g.rm_stride + (size_t)(m - qi * g.rm_B) * g.rm_slot + (size_t)(on >> sh) * g.rm_head + (on & ((1 << sh) - 1));
   }
   return (size_t)m * ldo + on;
 }
@@ -212,6 +216,7 @@ struct EncAttnArgs {
                            //   bucket table indexed by i - j (unidirectional)
   int mfma;                // 1: sequences of <= 32 padded positions with fp32 output may take the fp32-MFMA kernel (training
                            //   forward; the search encoder keeps the summation order of enc_attn_kernel)
+  int dkv = 0;             // head dim (0 = 64); 128 (t5-3b) takes enc_attn_kernel<128>
 };
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s);
 // tail_kernels.hip: the search encoder's attention (<= 32 positions) on the fp32-MFMA tile; false = shape not taken
@@ -238,6 +243,7 @@ struct DecSelfAttnArgs {
   unsigned int* sat;
   const int* nq_dev;       // nullable: live query count on the device (compacted stage); queries past it are skipped
   unsigned b_magic = 0, h_magic = 0;   // set by the launcher: reciprocals of B and H (kernel_utils.h udiv_magic)
+  int dkv = 0;             // head dim (0 = 64); 128 (t5-3b) takes the generic kernel dec_attn_kernel<true, 128>
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, hipStream_t s);
 
@@ -255,6 +261,7 @@ struct DecCrossAttnArgs {
   int bchunk;              // set by the launcher: beams per block when the beam is split over blockIdx.y (0 = all)
   unsigned int* sat;
   const int* nq_dev;       // nullable: live query count on the device; queries past it are skipped
+  int dkv = 0;             // head dim (0 = 64); 128 (t5-3b) takes the generic kernel dec_attn_kernel<false, 128>
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, hipStream_t s);
 

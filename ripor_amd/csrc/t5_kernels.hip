@@ -154,29 +154,31 @@ hipError_t launch_dec_embed(const float* start, const float* in_embeds, const ui
 // table, two dependent loads), the key mask and the q rows (eight rows of the wave per batch, requested together) are
 // staged in LDS first. With those three loads in the loop a row cost two memory round trips: 61 us for the 3072 blocks of
 // a teacher-forced decoder layer (32 positions), 290 us for 2150 packed queries of the search encoder.
+template <int D>   // head dim: 64 (every kernel argument / LDS row as before) or 128 (t5-3b): a lane holds D / 64 dims of a row
 __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Lq = a.Lq, H = a.H, inner = H * DKV, ld = 3 * inner;
+  constexpr int NV = D / 64;
+  const int Lq = a.Lq, H = a.H, inner = H * D, ld = 3 * inner;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
-  float* Ks = smem;                    // [Lq][65]
-  float* Vs = smem + (size_t)Lq * 65;  // [Lq][64]
-  float* Ps = Vs + (size_t)Lq * 64;    // [4][Lq] normalised weights per wave
-  float* RB = Ps + 4 * Lq;             // [2 Lq] bias of this head per key offset (causal: i - j; else j - i + nrow - 1)
-  float* Qs = RB + 2 * Lq;             // [4][8][64] q rows of the wave's current batch
-  int* Ms = reinterpret_cast<int*>(Qs + 4 * 8 * 64);   // [Lq] key mask
+  float* Ks = smem;                         // [Lq][D + 1]
+  float* Vs = smem + (size_t)Lq * (D + 1);  // [Lq][D]
+  float* Ps = Vs + (size_t)Lq * D;          // [4][Lq] normalised weights per wave
+  float* RB = Ps + 4 * Lq;                  // [2 Lq] bias of this head per key offset (causal: i - j; else j - i + nrow - 1)
+  float* Qs = RB + 2 * Lq;                  // [4][8][D] q rows of the wave's current batch
+  int* Ms = reinterpret_cast<int*>(Qs + 4 * 8 * D);   // [Lq] key mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // packed encoder: the query's rows start at offs[qi] and only its own lens[qi] positions exist (the padded
   // positions behind them are masked keys and unused query rows in the padded layout)
   const int nrow = a.offs ? a.lens[qi] : Lq;
   const size_t row0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * Lq;
-  const float* base = a.qkv + row0 * ld + h * DKV;
-  for (int i = tid; i < nrow * 16; i += 256) {
-    const int j = i >> 4, c = (i & 15) * 4;
+  const float* base = a.qkv + row0 * ld + h * D;
+  for (int i = tid; i < nrow * (D / 4); i += 256) {
+    const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
     const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + inner + c);
     const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * inner + c);
-    float* kd = Ks + j * 65 + c;
+    float* kd = Ks + j * (D + 1) + c;
     kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+    *reinterpret_cast<float4*>(Vs + j * D + c) = vv;
   }
   const int nrb = a.causal ? nrow : 2 * nrow - 1, rb0 = a.causal ? 0 : MAX_LQ - nrow;
   for (int k = tid; k < nrb; k += 256) RB[k] = a.rel_bias[a.bucket[rb0 + k] * H + h];
@@ -187,20 +189,28 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   __syncthreads();
   const int nchunk = (nrow + 63) >> 6;
   float* P = Ps + wave * Lq;
-  float* Qw = Qs + wave * 8 * 64;
+  float* Qw = Qs + wave * 8 * D;
   for (int i0 = wave; i0 < nrow; i0 += 32) {
     {   // the wave's next eight q rows: all requests go out before the first one is used
-      float qb[8];
+      float qb[8][NV];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = i0 + 4 * u; qb[u] = i < nrow ? base[(size_t)i * ld + lane] : 0.f; }
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 4 * u;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) Qw[u * 64 + lane] = qb[u];
+        for (int v = 0; v < NV; ++v) qb[u][v] = i < nrow ? base[(size_t)i * ld + 64 * v + lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) Qw[u * D + 64 * v + lane] = qb[u][v];
     }
     __builtin_amdgcn_wave_barrier();
   for (int u = 0; u < 8; ++u) {
     const int i = i0 + 4 * u;
     if (i >= nrow) break;
-    const float qv = Qw[u * 64 + lane];  // lane d holds q_i[d]
+    float qv[NV];                             // lane d holds q_i[d], q_i[64 + d]
+#pragma unroll
+    for (int v = 0; v < NV; ++v) qv[v] = Qw[u * D + 64 * v + lane];
     float sc[MAX_LQ / 64];
     float mx = -INFINITY;
 #pragma unroll
@@ -208,13 +218,15 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
       if (c >= nchunk) break;
       const int j = c * 64 + lane;
       const int jc = j < nrow ? j : nrow - 1;
-      const float* kr = Ks + jc * 65;
+      const float* kr = Ks + jc * (D + 1);
       float acc = 0.f;
 #pragma unroll
-      for (int d = 0; d < DKV; ++d) {
-        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
-        acc = fmaf(qd, kr[d], acc);
-      }
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+          const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[v]), d));
+          acc = fmaf(qd, kr[64 * v + d], acc);
+        }
       float s = -INFINITY;
       if (a.causal) { if (j <= i) s = acc + RB[i - j]; }   // teacher-forced decoder: rel = j - i <= 0, table[n = i - j]
       else if (j < nrow && Ms[j] != 0) s = acc + RB[j - i + nrow - 1];
@@ -238,31 +250,44 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
       if (j < nrow) P[j] = sc[c] / sum;
     }
     __builtin_amdgcn_wave_barrier();
-    float o = 0.f;
-    for (int j = 0; j < nrow; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
-    const size_t oidx = (row0 + i) * inner + h * DKV + lane;
-    if (a.out_h) {
-      __half hi, lo;
-      split_f16(o * A_PLANE_SCALE, hi, lo, a.sat);
-      a.out_h[oidx] = hi;
-      a.out_h[a.o_ps + oidx] = lo;
-    } else {
-      a.out[oidx] = o;
+    float o[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) o[v] = 0.f;
+    for (int j = 0; j < nrow; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) o[v] = fmaf(P[j], Vs[j * D + 64 * v + lane], o[v]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const size_t oidx = (row0 + i) * inner + h * D + 64 * v + lane;
+      if (a.out_h) {
+        __half hi, lo;
+        split_f16(o[v] * A_PLANE_SCALE, hi, lo, a.sat);
+        a.out_h[oidx] = hi;
+        a.out_h[a.o_ps + oidx] = lo;
+      } else {
+        a.out[oidx] = o[v];
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
   }
 }
 
-static size_t enc_attn_smem(int Lq) {
-  return ((size_t)Lq * 65 + (size_t)Lq * 64 + 4 * (size_t)Lq + 2 * (size_t)Lq + 4 * 8 * 64 + (size_t)Lq) * sizeof(float);
+static size_t enc_attn_smem(int Lq, int D) {
+  return ((size_t)Lq * (D + 1) + (size_t)Lq * D + 4 * (size_t)Lq + 2 * (size_t)Lq + 4 * 8 * (size_t)D + (size_t)Lq) * sizeof(float);
 }
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
+  if (a.dkv == 128) {   // t5-3b heads: the generic kernel only
+    const size_t smem = enc_attn_smem(a.Lq, 128);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;   // Lq <= ~150 at 128-dim heads
+    hipLaunchKernelGGL(enc_attn_kernel<128>, dim3(a.Q * a.H), dim3(256), smem, s, a);
+    return hipGetLastError();
+  }
   static const bool mfma_off = [] { const char* e = getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (a.mfma && !mfma_off && a.Lq <= 32 && !a.offs && !a.out_h) return launch_train_self_attn_mfma(a, s);
   if (!a.mfma) { hipError_t e; if (launch_enc_attn_mfma_v2(a, s, &e)) return e; }
-  hipLaunchKernelGGL(enc_attn_kernel, dim3(a.Q * a.H), dim3(256), enc_attn_smem(a.Lq), s, a);
+  hipLaunchKernelGGL(enc_attn_kernel<64>, dim3(a.Q * a.H), dim3(256), enc_attn_smem(a.Lq, 64), s, a);
   return hipGetLastError();
 }
 
@@ -275,7 +300,7 @@ hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
 // Work item order: w = ((q * H + h) * B + b): the B beams of one (query, head) are adjacent and are
 // remapped so that one XCD (one L2) gets a contiguous chunk of work items — beams of a query share
 // most of their ancestors' K/V rows and the encoder K/V rows, which then hit in that XCD's L2.
-template <bool SELF>
+template <bool SELF, int D = DKV>   // D = head dim: 64, or 128 (t5-3b: 32 lanes per row, two rows per wave instruction)
 __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qbuf, const float* __restrict__ kbase,
                                                         const float* __restrict__ vbase, const uint16_t* __restrict__ anc,
                                                         int anc_ld, const float* __restrict__ rel_bias,
@@ -283,7 +308,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
                                                         float* __restrict__ out, int Q, int B, int H, int t, int Lq,
                                                         int xld, __half* __restrict__ out_h, size_t o_ps,
                                                         size_t q_stride, size_t h_stride, size_t pos_stride,
-                                                        size_t slot_stride, unsigned int* sat, const int* __restrict__ nq_dev) {
+                                                        size_t slot_stride, unsigned int* sat, const int* __restrict__ nq_dev,
+                                                        const int32_t* __restrict__ offs = nullptr) {
+  constexpr int LPR = D / 4, GP = 64 / LPR;   // lanes per K / V row (float4 each), rows per wave instruction
   __shared__ float Ss[4][MAX_LQ];
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -293,15 +320,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = bid * 4 + wave;
-  const int R = Q * B, inner = H * DKV;
+  const int R = Q * B, inner = H * D;
   if (w >= R * H) return;
   const int b = w % B, qh = w / B, h = qh % H, qi = qh / H;
   if (nq_dev && qi >= *nq_dev) return;
   const int r = qi * B + b;
-  const int g = lane >> 4, li = lane & 15;
+  const int g = lane / LPR, li = lane % LPR;
   float* S = Ss[wave];
+  const size_t xrow0 = (!SELF && offs) ? (size_t)offs[qi] : (size_t)qi * Lq;   // packed encoder rows of the query
 
-  const float4 q4 = *reinterpret_cast<const float4*>(qbuf + (size_t)r * inner + h * DKV + li * 4);
+  const float4 q4 = *reinterpret_cast<const float4*>(qbuf + (size_t)r * inner + h * D + li * 4);
   const int nkeys = SELF ? (t + 1) : Lq;
   const uint16_t* ancr = SELF ? (anc + (size_t)r * anc_ld) : nullptr;
   const int32_t* mrow = SELF ? nullptr : (mask + (size_t)qi * Lq);
@@ -311,12 +339,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
       const int slot = (p == t) ? b : (int)ancr[p];
       return (size_t)qi * q_stride + (size_t)h * h_stride + (size_t)p * pos_stride + (size_t)slot * slot_stride + li * 4;
     } else {
-      return ((size_t)qi * Lq + p) * (size_t)xld + h * DKV + li * 4;
+      return (xrow0 + p) * (size_t)xld + h * D + li * 4;
     }
   };
 
   float mx = -INFINITY;
-  for (int p0 = 0; p0 < nkeys; p0 += 4) {
+  for (int p0 = 0; p0 < nkeys; p0 += GP) {
     const int p = p0 + g;
     float s = -INFINITY;
     bool ok = p < nkeys;
@@ -326,7 +354,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
       const float4 k4 = *reinterpret_cast<const float4*>(kbase + row_off(p));
       d = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
     }
-    d = group16_sum(d);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // (LPR = 16: the additions of group16_sum, in its order)
     if (ok) {
       s = d;
       if (SELF) s += rel_bias[bucket[t - p] * H + h];
@@ -346,7 +375,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   sum = wave_sum(sum);
   __builtin_amdgcn_wave_barrier();
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p0 = 0; p0 < nkeys; p0 += 4) {
+  for (int p0 = 0; p0 < nkeys; p0 += GP) {
     const int p = p0 + g;
     if (p < nkeys) {
       const float wgt = S[p] / sum;
@@ -360,14 +389,14 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     }
   }
 #pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
+  for (int o = LPR; o <= 32; o <<= 1) {
     acc.x += __shfl_xor(acc.x, o, 64);
     acc.y += __shfl_xor(acc.y, o, 64);
     acc.z += __shfl_xor(acc.z, o, 64);
     acc.w += __shfl_xor(acc.w, o, 64);
   }
   if (g == 0) {
-    const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
+    const size_t oidx = (size_t)r * inner + h * D + li * 4;
     if (out_h) store_planes4(out_h, o_ps, oidx, acc, sat);
     else *reinterpret_cast<float4*>(out + oidx) = acc;
   }
@@ -491,6 +520,13 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a_in, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
   if ((long)items >= (1l << 32) / std::max(a.B, a.H)) return hipErrorInvalidValue;   // udiv_magic's exact range
   const dim3 grid((items + 3) / 4), blk(256);
+  if (a.dkv == 128) {   // t5-3b heads: the generic one-wave-per-(beam, head) kernel
+    if (a.t + 1 > MAX_LQ) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((dec_attn_kernel<true, 128>), grid, blk, 0, s, a.q, a.kcache, a.vcache, a.anc, a.anc_ld, a.rel_bias, a.bucket,
+                       (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps, a.q_stride, a.h_stride, a.pos_stride,
+                       a.slot_stride, a.sat, a.nq_dev, (const int32_t*)nullptr);
+    return hipGetLastError();
+  }
   const int nk = a.t + 1;
   if (nk <= 8) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<2>, grid, blk, 0, s, a); return hipGetLastError(); }
   if (nk <= 16) { hipLaunchKernelGGL(dec_self_attn_fast_kernel<4>, grid, blk, 0, s, a); return hipGetLastError(); }
@@ -640,8 +676,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
 }
 
 hipError_t init_t5_kernel_attributes() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -650,6 +688,13 @@ hipError_t init_t5_kernel_attributes() {
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   DecCrossAttnArgs a = a_in;
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
+  if (a.dkv == 128) {   // t5-3b heads: one wave per (beam, head) over the query's encoder K / V rows (unattended keys masked)
+    const long items = (long)a.Q * a.B * a.H;
+    hipLaunchKernelGGL((dec_attn_kernel<false, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a.q, a.xk, a.xv,
+                       (const uint16_t*)nullptr, 0, (const float*)nullptr, (const int32_t*)nullptr, a.mask, a.out, a.Q, a.B, a.H, 0, a.Lq,
+                       a.xld, a.out_h, a.o_ps, (size_t)0, (size_t)0, (size_t)0, (size_t)0, a.sat, a.nq_dev, a.offs);
+    return hipGetLastError();
+  }
   auto smem_for = [&](int nb) { return ((size_t)a.Lq * (XK_LD + DKV) + (size_t)nb * (QS_LD + 2 * (a.Lq + 1)) + 4) * sizeof(float); };
   a.bchunk = 0;
   int chunks = 1;

@@ -1106,6 +1106,7 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
 hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   static const int mode = [] { const char* e = getenv("RPR_STEP_CROSS_MFMA"); return e ? atoi(e) : 2; }();
   const int HB = (a.H + 3) / 4;
+  if (a.dkv == 128) return launch_dec_cross_attn(a, s);   // t5-3b heads: the generic kernel
   if (mode == 2 && g_tail_attn_gen == 2 && a.Lq <= 32 && (long)a.B * a.H * DKV < (1l << 29)) {
     // 16-row tiles per wave: one while that gives the chip enough waves, else up to eight (K / V / mask loaded once per wave)
     const int tiles = (a.B + 15) / 16;

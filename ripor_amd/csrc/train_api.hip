@@ -828,6 +828,7 @@ int rpr_lngknp_backward_buckets(rpr_ctx* c, rpr_model* m, const int32_t* input_i
                   flat_grads, "NULL argument");
   RPR_REQUIRE(m->ctx == c, "model belongs to another ctx");
   RPR_REQUIRE(bz >= 1 && Lq >= 1 && Lq <= 128, "bz or Lq out of range (the training kernels hold Lq <= 128 keys in LDS)");
+  RPR_REQUIRE(m->d.d_kv == DKV, "the training kernels are written for d_kv == 64 (t5-base / t5-large)");
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= MAX_DEC_LEN, "smtid length exceeds the model's decoder length");
   RPR_REQUIRE(n_prefix >= 1 && n_prefix <= 8, "n_prefix out of range (1..8)");
   RPR_HIP(hipSetDevice(c->device));

@@ -131,8 +131,8 @@ class T5ForDocIDGeneration:
         self._sd: Dict[str, torch.Tensor] = {}
         self._device = torch.device("cpu")
         self._engine_model = None
-        if (config.num_decoder_layers, config.num_heads) not in ((12, 12), (24, 16)):
-            # the reference additionally accepts t5-3b (24 layers, 32 heads, d_kv=128): not built yet
+        if (config.num_decoder_layers, config.num_heads) not in ((12, 12), (24, 16), (24, 32)):
+            # t5-base, t5-large, t5-3b (32 heads of d_kv = 128: search and encode only): reference :116-135
             raise ValueError("the model with decoer layers {} is not supported.".format(config.num_decoder_layers))
         if state_dict is not None:
             self.load_state_dict(state_dict)

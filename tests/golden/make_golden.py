@@ -400,6 +400,10 @@ CASES = {
     # fixtures shrink d_ff and the encoder): beam 100, short smtids so that the reference's full-prefix recompute stays
     # within minutes on the build container's 8 cores. Pins the K = 4096 FF path inside a 24-layer decoder end to end.
     "g5_largefull_b100_l8": dict(kind="large_full", N=3000, Q=2, B=100, L=8, V=256, seed=501),
+    # t5-3b decoder shape (24 layers, 32 heads of d_kv = 128, d = 1024: t5_generative_retriever.py:128-133): the 128-dim head
+    # path (generic attention kernels, d_kv-strided KV cache); one encoder layer and a small d_ff keep the fixture small
+    "g7_3b_b10_l8": dict(kind="3b", N=3000, Q=4, B=10, L=8, V=256, seed=701),
+    "g7_3b_b100_l16": dict(kind="3b", N=3000, Q=2, B=100, L=16, V=256, seed=702),
     # RIPOR's 16 x 1024 codebook variant (reference full_16_1024_scripts/full_evaluate_t5seq_aq_encoder.sh:19-22: M=16,
     # nbits=10) at the real t5-base dimensions, at the headline beam and at the training-data beam
     "g6_base_v1024_b10_l16": dict(kind="base", N=3000, Q=4, B=10, L=16, V=1024, seed=601),
@@ -430,11 +434,14 @@ def make_case(name, spec, gen, mod, utils, shim):
                                num_heads=16, decoder_vocab_sizes=[V] * L, shared_output_input_embeds=shared)
     elif kind == "large_full":
         dims = synth.t5_large_dims(L=L, V=V, vocab_size=2048, shared_output_input_embeds=shared)
+    elif kind == "3b":
+        dims = synth.ModelDims(vocab_size=512, d_model=1024, d_kv=128, d_ff=512, num_layers=1, num_decoder_layers=24,
+                               num_heads=32, decoder_vocab_sizes=[V] * L, shared_output_input_embeds=shared)
     else:
         raise ValueError(kind)
     t0 = time.time()
     sd = synth.make_state_dict(dims, seed=seed)
-    model = build_reference_model(mod, dims, sd, which="t5-large" if kind.startswith("large") else "t5-base")
+    model = build_reference_model(mod, dims, sd, which="t5-3b" if kind == "3b" else "t5-large" if kind.startswith("large") else "t5-base")
     codes = synth.make_codes(N, L, V, seed=seed)
     d2s, lst = reference_trie(gen, codes)
     processor = gen.PrefixConstrainLogitProcessorFastSparse(lst, V)
