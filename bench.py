@@ -245,6 +245,32 @@ def secondary_config4(E, synth, ctx, trie, dev, L, queries=162, steps=5):
     return out
 
 
+def secondary_t5_3b(E, synth, ctx, trie, dev, L, queries=384, steps=2):
+    """t5-3b dims (the third model size the reference's constructor accepts, t5_generative_retriever.py:128-133: d 1024, 32 heads of
+    d_kv 128, d_ff 16384, 24 + 24 layers), the same trie, beam 10: the 128-dim head path (generic attention kernels, no forced
+    tail). Opt-in (--secondary ...,t5_3b): 23 GB of weights + planes and 250 MB of self-attention K/V per query in flight."""
+    dims = synth.ModelDims(d_model=1024, d_kv=128, d_ff=16384, num_layers=24, num_decoder_layers=24, num_heads=32,
+                           decoder_vocab_sizes=[256] * L)
+    t0 = time.time()
+    model = E.DeviceModel(ctx, synth.make_state_dict(dims), dims)
+    t_w = time.time() - t0
+    batches = _query_batches(synth, dims, queries, 2, dev, seed=405)
+    dt, r = _time_search(E, model, trie, batches, 10, L, steps)
+    ok = int((r.row_hi > r.row_lo).sum().item())
+    st = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], 10, L))
+    lanes = 0 < ctx.lane_split() <= queries * 10
+    roof = _gemm_roofline(st, PEAK_F16_MFMA_TFLOPS / 3.0, 0.5 if lanes else 1.0, "rpr::gemm_h2_pp_kernel (+ small-tile kernels)",
+                          "algorithmic 2MNK flops of every projection launch of one step / their summed event durations; 3 f16 "
+                          "MFMAs per product -> peak 2500/3 TF/s, halved per launch when the step runs as two CU-masked lanes")
+    by_class = {k: round(v["total_ms"], 2) for k, v in st.items() if v["launches"]}
+    out = {"workload": f"t5-3b dims (d 1024, 32 heads x 128, d_ff 16384, 24+24 layers), {trie.N}-doc trie, beams=10, len={L}, {queries} queries/step",
+           "value": queries / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps, "queries_per_step": queries,
+           "roofline": roof, "lanes": 2 if lanes else 1, "kernel_ms_by_class": by_class,
+           "dtype": "f32 via f16x2-split MFMA (fp32 accumulate)", "valid_leaves": f"{ok}/{queries * 10}", "weights_s": round(t_w, 1)}
+    del model
+    return out
+
+
 def board_power_under(run, seconds=2.5):
     """Board power and shader clock while `run()` keeps the GPU busy (outside every timed region): `rocm-smi --showpower
     --showclocks --showuse` sampled from a thread. Best effort — None when rocm-smi is missing or prints something else."""
@@ -535,7 +561,7 @@ def main():
     ap.add_argument("--secondary", default="train,config4,f2,skew,latency,small_batch,heavy_tail,v1024",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
-                         "1000); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
+                         "1000, t5_3b = opt-in: t5-3b dims at beam 10); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
     ap.add_argument("--log-softmax", action="store_true", dest="log_softmax",
                     help="apply_log_softmax_for_scores=True (reference generation.py:453-455; not the headline configuration)")
     ap.add_argument("--no-lanes", action="store_true",
@@ -986,6 +1012,8 @@ def main():
             leg("small_batch", lambda: secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L))
         if "config4" in legs and args.model == "t5-base":
             leg("config4", lambda: secondary_config4(E, synth, ctx, trie, dev, L))
+        if "t5_3b" in legs and args.model == "t5-base":
+            leg("t5_3b", lambda: secondary_t5_3b(E, synth, ctx, trie, dev, L))
     if rank == 0:
         out["secondary"] = sec
         print(json.dumps(out), flush=True)

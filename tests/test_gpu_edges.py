@@ -318,7 +318,7 @@ def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
     model = E.DeviceModel(ctx, sd, dims)
     trie = E.DeviceTrie.from_codes(ctx, codes, V)
     pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
-    ids, mask = synth.make_queries(Q, vocab_size=512, seed=92, max_len=qlen)
+    ids, mask = synth.make_queries(Q, vocab_size=512, seed=92, max_len=qlen, mean_len=0.75 * qlen, std_len=0.2 * qlen)
     seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
     exp_tok, exp_sc = seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:], sc.numpy().reshape(Q, B)
     assert ctx.fork_depths(model, trie, Q, B, L, False) == []
@@ -336,6 +336,10 @@ def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
         # a rank may differ from the oracle's only where two candidates tie within the score tolerance
         assert bool((same | (np.abs(got_sc - exp_sc) <= 1e-4)).all()) and same.mean() >= 0.98, (case, precision, same.mean())
     assert ctx.status() == 0
+    if case == "short":   # the documented limit of this head size fails with a message, not with a launch error
+        long_ids, long_mask = synth.make_queries(2, vocab_size=512, seed=93, fixed_len=129)
+        with pytest.raises(E.RiporHipError, match="up to 128 tokens"):
+            E.search(model, trie, torch.from_numpy(long_ids), torch.from_numpy(long_mask), B, L)
 
 
 # ---- saturation guard of the split-precision planes -------------------------------------------------
