@@ -419,7 +419,7 @@ constexpr int SELF_MAXIT_MAX = 9;  // 36 keys: covers L <= 35 (the reference use
 // SELF_MAXIT = row groups of 4 keys held in registers. Early steps use the small instantiations: fewer
 // VGPRs -> 8 waves per SIMD instead of 4, which is what hides the anc -> K/V dependent-load chain when a
 // wave only has a few hundred bytes to fetch.
-template <int SELF_MAXIT>
+template <int SELF_MAXIT, int D = DKV>   // D = 128 (t5-3b): 32 lanes per row, SELF_MAXIT groups of TWO keys
 __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs a) {
   const int nblk = gridDim.x;
   int bid = blockIdx.x;
@@ -432,13 +432,14 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int B = a.B, H = a.H, t = a.t;
   const int w = bid * 4 + wave;
-  const int R = a.Q * B, inner = H * DKV;
+  constexpr int LPR = D / 4, GP = 64 / LPR;   // lanes per K / V row, rows per load instruction
+  const int R = a.Q * B, inner = H * D;
   if (w >= R * H) return;
   const int qh = udiv_magic((unsigned)w, B, a.b_magic), b = w - qh * B;
   const int qi = udiv_magic((unsigned)qh, H, a.h_magic), h = qh - qi * H;
   if (a.nq_dev && qi >= *a.nq_dev) return;
   const int r = qi * B + b;
-  const int g = lane >> 4, li = lane & 15;
+  const int g = lane / LPR, li = lane % LPR;
   const int nkeys = t + 1;
   const uint16_t* ancr = a.anc + (size_t)r * a.anc_ld;
 
@@ -451,46 +452,47 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   int off[SELF_MAXIT];
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
-    const int p = it * 4 + g;
+    const int p = it * GP + g;
     const int pc = p < nkeys ? p : t;
     const int slot = (pc == t) ? b : (int)ancr[pc];
     off[it] = pc * pstr + slot * sstr + li * 4;
   }
-  const float4 q4 = *reinterpret_cast<const float4*>(a.q + ((size_t)r * inner + h * DKV) + li * 4);
+  const float4 q4 = *reinterpret_cast<const float4*>(a.q + ((size_t)r * inner + h * D) + li * 4);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) kreg[it] = ld_stream(kb + off[it]);
+    if (it * GP < nkeys) kreg[it] = ld_stream(kb + off[it]);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it)
-    if (it * 4 < nkeys) vreg[it] = ld_stream(vb + off[it]);
+    if (it * GP < nkeys) vreg[it] = ld_stream(vb + off[it]);
 
   float sc[SELF_MAXIT];
   float mx = -INFINITY;
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
     sc[it] = -INFINITY;
-    if (it * 4 < nkeys) {  // wave-uniform
-      const int p = it * 4 + g;
+    if (it * GP < nkeys) {  // wave-uniform
+      const int p = it * GP + g;
       float d = q4.x * kreg[it].x + q4.y * kreg[it].y + q4.z * kreg[it].z + q4.w * kreg[it].w;
-      d = group16_sum(d);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // D = 64: group16_sum's additions in its order
       if (p < nkeys) sc[it] = d + a.rel_bias[a.bucket[t - p] * H + h];
       mx = fmaxf(mx, sc[it]);
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+  for (int o = LPR; o <= 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   float sum = 0.f;
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
     sc[it] = exp_nonpos(sc[it] - mx);   // the bits of expf; a masked score is -inf: 0 (mx is finite: key t is always there)
     sum += sc[it];
   }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+  for (int o = LPR; o <= 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
-    if (it * 4 < nkeys) {
+    if (it * GP < nkeys) {
       const float wgt = sc[it] / sum;
       if (wgt != 0.f) {  // lanes past nkeys hold a clamped duplicate row with weight 0
         acc.x = fmaf(wgt, vreg[it].x, acc.x);
@@ -501,14 +503,14 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
     }
   }
 #pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
+  for (int o = LPR; o <= 32; o <<= 1) {
     acc.x += __shfl_xor(acc.x, o, 64);
     acc.y += __shfl_xor(acc.y, o, 64);
     acc.z += __shfl_xor(acc.z, o, 64);
     acc.w += __shfl_xor(acc.w, o, 64);
   }
   if (g == 0) {
-    const size_t oidx = (size_t)r * inner + h * DKV + li * 4;
+    const size_t oidx = (size_t)r * inner + h * D + li * 4;
     if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, acc, a.sat);
     else *reinterpret_cast<float4*>(a.out + oidx) = acc;
   }
@@ -520,7 +522,12 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a_in, hipStream_t s) {
   const int items = a.Q * a.B * a.H;
   if ((long)items >= (1l << 32) / std::max(a.B, a.H)) return hipErrorInvalidValue;   // udiv_magic's exact range
   const dim3 grid((items + 3) / 4), blk(256);
-  if (a.dkv == 128) {   // t5-3b heads: the generic one-wave-per-(beam, head) kernel
+  if (a.dkv == 128) {   // t5-3b heads: two keys per register group; beyond 36 keys the generic one-wave-per-(beam, head) kernel
+    const int nk = a.t + 1;
+    if (nk <= 8) { hipLaunchKernelGGL((dec_self_attn_fast_kernel<4, 128>), grid, blk, 0, s, a); return hipGetLastError(); }
+    if (nk <= 16) { hipLaunchKernelGGL((dec_self_attn_fast_kernel<8, 128>), grid, blk, 0, s, a); return hipGetLastError(); }
+    if (nk <= 24) { hipLaunchKernelGGL((dec_self_attn_fast_kernel<12, 128>), grid, blk, 0, s, a); return hipGetLastError(); }
+    if (nk <= 36) { hipLaunchKernelGGL((dec_self_attn_fast_kernel<18, 128>), grid, blk, 0, s, a); return hipGetLastError(); }
     if (a.t + 1 > MAX_LQ) return hipErrorInvalidValue;
     hipLaunchKernelGGL((dec_attn_kernel<true, 128>), grid, blk, 0, s, a.q, a.kcache, a.vcache, a.anc, a.anc_ld, a.rel_bias, a.bucket,
                        (const int32_t*)nullptr, a.out, a.Q, a.B, a.H, a.t, 0, 0, a.out_h, a.o_ps, a.q_stride, a.h_stride, a.pos_stride,
@@ -548,11 +555,13 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a_in, hipStream_t s) {
 // padded to 68 floats (conflict-free); softmax — one wave per beam; P.V — one thread per (beam, 4 dims).
 constexpr int XK_LD = DKV + 4, QS_LD = DKV + 4;
 
+template <int D>   // head dim: 64, or 128 (t5-3b); rows padded by 4 floats either way (stride = 4 mod 32 banks)
 __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnArgs a) {
+  constexpr int XK_LD = D + 4, QS_LD = D + 4, D4 = D / 4;   // D4 = float4 pieces per row
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // Bq = beams of the query, B = the beams this block handles (all of them, or one chunk of a.bchunk when the
   // per-beam LDS rows of a large beam — topk = 1000 in the reference's retrieval script — would not fit)
-  const int H = a.H, Bq = a.B, inner = H * DKV;
+  const int H = a.H, Bq = a.B, inner = H * D;
   const int b_first = a.bchunk ? (int)blockIdx.y * a.bchunk : 0;
   const int B = a.bchunk ? min(a.bchunk, Bq - b_first) : Bq;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
@@ -560,22 +569,22 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   const int SLD = a.Lq + 1;
   float* Ks = smem;                        // [Lq][68]
   float* Vs = Ks + (size_t)a.Lq * XK_LD;   // [Lq][64]
-  float* Qs = Vs + (size_t)a.Lq * DKV;     // [B][68]
+  float* Qs = Vs + (size_t)a.Lq * D;     // [B][68]
   float* S = Qs + (size_t)(a.bchunk ? a.bchunk : Bq) * QS_LD;       // [B][Lq+1]
   const int tid = threadIdx.x;
   const int32_t* mrow = a.mask + (size_t)qi * a.Lq;
   const size_t xrow0 = a.offs ? (size_t)a.offs[qi] : (size_t)qi * a.Lq;   // packed or padded encoder rows
-  const float* kb = a.xk + xrow0 * a.xld + h * DKV;
-  const float* vb = a.xv + xrow0 * a.xld + h * DKV;
+  const float* kb = a.xk + xrow0 * a.xld + h * D;
+  const float* vb = a.xv + xrow0 * a.xld + h * D;
   // keys at and beyond the last attended position are padding: every loop runs over that prefix only
   // (queries are padded to the batch maximum, typically 2-3x their own length); a.last[q] is computed
   // once per search. All global loads of the block are issued back to back before the first wait.
   const int Lq = a.last[qi];
   if (Lq == 0) {   // query without a single attended token (reported through the ctx status word by mask_lengths_kernel):
                    // its packed encoder has no rows — write zeros instead of reading a neighbour's K/V
-    for (int item = tid; item < B * 16; item += 256) {
-      const int b = item >> 4, c = (item & 15) * 4;
-      const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c;
+    for (int item = tid; item < B * D4; item += 256) {
+      const int b = item / D4, c = (item % D4) * 4;
+      const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * D + c;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, z, a.sat);
       else *reinterpret_cast<float4*>(a.out + oidx) = z;
@@ -586,35 +595,35 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   float4 pk[PF], pv[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
-    const int i = tid + u * 256, j = i >> 4, c = (i & 15) * 4;
+    const int i = tid + u * 256, j = i / D4, c = (i % D4) * 4;
     pk[u] = make_float4(0.f, 0.f, 0.f, 0.f); pv[u] = pk[u];
     if (j < Lq && mrow[j] != 0) {  // padded keys are never read; zero rows keep 0 * garbage out of the PV sum
       pk[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * a.xld + c);
       pv[u] = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + c);
     }
   }
-  for (int i = tid; i < B * 16; i += 256) {
-    const int b = i >> 4, c = (i & 15) * 4;
+  for (int i = tid; i < B * D4; i += 256) {
+    const int b = i / D4, c = (i % D4) * 4;
     *reinterpret_cast<float4*>(Qs + b * QS_LD + c) =
-        *reinterpret_cast<const float4*>(a.q + (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c);
+        *reinterpret_cast<const float4*>(a.q + (size_t)(qi * Bq + b_first + b) * inner + h * D + c);
   }
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
-    const int i = tid + u * 256, j = i >> 4, c = (i & 15) * 4;
+    const int i = tid + u * 256, j = i / D4, c = (i % D4) * 4;
     if (j < Lq) {
       *reinterpret_cast<float4*>(Ks + j * XK_LD + c) = pk[u];
-      *reinterpret_cast<float4*>(Vs + j * DKV + c) = pv[u];
+      *reinterpret_cast<float4*>(Vs + j * D + c) = pv[u];
     }
   }
-  for (int i = tid + PF * 256; i < Lq * 16; i += 256) {  // long queries: remaining rows
-    const int j = i >> 4, c = (i & 15) * 4;
+  for (int i = tid + PF * 256; i < Lq * D4; i += 256) {  // long queries: remaining rows
+    const int j = i / D4, c = (i % D4) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (mrow[j] != 0) {
       kv = *reinterpret_cast<const float4*>(kb + (size_t)j * a.xld + c);
       vv = *reinterpret_cast<const float4*>(vb + (size_t)j * a.xld + c);
     }
     *reinterpret_cast<float4*>(Ks + j * XK_LD + c) = kv;
-    *reinterpret_cast<float4*>(Vs + j * DKV + c) = vv;
+    *reinterpret_cast<float4*>(Vs + j * D + c) = vv;
   }
   __syncthreads();
   // scores: two threads per (beam, key) pair, 32 dims each (B * Lq is ~120 pairs for 10 beams: one thread per pair
@@ -626,11 +635,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
     float sv = 0.f;
     const bool live = mrow[j] != 0;
     if (live) {
-      const float4* qr = reinterpret_cast<const float4*>(Qs + b * QS_LD) + hlf * (DKV / 8);
-      const float4* kr = reinterpret_cast<const float4*>(Ks + j * XK_LD) + hlf * (DKV / 8);
+      const float4* qr = reinterpret_cast<const float4*>(Qs + b * QS_LD) + hlf * (D / 8);
+      const float4* kr = reinterpret_cast<const float4*>(Ks + j * XK_LD) + hlf * (D / 8);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int d = 0; d < DKV / 8; ++d) {
+      for (int d = 0; d < D / 8; ++d) {
         const float4 q4 = qr[d], k4 = kr[d];
         a0 = fmaf(q4.x, k4.x, a0); a1 = fmaf(q4.y, k4.y, a1);
         a2 = fmaf(q4.z, k4.z, a2); a3 = fmaf(q4.w, k4.w, a3);
@@ -656,20 +665,20 @@ __global__ __launch_bounds__(256) void dec_cross_attn_block_kernel(DecCrossAttnA
   }
   __syncthreads();
   // P.V: one thread per (beam, 4 output dims)
-  for (int item = tid; item < B * 16; item += 256) {
-    const int b = item >> 4, c = (item & 15) * 4;
+  for (int item = tid; item < B * D4; item += 256) {
+    const int b = item / D4, c = (item % D4) * 4;
     const float* row = P + b * SLD;
     float sum = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < Lq; ++j) {
       const float e = row[j];
       sum += e;
-      const float4 v4 = *reinterpret_cast<const float4*>(Vs + j * DKV + c);
+      const float4 v4 = *reinterpret_cast<const float4*>(Vs + j * D + c);
       o.x = fmaf(e, v4.x, o.x); o.y = fmaf(e, v4.y, o.y); o.z = fmaf(e, v4.z, o.z); o.w = fmaf(e, v4.w, o.w);
     }
     const float inv = 1.0f / sum;
     o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-    const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * DKV + c;
+    const size_t oidx = (size_t)(qi * Bq + b_first + b) * inner + h * D + c;
     if (a.out_h) store_planes4(a.out_h, a.o_ps, oidx, o, a.sat);
     else *reinterpret_cast<float4*>(a.out + oidx) = o;
   }
@@ -681,14 +690,24 @@ hipError_t init_t5_kernel_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel<64>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   DecCrossAttnArgs a = a_in;
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
-  if (a.dkv == 128) {   // t5-3b heads: one wave per (beam, head) over the query's encoder K / V rows (unattended keys masked)
+  if (a.dkv == 128) {   // t5-3b heads
+    // the block kernel (K / V of the (query, head) staged once for all beams) when everything fits one block's LDS ...
+    const size_t smem128 = ((size_t)a.Lq * (132 + 128) + (size_t)a.B * (132 + 2 * (a.Lq + 1)) + 4) * sizeof(float);
+    if (smem128 <= 160 * 1024) {
+      a.bchunk = 0;
+      hipLaunchKernelGGL(dec_cross_attn_block_kernel<128>, dim3(a.Q * a.H, 1), dim3(256), smem128, s, a);
+      return hipGetLastError();
+    }
+    // ... else one wave per (beam, head) over the query's encoder K / V rows (unattended keys masked)
     const long items = (long)a.Q * a.B * a.H;
     hipLaunchKernelGGL((dec_attn_kernel<false, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a.q, a.xk, a.xv,
                        (const uint16_t*)nullptr, 0, (const float*)nullptr, (const int32_t*)nullptr, a.mask, a.out, a.Q, a.B, a.H, 0, a.Lq,
@@ -705,7 +724,7 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   }
   const size_t smem = smem_for(a.bchunk ? a.bchunk : a.B);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dec_cross_attn_block_kernel, dim3(a.Q * a.H, chunks), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(dec_cross_attn_block_kernel<64>, dim3(a.Q * a.H, chunks), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 

@@ -92,17 +92,17 @@ for case in range(n_cases):                 # every random draw up front, so tha
         B, Q = 10, rng.randint(1030, 1300)
     d0 = rng.randint(1, max(1, L - 2))
     depths = [d0] + ([rng.randint(d0 + 1, L - 1)] if rng.random() < 0.6 and d0 + 1 <= L - 1 else [])
-    params.append((N, L, V, B, Q, skew, dup, lsm, seed, depths))
+    params.append((N, L, V, B, Q, skew, dup, lsm, seed, depths, rng.random() < 0.1))   # last: 128-dim heads (6 of them)
 
 n_oracle = 0
-for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths) in enumerate(params):
+for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths, wide) in enumerate(params):
     if only is not None and case != only:
         continue
     codes = synth.make_codes(N, L, V, seed=seed, skew=skew)
     if dup:
         k = max(1, N // 8)
         codes[-k:] = codes[:k]
-    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128)
+    dims = synth.mini_dims(L=L, V=V, enc_layers=1, d_ff=128, **(dict(d_kv=128, num_heads=6) if wide else {}))
     sd = synth.make_state_dict(dims, seed=seed)
     ids, mask = synth.make_queries(Q, vocab_size=dims.vocab_size, seed=seed, max_len=14)
     ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
@@ -154,7 +154,7 @@ for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths) in enumerate(params):
         n_oracle += 1
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 1 == 0, f"case {case}: saturation flag"
-    print(f"case {case:3d}: N={N} L={L} V={V} B={B} Q={Q} skew={int(skew)} dup={int(dup)} logsm={int(lsm)}: " + "; ".join(notes), flush=True)
+    print(f"case {case:3d}: N={N} L={L} V={V} B={B} Q={Q} skew={int(skew)} dup={int(dup)} logsm={int(lsm)} dkv={dims.d_kv}: " + "; ".join(notes), flush=True)
     del model, trie
 ctx.set_forced_tail(1)
 print(f"{n_cases} cases passed ({n_oracle} also against the CPU oracle; {n_excused} queries excused at a pruning margin below {BOUNDARY_TOL})")
