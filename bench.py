@@ -948,6 +948,21 @@ def main():
                                                + ("; measured on the unsplit step (whole-chip launches); PMC traffic of "
                                                   "whole-chip launches: profiles/r02f_q2176_hbm_pmc.json" if lanes_on else "")}
                 out["self_attn_hbm"] = {"achieved_GBs": ach, "frac_of_8TBs": ach / (PEAK_HBM_TBS * 1e3)}
+            # the attention kernels of the step against HBM (same accounting: the library's algorithmic bytes per class —
+            # q / k / v rows read once, planes written once — over the hipEvent time of the unsplit step's launches)
+            hk = {}
+            for cls, label in (("tail_self_attn", "rpr::tail_self_attn_mfma_v2_kernel"),
+                               ("dec_cross_attn", "rpr::tail_cross_attn_mfma_v2_kernel + step_cross_attn_mfma16_kernel"),
+                               ("enc_attn", "rpr::enc_attn_mfma_v2_kernel")):
+                v = stats.get(cls)
+                if v and v["total_ms"] > 0 and v["bytes"] > 0:
+                    a_gbs = v["bytes"] / (v["total_ms"] * 1e-3) / 1e9
+                    hk[cls] = {"kernel": label, "bound": "hbm", "achieved": a_gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                               "frac": a_gbs / (PEAK_HBM_TBS * 1e3), "launches_per_step": v["launches"],
+                               "avg_launch_us": v["total_ms"] * 1e3 / max(1, v["launches"]),
+                               "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"])}
+            if hk:
+                out["roofline_hbm_attention"] = hk
         if world == 1 and not args.no_roofline:
             try:
                 out["board_power"] = board_power_under(lambda: run_step(W))

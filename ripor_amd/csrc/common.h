@@ -96,6 +96,8 @@ struct GemmH2Args {
   int rm_B; size_t rm_stride, rm_slot, rm_head;  // KV-cache element map for out[1], out[2] (see GemmArgs)
   int rm_dshift;                           // log2(d_kv) of that map (0 = 6)
   const int* m_dev;                        // nullable: live row count on the device (see GemmArgs)
+  int m_base;                              // rows in front of this launch's first row that *m_dev counts too (the second launch of a
+                                           // row-split product, launch_gemm_h2; 128-row tile kernels only): live rows = *m_dev - m_base
   // Power-of-two scaling of the f16 planes (exact; see W_/A_/FF_PLANE_SCALE below): the accumulators are multiplied
   // by acc_scale = 1 / (scale of A's planes * scale of W's planes); planes written by the epilogue (out_h) are
   // scaled by plane_scale. 0 means 1.

@@ -21,6 +21,7 @@
 // K-tiles with LDS-DMA into unpadded XOR-swizzled rows. Earlier variants (register staging, in-phase software
 // pipelining) are in the history and in DESIGN.md §5 / §8 with their measured numbers.
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
 #include <hip/hip_fp16.h>
 
@@ -85,7 +86,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
   int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
   if (g.m_dev) {   // packed encoder: only the tiles holding live rows are distributed (evenly) over the XCDs
-    const int live = min(*g.m_dev, g.M);
+    const int live = max(0, min(*g.m_dev - g.m_base, g.M));
     if (g.live_hi > 0 && (*g.m_dev <= g.live_lo || *g.m_dev > g.live_hi)) return;   // the other kernel of the pair runs
     nt = ((live + BM - 1) / BM) * tiles_n;
     if (bid >= nt) return;
@@ -475,7 +476,7 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   // store per plane, the row scales come from LDS (rs_tile, filled before the K-loop) and the saturation check is
   // one max per element plus one compare per half.
   __syncthreads();                                   // all waves are done reading operand tiles
-  const int Mlim = g.m_dev ? min(*g.m_dev, g.M) : g.M;   // packed encoder: rows past the live count are never stored
+  const int Mlim = g.m_dev ? min(*g.m_dev - g.m_base, g.M) : g.M;   // packed encoder: rows past the live count are never stored
   constexpr int SW = TN * 32;                         // staged row width (floats)
   constexpr int NS = TM * 32 / SH;                    // strips per wave
   float* stg = reinterpret_cast<float*>(smem) + wave * (SH * SW);
@@ -1412,6 +1413,44 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   const double round_eff = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);
   if (force == 256 || a.prefer_pp || (force == 0 && t256 >= 112L * cus / 256 && (round_eff >= 0.6 || a.out_h || a.row_ssq))) {
     a_in.kernel_cls = RPR_K_GEMM;
+    // Row split of a launch just over a whole number of rounds (beam 1000 with one query: 318 tiles of 256^2 for the
+    // N = 768 products = 1.24 rounds, the second one with 62 of 256 CUs busy): the row tiles that fill whole rounds go to
+    // the ping-pong kernel, the rows behind them to the 128 x 128 tile kernel (a quarter of the work per block, 1.22 x the
+    // time per flop), as a second launch on the same stream. Taken when the estimate — whole rounds + 0.43 per round of
+    // 128^2 tiles (measured: 5240 rows x 768 columns = 246 such tiles in 35.7 us against 87.1 us for the 255 tiles of 256^2
+    // in front of them, profiles/r05x_rowsplit_gemm.txt) + ~6 us for the second launch — is under 0.9 of the rounds the
+    // ping-pong kernel alone would need. RPR_GEMM_ROWSPLIT=0: off; =2 (tests): every launch of this route with two or more
+    // row tiles is split in the middle.
+    static const int row_split = [] { const char* e = getenv("RPR_GEMM_ROWSPLIT"); return e ? atoi(e) : 1; }();
+    const bool split_all = row_split == 2 && a.M > 256;
+    if (row_split && (force == 0 || split_all) && !a.prefer_pp && !a.rm_B && a.ksplit <= 1 && !a.trace && a.small_live == 0 &&
+        (t256 > cus || split_all)) {
+      const int tiles_n = (a.N + 255) / 256;
+      const long rounds = t256 / cus;
+      const int rows_main = split_all ? ((a.M + 255) / 256 / 2) * 256 : (int)((rounds * cus) / tiles_n) * 256, m_rest = a.M - rows_main;
+      if ((t256 % cus != 0 || split_all) && rows_main > 0 && m_rest > 0) {
+        const long t128r = (long)((m_rest + 127) / 128) * ((a.N + 127) / 128);
+        const double tile_us = 78.0 * a.K / 768.0;
+        const double cost_split = (double)rounds + 0.43 * (double)((t128r + cus - 1) / cus) + 6.0 / tile_us;
+        if (split_all || cost_split < 0.9 * (double)(rounds + 1)) {
+          static const int log_split = [] { const char* e = getenv("RPR_GEMM_ROWSPLIT_LOG"); return e ? atoi(e) : 0; }();
+          if (log_split) fprintf(stderr, "[rowsplit] M=%d N=%d K=%d: %d rows on 256x256 tiles, %d on 128x128\n", a.M, a.N, a.K, rows_main, m_rest);
+          GemmH2Args main_p = a, rest = a;
+          main_p.M = rows_main;
+          rest.M = m_rest; rest.m_base = a.m_base + rows_main;
+          rest.A = a.A + (size_t)rows_main * a.lda;
+          for (int i = 0; i < 3; ++i) if (a.out[i]) rest.out[i] = a.out[i] + (size_t)rows_main * a.ldo[i];
+          if (a.out_h) rest.out_h = a.out_h + (size_t)rows_main * a.ldoh;
+          if (a.resid) rest.resid = a.resid + (size_t)rows_main * a.ldr;
+          if (a.resid_h) rest.resid_h = a.resid_h + (size_t)rows_main * a.ldrh;
+          if (a.row_ssq) rest.row_ssq = a.row_ssq + rows_main;
+          if (a.ssq_out) rest.ssq_out = a.ssq_out + rows_main;
+          hipError_t e = launch_256(main_p, s);
+          if (e != hipSuccess) return e;
+          return launch_cfg<128, 128>(rest, s);
+        }
+      }
+    }
     return launch_256(a, s);
   }
   // a handful of rows (one to a few queries in flight): the launch is a weight stream; a 128-row tile would spend
