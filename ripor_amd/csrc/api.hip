@@ -140,6 +140,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.sat = L.c->status;
     g.cus = L.c->cur_cus;
     g.small_live = m_dev ? L.c->cur_small_live : 0;
+    g.no_row_split = L.c->cur_no_row_split;
     g.part = P<float>(L.c->ws.part); g.part_cap = L.c->ws.part.cap / sizeof(float); g.mid_split = 1;
     L.run(RPR_K_GEMM, fl, by, [&] { return launch_gemm_h2(g, s); }, &g.kernel_cls);
   } else {
@@ -651,6 +652,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s, c->status + 1); });
   static const bool packed_env = [] { const char* e = getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
   const bool packed = packed_env && !taps;   // taps return the padded [Q, Lq, d] encoder output
+  c->cur_no_row_split = packed ? 1 : 0;   // the packed rows' capacity says nothing about the live rows (reset below, after the cross-K/V product)
   enqueue_encoder(Ln, c, m, Q, Lq, packed);
   if (taps && taps->encoder_out && !Ln.err) {
     hipError_t e = hipMemcpyAsync(taps->encoder_out, w.enc_out.p, (size_t)T * dm * 4, hipMemcpyDeviceToDevice, s);
@@ -663,6 +665,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
          out_f32(P<float>(w.xkv), xld, xld), packed ? P<int>(w.offs) + Q : nullptr, c->enc_rows_accounted);
   Ln.account_live(nullptr, 0);
+  c->cur_no_row_split = 0;
 
   const SearchDims sd{Q, Lq, B, L, xld, packed, flags};
   StageView sv{};
@@ -733,11 +736,13 @@ void enqueue_train_forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, int bz,
   const float eps = d.layer_norm_eps;
   hipStream_t s = Ln.s;
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), bz, Lq, s, c->status + 1); });
+  c->cur_no_row_split = 1;
   enqueue_encoder(Ln, c, m, bz, Lq, true);
   const int xld = nd * 2 * inner;
   linear(Ln, {P<float>(w.enc_out), P<__half>(w.enc_out_h), (size_t)T * dm, dm}, {d.dec_xkv, m->h_dec_xkv, xld, dm}, T,
          out_f32(P<float>(w.xkv), xld, xld), P<int>(w.offs) + bz, c->enc_rows_accounted);
   Ln.account_live(nullptr, 0);
+  c->cur_no_row_split = 0;
 
   float *x = P<float>(w.x), *h = P<float>(w.h), *qkv = P<float>(w.tr_x), *qb = P<float>(w.q), *attn = P<float>(w.attn),
         *ff = P<float>(w.ff);

@@ -127,6 +127,8 @@ struct GemmH2Args {
   int bf16;                                // 1: A and W are single bf16 planes (training GEMMs, RPR_PREC_BF16); fp32 output only
   int prefer_pp;                           // 1: the 256x256 ping-pong kernel whatever the tile count, one K-loop per tile (weight gradients:
                                            // few tiles, thousands of K rows, several launches side by side on separate streams)
+  int no_row_split;                        // 1: never split the rows of this launch over two kernels (packed encoder: M is a capacity far above
+                                           // the live row count, which only the device knows)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
 };
 

@@ -1423,7 +1423,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // row tiles is split in the middle.
     static const int row_split = [] { const char* e = getenv("RPR_GEMM_ROWSPLIT"); return e ? atoi(e) : 1; }();
     const bool split_all = row_split == 2 && a.M > 256;
-    if (row_split && (force == 0 || split_all) && !a.prefer_pp && !a.rm_B && a.ksplit <= 1 && !a.trace && a.small_live == 0 &&
+    if (row_split && (force == 0 || split_all) && !a.prefer_pp && !a.rm_B && a.ksplit <= 1 && !a.trace && a.small_live == 0 && (!a.no_row_split || split_all) &&
         (t256 > cus || split_all)) {
       const int tiles_n = (a.N + 255) / 256;
       const long rounds = t256 / cus;

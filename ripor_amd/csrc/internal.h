@@ -163,6 +163,7 @@ struct rpr_ctx {
   int cur_cus = 0;              // CUs of the lane the current enqueue runs on (0 = the whole chip)
   int lane_cus = 0;             // CUs per lane
   int cur_lane = -1;            // lane of the current enqueue (-1 = the ctx stream)
+  int cur_no_row_split = 0;     // 1 while the packed encoder (and the cross-K/V product on its rows) is enqueued: GemmH2Args.no_row_split
   int cur_small_live = 0;       // > 0 while a leftover stage is enqueued: its GEMMs are paired (GemmH2Args.small_live)
   int forced_tail = 1;          // 0 = every query runs all L steps sequentially, 1 = exact forced tail, 2 = optimistic (see choose_forks)
   int fork_override[MAX_FORKS] = {0, 0};   // explicit fork depths (rpr_set_fork_depths / RPR_FORK_DEPTHS); 0 = from the trie statistics
