@@ -403,7 +403,6 @@ CASES = {
     # t5-3b decoder shape (24 layers, 32 heads of d_kv = 128, d = 1024: t5_generative_retriever.py:128-133): the 128-dim head
     # path (generic attention kernels, d_kv-strided KV cache); one encoder layer and a small d_ff keep the fixture small
     "g7_3b_b10_l8": dict(kind="3b", N=3000, Q=4, B=10, L=8, V=256, seed=701),
-    "g7_3b_b100_l16": dict(kind="3b", N=3000, Q=2, B=100, L=16, V=256, seed=702),
     # RIPOR's 16 x 1024 codebook variant (reference full_16_1024_scripts/full_evaluate_t5seq_aq_encoder.sh:19-22: M=16,
     # nbits=10) at the real t5-base dimensions, at the headline beam and at the training-data beam
     "g6_base_v1024_b10_l16": dict(kind="base", N=3000, Q=4, B=10, L=16, V=1024, seed=601),
