@@ -125,12 +125,21 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   const int search_items = (t == 0) ? V : items;
   // from depth ~3 on every range is narrow (one doc each): the (beam, token) loop has nothing to search then and, with
   // the logits left in global memory (large beams), nothing to stage either — at B = 1000 it cost 190 us per step
+  // step 1 with the trie's child arrays: the first token of every beam once, into LDS (widx is free until the selection),
+  // so that the table lookups below depend on no other global load
+  const bool tab1 = t == 1 && a.lvl1 != nullptr && t < Lc;      // block-uniform
+  const bool tab0 = t == 0 && a.lvl0 != nullptr;
+  if (tab1) {
+    for (int b = tid; b < B; b += 256) widx[b] = a.cur.tokens[(size_t)(r0 + b) * a.cur.ld];
+    __syncthreads();
+  }
   if (*any_wide || a.lds_logits)
   for (int item = tid; item < items; item += 4 * 256) {
     // four (beam, token) pairs per thread advance their binary searches in lockstep: the four probes of a step
     // are independent loads (one search at a time was one dependent L2/HBM latency per probe)
     int lo4[4], hi4[4], end4[4], c4[4], tab4[4], nxt4[4];
-    bool act[4];
+    bool act[4], use_tab[4];
+    const int32_t* tptr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int it = item + u * 256;
@@ -141,17 +150,21 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
       const bool narrow = hi - lo <= NARROW;           // wave-uniform: a wave covers 64 tokens of one beam
       act[u] = in && !narrow && it < search_items;
       lo4[u] = lo; hi4[u] = (act[u] && t < Lc) ? hi : lo; end4[u] = hi; c4[u] = c;
-      tab4[u] = -1;
-      if (act[u] && t < Lc && c < a.lvl_V) {
-        // levels 0 / 1: the lower bound of (prefix, c) and of its successor straight from the trie's child arrays
-        // (the range of this beam is [lvl0[c0], lvl0[c0 + 1]) at step 1: its rows share code 0 = c0)
-        if (t == 0 && a.lvl0) { tab4[u] = a.lvl0[c]; nxt4[u] = a.lvl0[c + 1]; hi4[u] = lo; }
-        else if (t == 1 && a.lvl1) {
-          const int c0 = a.cur.tokens[(size_t)(r0 + b) * a.cur.ld];
-          const int32_t* row = a.lvl1 + (size_t)c0 * a.lvl_V + c;
-          tab4[u] = row[0]; nxt4[u] = row[1]; hi4[u] = lo;
-        }
-      }
+      tab4[u] = -1; nxt4[u] = 0;
+      // levels 0 / 1: the lower bound of (prefix, c) and of its successor straight from the trie's child arrays (the range of
+      // this beam is [lvl0[c0], lvl0[c0 + 1]) at step 1: its rows share code 0 = c0). Address by selects, loads unconditional
+      // (a pair without a table entry reads the scratch array): inside a branch per pair the compiler retired every load before
+      // the next pair's was issued — 248 serial latencies per thread, 838 us of phase A at beam 1000 with one query.
+      use_tab[u] = act[u] && t < Lc && c < a.lvl_V && (tab0 || tab1);
+      tptr[u] = !use_tab[u] ? a.lb_scratch : tab0 ? a.lvl0 + c : a.lvl1 + (size_t)widx[b] * a.lvl_V + c;
+    }
+    {
+      int e0[4], e1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { e0[u] = tptr[u][0]; e1[u] = tptr[u][1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (use_tab[u]) { tab4[u] = e0[u]; nxt4[u] = e1[u]; hi4[u] = lo4[u]; }
     }
     for (;;) {
       int v4[4];
