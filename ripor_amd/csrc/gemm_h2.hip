@@ -589,7 +589,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
   // loaded after the reduction): the fused-RMSNorm sums of squares of the lane's 16 rows and the residual of its 16
   // outputs (column bn + lane % 32, rows 4 * (lane / 32) + (r & 3) + 8 * (r >> 2)).
   unsigned long long e_ssq[16];
-  __half e_rh[16], e_rl[16];
+  unsigned int e_rh[16], e_rl[16];   // raw f16 bits, one 32-bit register each: as __half pairs the compiler packed them on arrival,
+                                          // i.e. waited for every pair of loads before requesting the next (16 serial latencies in front of the K walk)
   float e_rf[16];
   if (wave == 0) {
     const int n = bn + (lane & 31), rsub = 4 * (lane >> 5);
@@ -600,8 +601,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
       const bool mok = m < Mlive;
       e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
       e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
-      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
-      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+      e_rh[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[(size_t)m * g.ldrh + n] : 0u;
+      e_rl[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[g.r_ps + (size_t)m * g.ldrh + n] : 0u;
     }
   }
 
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
     if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.resid && ok) v = e_rf[r] + v;
-    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
+    if (g.resid_h && ok) v = x_from_planes(__ushort_as_half((unsigned short)e_rh[r]), __ushort_as_half((unsigned short)e_rl[r])) + v;
     if (ok) {
       if (g.out_h) {
         __half hi, lo;
@@ -739,7 +740,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
   __half* wsm = smem + (size_t)wave * ST * ROWS * HBK;
   // epilogue operands of wave 0, requested before the K walk: lane = column bn + lane % 16, rows 4 (lane / 16) + r
   unsigned long long e_ssq[4];
-  __half e_rh[4], e_rl[4];
+  unsigned int e_rh[4], e_rl[4];   // raw f16 bits, one 32-bit register each: as __half pairs the compiler packed them on arrival,
+                                          // i.e. waited for every pair of loads before requesting the next (16 serial latencies in front of the K walk)
   float e_rf[4];
   if (wave == 0) {
     const int n = bn + (lane & 15), rsub = 4 * (lane >> 4);
@@ -750,8 +752,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
       const bool mok = m < Mlive;
       e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
       e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
-      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
-      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+      e_rh[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[(size_t)m * g.ldrh + n] : 0u;
+      e_rl[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[g.r_ps + (size_t)m * g.ldrh + n] : 0u;
     }
   }
   const __half* src[PIECES];
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
     if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.resid && ok) v = e_rf[r] + v;
-    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
+    if (g.resid_h && ok) v = x_from_planes(__ushort_as_half((unsigned short)e_rh[r]), __ushort_as_half((unsigned short)e_rl[r])) + v;
     if (ok) {
       if (g.out_h) {
         __half hi, lo;
@@ -888,7 +890,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_wsplit_kernel(GemmH2Args g, in
   const bool fused = g.ksplit <= 1;                          // split-K launches store raw partial sums
   // epilogue operands of the quadrant waves, requested before the K walk (see gemm_h2_skinny_kernel)
   unsigned long long e_ssq[16];
-  __half e_rh[16], e_rl[16];
+  unsigned int e_rh[16], e_rl[16];   // raw f16 bits, one 32-bit register each: as __half pairs the compiler packed them on arrival,
+                                          // i.e. waited for every pair of loads before requesting the next (16 serial latencies in front of the K walk)
   float e_rf[16];
   if (wave < NQ && fused) {
     const int n = bn + 32 * qj + (lane & 31), rsub = bm + 32 * qi + 4 * (lane >> 5);
@@ -899,8 +902,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_wsplit_kernel(GemmH2Args g, in
       const bool mok = m < Mlive;
       e_ssq[r] = (g.row_ssq && mok) ? g.row_ssq[m] : 0ull;
       e_rf[r] = (g.resid && mok && nok) ? g.resid[(size_t)m * g.ldr + n] : 0.f;
-      e_rh[r] = (g.resid_h && mok && nok) ? g.resid_h[(size_t)m * g.ldrh + n] : __half(0.f);
-      e_rl[r] = (g.resid_h && mok && nok) ? g.resid_h[g.r_ps + (size_t)m * g.ldrh + n] : __half(0.f);
+      e_rh[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[(size_t)m * g.ldrh + n] : 0u;
+      e_rl[r] = (g.resid_h && mok && nok) ? (unsigned int)reinterpret_cast<const unsigned short*>(g.resid_h)[g.r_ps + (size_t)m * g.ldrh + n] : 0u;
     }
   }
   // K range of this block, then K-tiles wave, wave + 4, ... of it
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_wsplit_kernel(GemmH2Args g, in
     if (g.row_ssq && mok) v *= ssq_rsqrt(e_ssq[r], g.inv_d_fix, g.eps);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.resid && ok) v = e_rf[r] + v;
-    if (g.resid_h && ok) v = x_from_planes(e_rh[r], e_rl[r]) + v;
+    if (g.resid_h && ok) v = x_from_planes(__ushort_as_half((unsigned short)e_rh[r]), __ushort_as_half((unsigned short)e_rl[r])) + v;
     if (ok) {
       if (g.out_h) {
         __half hi, lo;

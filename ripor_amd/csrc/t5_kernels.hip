@@ -450,11 +450,19 @@ __global__ __launch_bounds__(256) void dec_self_attn_fast_kernel(DecSelfAttnArgs
   const float* vb = a.vcache + hbase;
   const int pstr = (int)a.pos_stride, sstr = (int)a.slot_stride;
   int off[SELF_MAXIT];
+  // the ancestry entries of all row groups first, unconditionally (entry t of the row is inside the row and unused): behind the
+  // `pc == t` test every load was retired before the next one was requested — SELF_MAXIT serial latencies in front of the K / V loads
+  int av[SELF_MAXIT];
+#pragma unroll
+  for (int it = 0; it < SELF_MAXIT; ++it) {
+    const int p = it * GP + g;
+    av[it] = (int)ancr[p < nkeys ? p : t];
+  }
 #pragma unroll
   for (int it = 0; it < SELF_MAXIT; ++it) {
     const int p = it * GP + g;
     const int pc = p < nkeys ? p : t;
-    const int slot = (pc == t) ? b : (int)ancr[pc];
+    const int slot = (pc == t) ? b : av[it];
     off[it] = pc * pstr + slot * sstr + li * 4;
   }
   const float4 q4 = *reinterpret_cast<const float4*>(a.q + ((size_t)r * inner + h * D) + li * 4);
