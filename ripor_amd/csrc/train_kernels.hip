@@ -239,14 +239,19 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         const bool ok = rok && i < n4;
-        xv[rr][k] = ok ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        gv[rr][k] = ok ? gr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        rv[rr][k] = (ok && dres) ? rr4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // unconditional loads of clamped addresses, zeroed by selects: behind the range test every load was retired
+        // (s_waitcnt vmcnt(0)) before the next one was requested
+        const int ic = i < n4 ? i : 0;
+        const float4 lx = xr[ic], lg = gr[ic], lr = rr4[ic];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[rr][k] = ok ? lx : z4;
+        gv[rr][k] = ok ? lg : z4;
+        rv[rr][k] = (ok && dres) ? lr : z4;
       }
     }
     float4 wv[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; wv[k] = i < n4 ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; const float4 lw = wr[i < n4 ? i : 0]; wv[k] = i < n4 ? lw : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
       const int row = blockIdx.x * NB_ROWS + rr * 4 + wave;
@@ -1092,12 +1097,13 @@ __global__ __launch_bounds__(512) void rmsnorm_bf16_T_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = lane + 64 * k;
-      xv[rr][k] = (row < rows && i < n4) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 lx = xr[i < n4 ? i : 0];   // unconditional (clamped) load + select: see rmsnorm_bwd_kernel
+      xv[rr][k] = (row < rows && i < n4) ? lx : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   float4 wv[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; wv[k] = i < n4 ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  for (int k = 0; k < NV; ++k) { const int i = lane + 64 * k; const float4 lw = wr[i < n4 ? i : 0]; wv[k] = i < n4 ? lw : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
     const int lr = wave * NR + rr, row = r0 + lr;
