@@ -195,10 +195,11 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
   E(w.ff, R * dff * f); E(w.logits, R * (size_t)m->Vp() * f);
   const size_t depth0 = forks.empty() ? (size_t)L : (size_t)forks[0];   // stage 0 stops at the first fork
   E(w.kcache, nd * depth0 * R * inner * f); E(w.vcache, nd * depth0 * R * inner * f);
-  E(w.lb, R * (size_t)m->Vp() * 4);
+  E(w.lb, R * (size_t)m->Vp() * 4 * 2);   // start and end of every child's row range
   {
     const int G = select_groups(Q, B, m->Vp(), 256);
     if (G > 1) E(w.sel_part, R * (size_t)G * 20);
+    if (select_radix_wanted(B, m->Vp())) E(w.sel_rs, select_radix_ws_bytes(Q, B, m->Vp()));
   }
   for (int i = 0; i < 2; ++i) {
     E(w.score[i], R * 8); E(w.lo[i], R * 4); E(w.hi[i], R * 4);
@@ -454,7 +455,13 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     SelectArgs sa{};
     sa.logits = lg; sa.codes = tr->codes; sa.Lc = tr->L; sa.cur = cur; sa.nxt = nxt;
     sa.lb_scratch = P<int32_t>(w.lb); sa.Q = Q; sa.B = B; sa.V = Vp; sa.Vreal = V; sa.t = t;
-    if (tr->lvl_V == tr->V) { sa.lvl0 = tr->lvl0; sa.lvl1 = tr->lvl1; sa.lvl_V = tr->lvl_V; }
+    if (tr->lvl_V == tr->V) {
+      sa.lvl0 = tr->lvl0; sa.lvl1 = tr->lvl1; sa.lvl_V = tr->lvl_V;
+      sa.idx2 = tr->idx2; sa.n_deep = tr->n_deep;
+      for (int i = 0; i < tr->n_deep; ++i) { sa.d_start[i] = tr->d_start[i]; sa.d_tok[i] = tr->d_tok[i]; sa.d_n[i] = tr->d_n[i]; }
+    }
+    if (w.sel_rs.p && select_radix_wanted(B, Vp) && w.sel_rs.cap >= select_radix_ws_bytes(Q, B, Vp))
+      select_radix_carve(sa.rs, w.sel_rs.p, P<int32_t>(w.lb) + (size_t)R * Vp, Q, B, Vp);
     sa.log_softmax = (sd.flags & RPR_FLAG_LOG_SOFTMAX) ? 1 : 0;
     sa.shared0 = (Bt != B) ? 1 : 0;
     sa.nq_dev = sv.nq_dev;
@@ -467,7 +474,7 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
     if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
     // few queries x many beams: G blocks per query + a merge, on the steps whose candidate sets are large — about
     // B * min(V, docs per depth-t node) valid candidates; narrow steps go through the single block's compact path
-    const int G = taps ? 1 : select_groups(sd.Q, B, Vp, 256);
+    const int G = (taps || sa.rs.hist) ? 1 : select_groups(sd.Q, B, Vp, 256);
     if (G > 1 && w.sel_part.p) {
       double per_node = (double)tr->N;
       for (int i = 0; i < t && per_node > 1.0; ++i) per_node /= (double)V;
@@ -674,6 +681,11 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   sv.kcache = P<float>(w.kcache); sv.vcache = P<float>(w.vcache); sv.depth = forks.empty() ? L : forks[0]; sv.dkv = d.d_kv;
   for (int i = 0; i < 2; ++i) sv.st[i] = beam_state(w.score, w.lo, w.hi, w.tokens, w.anc, i, L);
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_init_beams(sv.st[0], Q, B, tr->N, s); });
+  if (w.sel_rs.p && select_radix_wanted(B, m->Vp()) && w.sel_rs.cap >= select_radix_ws_bytes(Q, B, m->Vp())) {
+    RadixWs rs;   // the radix selection's histograms and counters start at zero (every step leaves them so)
+    select_radix_carve(rs, w.sel_rs.p, nullptr, Q, B, m->Vp());
+    Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_select_radix_reset(rs, Q, s); });
+  }
 
   // Step 0: every beam of a query starts from the same start embedding and the same encoder states, so the
   // decoder pass is computed once per query (Q rows, "one beam") and select reads the shared logits row; the
@@ -1009,39 +1021,39 @@ void rpr_free_model(rpr_model* m) {
   delete m;
 }
 
+// child arrays of the trie for its current vocab size (see rpr_trie / trie.h ChildLevels): built on the host in one pass over
+// the sorted rows, uploaded once; rpr_trie_set_vocab rebuilds them (the dense tables are indexed with V)
+static int upload_levels(rpr_trie* t) {
+  t->free_levels();
+  static const bool levels_on = [] { const char* e = getenv("RPR_SELECT_LEVELS"); return !(e && atoi(e) == 0); }();
+  if (!levels_on || t->N >= ((int64_t)1 << 31) - 1) return RPR_OK;
+  ChildLevels cl;
+  // at most two entries per doc over all the deep levels: 8.8 M x 32 MS MARCO codes need 6.9 M (level 2 only)
+  build_child_levels(t->host_sorted.data(), t->N, t->L, t->V, TRIE_NARROW, TRIE_MAX_DEEP, 2 * t->N + 1024, cl);
+  auto up = [](auto*& dst, const auto& v) -> hipError_t {
+    if (v.empty()) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dst), v.size() * sizeof(v[0]));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
+  };
+  RPR_HIP(up(t->lvl0, cl.lvl0));
+  RPR_HIP(up(t->lvl1, cl.lvl1));
+  if (!cl.deep.empty()) RPR_HIP(up(t->idx2, cl.idx2));
+  for (size_t i = 0; i < cl.deep.size() && i < (size_t)TRIE_MAX_DEEP; ++i) {
+    RPR_HIP(up(t->d_start[i], cl.deep[i].start));
+    RPR_HIP(up(t->d_tok[i], cl.deep[i].tok));
+    t->d_n[i] = (int)cl.deep[i].start.size();
+    t->n_deep = (int)i + 1;
+  }
+  t->lvl_V = t->V;
+  return RPR_OK;
+}
+
 static int upload_trie(rpr_ctx* c, std::unique_ptr<rpr_trie>& t) {
   RPR_HIP(hipSetDevice(c->device));
   RPR_HIP(hipMalloc(&t->codes, t->host_sorted.size() * sizeof(uint16_t)));
   RPR_HIP(hipMemcpy(t->codes, t->host_sorted.data(), t->host_sorted.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  // child arrays of the first two levels (see rpr_trie): one pass over the sorted rows
-  static const bool levels_on = [] { const char* e = getenv("RPR_SELECT_LEVELS"); return !(e && atoi(e) == 0); }();
-  if (levels_on && t->N < ((int64_t)1 << 31) - 1) {
-    const int V = t->V, L = t->L;
-    const int64_t N = t->N;
-    const uint16_t* c = t->host_sorted.data();
-    std::vector<int32_t> l0((size_t)V + 1, (int32_t)N);
-    {
-      int next = 0;                                   // tokens < next have their lower bound
-      for (int64_t r = 0; r < N; ++r) {
-        const int v = c[(size_t)r * L];
-        while (next <= v) l0[(size_t)next++] = (int32_t)r;
-      }
-    }
-    RPR_HIP(hipMalloc(&t->lvl0, l0.size() * 4));
-    RPR_HIP(hipMemcpy(t->lvl0, l0.data(), l0.size() * 4, hipMemcpyHostToDevice));
-    if (L >= 2 && V <= 1024) {
-      std::vector<int32_t> l1((size_t)V * V + 1, (int32_t)N);
-      int64_t next = 0;
-      for (int64_t r = 0; r < N; ++r) {
-        const int64_t v = (int64_t)c[(size_t)r * L] * V + c[(size_t)r * L + 1];
-        while (next <= v) l1[(size_t)next++] = (int32_t)r;
-      }
-      RPR_HIP(hipMalloc(&t->lvl1, l1.size() * 4));
-      RPR_HIP(hipMemcpy(t->lvl1, l1.data(), l1.size() * 4, hipMemcpyHostToDevice));
-    }
-    t->lvl_V = V;
-  }
-  return RPR_OK;
+  return upload_levels(t.get());
 }
 
 int rpr_build_trie(rpr_ctx* c, const uint16_t* codes, int64_t N, int32_t L, int32_t V, rpr_trie** out) {
@@ -1191,9 +1203,16 @@ int rpr_trie_set_vocab(rpr_trie* t, int32_t V) {
   uint16_t mx = 0;
   for (uint16_t v : t->host_sorted) mx = v > mx ? v : mx;
   RPR_REQUIRE((int)mx < V, "a code of the trie is >= the requested vocab size");
-  if (V != t->V) t->lvl_V = 0;   // the level tables are indexed with the vocab size they were built for: searches fall back to the probes
+  if (V == t->V) return RPR_OK;
   t->V = V;
-  return RPR_OK;
+  // the child arrays are indexed with the vocab size they were built for: rebuild them (searches captured against the old
+  // tables are dropped with them)
+  RPR_HIP(hipSetDevice(t->ctx->device));
+  RPR_HIP(hipDeviceSynchronize());
+  for (auto it = t->ctx->graphs.begin(); it != t->ctx->graphs.end();) {
+    if (it->first.t == t) { (void)hipGraphExecDestroy(it->second); it = t->ctx->graphs.erase(it); } else ++it;
+  }
+  return upload_levels(t);
 }
 
 int rpr_d2s_open(const char* path, rpr_d2s** out) {
@@ -1355,7 +1374,7 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
     // the per-call debug switches of the selection / ranking kernels are part of the key (tests flip them between calls)
     auto env_int = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
     const unsigned dbg = ((unsigned)(env_int("RPR_SELECT_GROUPS", -1) + 1) & 0x3fu) | (env_int("RPR_SELECT_GROUPS_ALL", 0) ? 0x40u : 0u) |
-                         (env_int("RPR_TAIL_RANK_REPLAY", 0) ? 0x80u : 0u);
+                         (env_int("RPR_TAIL_RANK_REPLAY", 0) ? 0x80u : 0u) | ((unsigned)(env_int("RPR_SELECT_RADIX", -1) + 1) << 8);
     GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16) | (dbg << 20), lane, pack_forks(forks, drop_last)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {

@@ -600,13 +600,16 @@ hipError_t init_beam_kernel_attributes() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           MERGE_MAX * 12);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<SEL_TK_HOST>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<SEL_TK_HOST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024);
+  if (e != hipSuccess) return e;
+  return init_select_radix_attributes();
 }
 
 hipError_t launch_select(const SelectArgs& a_in, hipStream_t s) {
   SelectArgs a = a_in;
   if (a.V % 64 != 0) return hipErrorInvalidValue;
+  if (a.rs.hist && select_radix_wanted(a.B, a.V)) return launch_select_radix(a, s);   // many beams: select_radix.hip
   const int G = a.G > 1 ? a.G : 1;
   if (G > 1 && (a.B % G != 0 || !a.p_score || !a.p_item || !a.p_lo || !a.p_hi || (long)G * a.B > MERGE_MAX || a.tap_scores ||
                 a.tap_tokens || a.tap_parent || a.tap_valid))

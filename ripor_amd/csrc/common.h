@@ -280,6 +280,20 @@ struct BeamState {           // one of two ping-pong buffers
 };
 hipError_t launch_init_beams(const BeamState& st, int Q, int B, int64_t N, hipStream_t s);
 
+// Scratch of the radix selection (select_radix.hip), carved from one buffer by select_radix_carve
+struct RadixWs {
+  unsigned* hist;            // [Q][3][2048] digit histograms of the three passes (zero between steps)
+  unsigned* cnt;             // [Q][4] collected winners, collected ties
+  unsigned long long* valid; // [Q][B * V / 64] child bitmap (bit = beam * V + token)
+  float* lstat;              // [Q][B][2] log-softmax mode: row maximum, log of the sum
+  int32_t* win;              // [Q][B] candidates above the threshold prefix
+  int32_t* tie;              // [Q][B * V] candidates on it
+  int32_t* chi;              // [R, V] end of the child's row range (SelectArgs::lb_scratch holds its start)
+  int sort_cap;              // set by the launcher: entries of the finish kernel's LDS sort
+};
+constexpr int TRIE_NARROW = 64;   // trie nodes of at most this many rows have no entries in the deep child arrays (trie.h)
+constexpr int TRIE_MAX_DEEP = 6;  // CSR levels 2 .. 7
+
 struct SelectArgs {
   const float* logits;       // [R, V]
   const uint16_t* codes;     // sorted [N, Lc]
@@ -289,6 +303,10 @@ struct SelectArgs {
   const int32_t* lvl0;       // nullable: child arrays of trie levels 0 / 1 (rpr_trie::lvl0 / lvl1), row stride lvl_V
   const int32_t* lvl1;
   int lvl_V;
+  // radix selection only: CSR child arrays of the levels 2 .. 2 + n_deep - 1 and the level-2 entry of every (c0, c1) node
+  const int32_t* idx2;
+  const int32_t* d_start[TRIE_MAX_DEEP]; const uint16_t* d_tok[TRIE_MAX_DEEP]; int d_n[TRIE_MAX_DEEP]; int n_deep;
+  RadixWs rs;                // rs.hist != nullptr: the launch may take the radix path (launch_select decides)
   int Q, B, V, t;            // V: width of the token axis = the model's vocab rounded up to 64 (logits row stride)
   int Vreal;                 // the model's decoder vocab size (0 = V): tokens >= Vreal are padding and never selectable
   int log_softmax;
@@ -306,6 +324,14 @@ struct SelectArgs {
   double* p_score; int32_t* p_item; int32_t* p_lo; int32_t* p_hi;
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
+// radix selection (select_radix.hip): many beams per query — five launches over all the CUs instead of one block per query
+bool select_radix_fits(int B, int V);
+bool select_radix_wanted(int B, int V);                  // the launcher's choice for this beam count (RPR_SELECT_RADIX overrides)
+size_t select_radix_ws_bytes(int Q, int B, int V);
+void select_radix_carve(RadixWs& w, void* base, int32_t* chi, int Q, int B, int V);
+hipError_t init_select_radix_attributes();
+hipError_t launch_select_radix_reset(const RadixWs& w, int Q, hipStream_t s);
+hipError_t launch_select_radix(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
 // number of blocks per query a grouped launch would use for Q queries of B beams (1 = not worth it / not possible)
 int select_groups(int Q, int B, int V, int cus);

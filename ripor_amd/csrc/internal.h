@@ -72,11 +72,29 @@ struct rpr_trie {
   int32_t* lvl0 = nullptr;
   int32_t* lvl1 = nullptr;
   int lvl_V = 0;
+  // [dev] round 6: CSR child arrays of the deeper levels (trie.h ChildLevels::deep: children of every node of more than
+  // TRIE_NARROW rows) and the level-2 entry of every (c0, c1) node; read by the radix selection (select_radix.hip)
+  int32_t* idx2 = nullptr;
+  int32_t* d_start[rpr::TRIE_MAX_DEEP] = {};
+  uint16_t* d_tok[rpr::TRIE_MAX_DEEP] = {};
+  int d_n[rpr::TRIE_MAX_DEEP] = {};
+  int n_deep = 0;
+  void free_levels() {
+    if (lvl0) (void)hipFree(lvl0);
+    if (lvl1) (void)hipFree(lvl1);
+    if (idx2) (void)hipFree(idx2);
+    for (int i = 0; i < rpr::TRIE_MAX_DEEP; ++i) {
+      if (d_start[i]) (void)hipFree(d_start[i]);
+      if (d_tok[i]) (void)hipFree(d_tok[i]);
+      d_start[i] = nullptr; d_tok[i] = nullptr; d_n[i] = 0;
+    }
+    lvl0 = lvl1 = idx2 = nullptr; n_deep = 0; lvl_V = 0;
+  }
   std::vector<int64_t> perm;
   std::vector<uint16_t> host_sorted;
   std::string keys;           // docid strings in original row order, '\n'-joined (only when loaded from a file that has them)
   std::map<int, std::vector<double>> single_frac;   // per search length L: trie_single_frac (lazily, first search of that length)
-  ~rpr_trie() { if (codes) (void)hipFree(codes); if (lvl0) (void)hipFree(lvl0); if (lvl1) (void)hipFree(lvl1); }
+  ~rpr_trie() { if (codes) (void)hipFree(codes); free_levels(); }
 };
 
 struct rpr_d2s {
@@ -119,6 +137,7 @@ struct Workspace {
   // decoder
   DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
   DevBuf sel_part;        // grouped selection (few queries x many beams): partial winners [Q, G, B] x (f64 + 3 x i32)
+  DevBuf sel_rs;          // radix selection (many beams): RadixWs scratch (select_radix_carve)
   // beam state (2 ping-pong buffers)
   DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];
   // staged outputs

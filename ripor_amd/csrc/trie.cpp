@@ -127,6 +127,61 @@ void trie_single_frac(const uint16_t* sorted, int64_t N, int Lc, int L, std::vec
   }
 }
 
+// ---- child arrays ------------------------------------------------------------------------------------------------------
+// One pass computes lcp[r] = common prefix length of rows r - 1 and r (capped at 255; lcp[0] = 0): row r opens a new depth-t
+// node iff r == 0 or lcp[r] < t. Level t lists the rows that open a depth-(t + 1) node inside a depth-t node of more than
+// `narrow` rows. Wide nodes nest, so the first level without any ends the build.
+void build_child_levels(const uint16_t* sorted, int64_t N, int Lc, int V, int narrow, int max_levels, int64_t max_entries,
+                        ChildLevels& out) {
+  out = ChildLevels{};
+  if (N <= 0 || Lc < 1 || V < 1) return;
+  out.lvl0.assign((size_t)V + 1, (int32_t)N);
+  {
+    int next = 0;                                   // tokens < next have their lower bound
+    for (int64_t r = 0; r < N; ++r) {
+      const int v = sorted[(size_t)r * Lc];
+      while (next <= v) out.lvl0[(size_t)next++] = (int32_t)r;
+    }
+  }
+  if (Lc < 2 || V > 1024) return;
+  out.lvl1.assign((size_t)V * V + 1, (int32_t)N);
+  {
+    int64_t next = 0;
+    for (int64_t r = 0; r < N; ++r) {
+      const int64_t v = (int64_t)sorted[(size_t)r * Lc] * V + sorted[(size_t)r * Lc + 1];
+      while (next <= v) out.lvl1[(size_t)next++] = (int32_t)r;
+    }
+  }
+  if (Lc < 3 || max_levels < 1) return;
+  std::vector<uint8_t> lcp((size_t)N, 0);
+  for (int64_t r = 1; r < N; ++r) {
+    const uint16_t* p = sorted + (size_t)(r - 1) * Lc;
+    const uint16_t* q = p + Lc;
+    int c = 0;
+    while (c < Lc && c < 255 && p[c] == q[c]) ++c;
+    lcp[(size_t)r] = (uint8_t)c;
+  }
+  out.idx2.assign((size_t)V * V, -1);
+  int64_t total = 0;
+  for (int t = 2; t < Lc && t < 255 && (int)out.deep.size() < max_levels; ++t) {
+    ChildLevels::Level lv;
+    int64_t a = 0;                                  // first row of the current depth-t node
+    for (int64_t r = 1; r <= N; ++r) {
+      if (r < N && lcp[(size_t)r] >= t) continue;   // same depth-t node
+      if (r - a > narrow) {
+        if (t == 2) out.idx2[(size_t)sorted[(size_t)a * Lc] * V + sorted[(size_t)a * Lc + 1]] = (int32_t)lv.start.size();
+        for (int64_t k = a; k < r; ++k)
+          if (k == a || lcp[(size_t)k] < t + 1) { lv.start.push_back((int32_t)k); lv.tok.push_back(sorted[(size_t)k * Lc + t]); }
+      }
+      a = r;
+    }
+    if (lv.start.empty()) break;
+    total += (int64_t)lv.start.size();
+    if (total > max_entries) { if (t == 2) std::fill(out.idx2.begin(), out.idx2.end(), -1); break; }
+    out.deep.push_back(std::move(lv));
+  }
+}
+
 // ---- docid_to_smtid.json ------------------------------------------------------------------------------------
 // One pass over the file with a 4 MB read buffer; no DOM. The reference loads this file with ujson into a dict of
 // 8.8 M Python lists (minutes and tens of GB, evaluate.py:400-402); here it becomes a uint16 matrix directly.

@@ -312,9 +312,9 @@ def test_rank_replay_path_equals_single_ranking_pass(E, monkeypatch):
 
 
 def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
-    """Beam 512 / 1000 with 2 queries: the automatic grouped selection (16 / 8 blocks per query on the wide steps, the
-    single block's compact path on the narrow ones) returns the bits of the single-block kernel, with and without the
-    forced tail; so does grouping forced onto every step."""
+    """Beam 512 / 1000 with 2 queries: the radix selection (the default from 256 beams on, select_radix.hip) and the grouped
+    selection it replaces (16 / 8 blocks per query on the wide steps + merge; RPR_SELECT_RADIX=0) return the bits of the
+    single-block kernel, with and without the forced tail; so does grouping forced onto every step."""
     from ripor_amd.utils import synth
     L, V, N = 12, 256, 300_000
     codes = synth.make_codes(N, L, V, seed=9)
@@ -324,15 +324,19 @@ def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
         for B in (512, 1000):
             for ft in (False, True):
                 ctx.set_forced_tail(ft)
+                monkeypatch.setenv("RPR_SELECT_RADIX", "0")
                 monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
                 monkeypatch.delenv("RPR_SELECT_GROUPS_ALL", raising=False)
                 ref = E.search(model, trie, ti, tm, B, L)
                 monkeypatch.delenv("RPR_SELECT_GROUPS")
-                auto = E.search(model, trie, ti, tm, B, L)
+                grouped = E.search(model, trie, ti, tm, B, L)
                 monkeypatch.setenv("RPR_SELECT_GROUPS_ALL", "1")
                 every = E.search(model, trie, ti, tm, B, L)
+                monkeypatch.delenv("RPR_SELECT_GROUPS_ALL")
+                monkeypatch.delenv("RPR_SELECT_RADIX")
+                radix = E.search(model, trie, ti, tm, B, L)
                 torch.cuda.synchronize()
-                for r, lab in ((auto, "auto"), (every, "every step")):
+                for r, lab in ((grouped, "grouped"), (every, "grouped on every step"), (radix, "radix (default)")):
                     assert torch.equal(r.tokens, ref.tokens) and torch.equal(r.scores, ref.scores), (B, ft, lab)
                     assert torch.equal(r.row_lo, ref.row_lo) and torch.equal(r.row_hi, ref.row_hi), (B, ft, lab)
     finally:
@@ -367,8 +371,9 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
         try:
             for name, ft, env in (("plain", False, {}), ("forced", True, {}), ("forced+replay", True, {"RPR_TAIL_RANK_REPLAY": "1"}),
                                   ("grouped", False, {"RPR_SELECT_GROUPS": "4", "RPR_SELECT_GROUPS_ALL": "1"}),
-                                  ("grouped+forced", True, {"RPR_SELECT_GROUPS": "3", "RPR_SELECT_GROUPS_ALL": "1"})):
-                for k in ("RPR_TAIL_RANK_REPLAY", "RPR_SELECT_GROUPS", "RPR_SELECT_GROUPS_ALL"):
+                                  ("grouped+forced", True, {"RPR_SELECT_GROUPS": "3", "RPR_SELECT_GROUPS_ALL": "1"}),
+                                  ("radix", False, {"RPR_SELECT_RADIX": "1"}), ("radix+forced", True, {"RPR_SELECT_RADIX": "1"})):
+                for k in ("RPR_TAIL_RANK_REPLAY", "RPR_SELECT_GROUPS", "RPR_SELECT_GROUPS_ALL", "RPR_SELECT_RADIX"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -389,7 +394,7 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
         # The step loop takes its logits from the split-precision GEMM, the tail pass from an exact fp32 dot product: with
         # non-zero codebooks the two families agree to ~1e-5, not to the bit, so bits are compared inside a family; with the
         # zero codebooks every tail logit is exactly 0 on both sides and all five paths must agree bit for bit.
-        families = ([("plain", "grouped"), ("forced", "forced+replay", "grouped+forced")] if variant == "paired rows"
+        families = ([("plain", "grouped", "radix"), ("forced", "forced+replay", "grouped+forced", "radix+forced")] if variant == "paired rows"
                     else [tuple(results)])
         for fam in families:
             base = results[fam[0]]
