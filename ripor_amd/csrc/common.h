@@ -58,12 +58,27 @@ __host__ __device__ __forceinline__ float dyn_plane_scale(float amax) {
   return u.f;
 }
 
-// Row sum of squares in fixed point (2^-20 units, int64): partial sums from different blocks are combined with
+// Row sum of squares in fixed point (2^-16 units, 64 bits): partial sums from different blocks are combined with
 // integer atomics, so the total does not depend on the order of arrival (bitwise-reproducible RMSNorm scale).
-constexpr float SSQ_FIX = 1048576.0f;
-__device__ __forceinline__ unsigned long long ssq_to_fix(float ss) { return (unsigned long long)(long long)(ss * SSQ_FIX); }
+// Range (round 6; the residual planes hold |x| < 1.05e6 since round 5, common.h X_PLANE_SCALE): a partial added by an
+// epilogue is capped at 2^57 units (2.2e12: two elements at the plane limit) and a row has at most 64 of them (16-column
+// tiles of d_model = 1024), so the 64-bit total cannot wrap; a row stored whole by an embedding kernel is capped at 2^63
+// (1.4e14: RMS 4.3e5 at d = 768). A capped value raises the ctx's sticky saturation word like a clamped plane element does,
+// and the boundary repeats the batch in exact fp32. (Until round 5: 2^-20 units read back as a signed value — the sum wrapped
+// silently from sum x^2 = 8.8e12 on, RMS 1e5 at d = 768.) Partials are rounded to nearest: the error of a row total is
+// ~6e-5 absolute, 1e-7 of a row of RMS 1.
+constexpr float SSQ_FIX = 65536.0f;
+constexpr float SSQ_PART_CAP = 2199023255552.0f;        // 2^41 = 2^57 units
+constexpr float SSQ_ROW_CAP = 140737488355328.0f;       // 2^47 = 2^63 units
+__device__ __forceinline__ unsigned long long ssq_to_fix(float ss, unsigned int* sat, float cap = SSQ_PART_CAP) {
+  if (!(ss < cap)) {                 // also NaN
+    if (sat) *sat = 1u;              // benign race: every writer stores 1
+    ss = cap;
+  }
+  return (unsigned long long)(ss * SSQ_FIX + 0.5f);
+}
 __device__ __forceinline__ float ssq_rsqrt(unsigned long long fix, float inv_d_fix, float eps) {
-  return rsqrtf(fmaf((float)(long long)fix, inv_d_fix, eps));   // inv_d_fix = 1 / (d * SSQ_FIX)
+  return rsqrtf(fmaf((float)fix, inv_d_fix, eps));   // inv_d_fix = 1 / (d * SSQ_FIX)
 }
 
 // ---- GEMM: C = act(A @ W^T) (+ residual), fp32 MFMA --------------------------------------------

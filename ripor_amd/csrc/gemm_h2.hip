@@ -395,7 +395,7 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
             if (!ok) ss = 0.f;
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+            if ((lane % LPR) == 0 && (FULL || m < Mlim)) atomicAdd(g.ssq_out + m, ssq_to_fix(ss, g.sat));
           }
         }
       }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny_kernel(GemmH2Args g, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = bm + rsub + (r & 3) + 8 * (r >> 2);
-        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
+        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r], g.sat));
       }
     }
   }
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_skinny16_kernel(GemmH2Args g, 
     if ((lane & 15) == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (bm + rsub + r < Mlive) atomicAdd(g.ssq_out + bm + rsub + r, ssq_to_fix(ssr[r]));
+        if (bm + rsub + r < Mlive) atomicAdd(g.ssq_out + bm + rsub + r, ssq_to_fix(ssr[r], g.sat));
     }
   }
 }
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256, 1) void gemm_h2_wsplit_kernel(GemmH2Args g, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = rsub + (r & 3) + 8 * (r >> 2);
-        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r]));
+        if (m < Mlive) atomicAdd(g.ssq_out + m, ssq_to_fix(ssr[r], g.sat));
       }
     }
   }
@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmH2Args g, cons
     float ss = v * v;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss, g.sat));
   }
 }
 
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue4_kernel(GemmH2Args g, con
     float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss));
+    if ((threadIdx.x & 63) == 0) atomicAdd(g.ssq_out + m, ssq_to_fix(ss, g.sat));
   }
 }
 

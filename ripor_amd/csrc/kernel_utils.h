@@ -73,7 +73,7 @@ __device__ __forceinline__ void copy_row_x(const float4* __restrict__ src, float
   }
   if (xo.ssq) {
     ss = wave_sum(ss);
-    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss);
+    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss, xo.sat, SSQ_ROW_CAP);
   }
 }
 

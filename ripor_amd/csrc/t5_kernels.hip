@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   for (int p0 = 0; p0 < nkeys; p0 += GP) {
     const int p = p0 + g;
     if (p < nkeys) {
-      const float wgt = S[p] / sum;
+      const float wgt = sum > 0.f ? S[p] / sum : 0.f;   // every key masked (an empty query): zeros, like dec_cross_attn_block_kernel
       if (wgt != 0.f) {
         const float4 v4 = *reinterpret_cast<const float4*>(vbase + row_off(p));
         acc.x = fmaf(wgt, v4.x, acc.x);

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void train_dec_embed_kernel(const float* __res
   }
   if (xo.ssq) {
     ss = wave_sum_f(ss);
-    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss);
+    if (lane == 0) xo.ssq[row] = ssq_to_fix(ss, xo.sat, SSQ_ROW_CAP);
   }
 }
 

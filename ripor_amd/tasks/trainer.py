@@ -126,9 +126,18 @@ class LngKnpTrainer:
                         if self.rank == 0:
                             self.log(json.dumps(rec))
                         window = []
-                    if a.save_steps > 0 and self.global_step % a.save_steps == 0 and self.rank == 0:
-                        self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
-                        self._rotate()
+                    if a.save_steps > 0 and self.global_step % a.save_steps == 0:
+                        ck = os.path.join(a.output_dir, f"checkpoint-{self.global_step}")
+                        if self.rank == 0:
+                            self.save_checkpoint(ck)          # weights, optimizer state, rank 0's RNG state
+                        if self.world > 1:
+                            import torch.distributed as dist
+                            dist.barrier()                    # the directory exists
+                            if self.rank != 0:
+                                self.save_rng_state(ck)       # every rank draws its own negatives: one RNG file per rank, like HF
+                            dist.barrier()
+                        if self.rank == 0:
+                            self._rotate()
                 epoch += 1
                 skip = 0
         finally:
@@ -161,7 +170,17 @@ class LngKnpTrainer:
         if st is not None:
             torch.save(dict(exp_avg=st.exp_avg.cpu(), exp_avg_sq=st.exp_avg_sq.cpu(), step=int(st.step), total=int(st.total)),
                        os.path.join(path, "optimizer.pt"))
-        torch.save(dict(python=random.getstate(), torch=torch.get_rng_state()), os.path.join(path, "rng_state.pth"))
+        self.save_rng_state(path)
+
+    def _rng_file(self, path: str) -> str:
+        """HF Trainer's naming: rng_state.pth for one process, rng_state_<rank>.pth per process of a distributed run."""
+        return os.path.join(path, "rng_state.pth" if self.world == 1 else f"rng_state_{self.rank}.pth")
+
+    def save_rng_state(self, path: str):
+        """This rank's Python / torch RNG states (the dataset draws its negatives with random.sample: every rank consumes its
+        own stream, so a multi-rank run resumes as the same run only if every rank gets ITS state back)."""
+        import random
+        torch.save(dict(python=random.getstate(), torch=torch.get_rng_state()), self._rng_file(path))
 
     def load_checkpoint_state(self, path: str) -> int:
         """Restore what ``save_checkpoint`` wrote beside the weights (the caller loads those: ``from_pretrained(path)``):
@@ -180,7 +199,10 @@ class LngKnpTrainer:
             if int(o["total"]) != int(st.total):
                 raise ValueError(f"{opt}: {o['total']} parameters, the model has {st.total}")
             st.exp_avg.copy_(o["exp_avg"]); st.exp_avg_sq.copy_(o["exp_avg_sq"]); st.step = int(o["step"])
-        rng = os.path.join(path, "rng_state.pth")
+        rng = self._rng_file(path)
+        if not os.path.exists(rng) and self.world > 1:
+            raise ValueError(f"{path}: no RNG state of rank {self.rank} ({os.path.basename(rng)}): the checkpoint was not written by "
+                             f"a {self.world}-rank run of this trainer")
         if os.path.exists(rng):
             r = torch.load(rng, map_location="cpu", weights_only=False)
             random.setstate(r["python"]); torch.set_rng_state(r["torch"])

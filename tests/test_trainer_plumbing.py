@@ -261,3 +261,9 @@ def test_resume_continues_the_interrupted_run(tmp_path):
         r2, t2 = make("part", 10)
         t2.steps_per_epoch += 1
         t2.train(resume_from_checkpoint=ck)
+    # a distributed run keeps one RNG file per rank (HF Trainer's rng_state_<rank>.pth): every rank draws its own negatives
+    r3, t3 = make("part", 10)
+    t3.world, t3.rank = 2, 1
+    assert os.path.basename(t3._rng_file(ck)) == "rng_state_1.pth"
+    t3.save_rng_state(ck)
+    assert "rng_state_1.pth" in os.listdir(ck) and "rng_state.pth" in os.listdir(ck)
