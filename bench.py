@@ -329,12 +329,26 @@ def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
     return out
 
 
+def _small_batch_traffic(key):
+    """(bytes per search, provenance) of a small-batch configuration from the committed PMC passes (profiles/latest_small_batch_pmc.json,
+    written by tools/small_batch_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, summed over every rpr:: kernel)."""
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "latest_small_batch_pmc.json")))
+        e = pmc[key]
+        b = (2.0 * e["fetch_kb_per_search"] + e["write_kb_per_search"]) * 1024.0
+        return b, (f"profiles/latest_small_batch_pmc.json[{key}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 over all kernels of one search; "
+                   f"counters of build {pmc.get('_meta', {}).get('build')}, this run is build {BUILD_ID}")
+    except Exception:
+        return None, None
+
+
 def secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L, steps=8):
     """the regime north_star's "fraction of the HBM roofline" is about — 1, 8 and 64 queries in flight
     (the reference script's literal setting is batch 1). Per batch size: queries/s, ms per search, and a `roofline` object
-    of bound "hbm": achieved = SURVEY §8(d)'s algorithmic bytes per query at this Q x queries/s against the 8 TB/s peak
-    (`achieved_forced_tail`: the bytes of the forced-tail algorithm actually run, first fork from the search itself), plus
-    the GEMM launches' share of the search from one event-timed eager pass (`gemm_ms`, `launches`)."""
+    of bound "hbm": achieved = the bytes of the forced-tail algorithm actually run (first fork from the search itself) x
+    queries/s against the 8 TB/s peak (`*_8d_equivalent`: SURVEY §8(d)'s bytes of the step-by-step algorithm — an equivalent-work
+    ratio), `traffic` from the committed PMC passes, plus the GEMM launches' share of the search from one
+    event-timed eager pass (`gemm_ms`, `launches`)."""
     out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams={B}, len={L}, Q queries per search, hipGraph replay", "unit": "queries/s"}
     for Q in (1, 8, 64):
         batches = _query_batches(synth, dims, Q, 4, dev, seed=404 + Q)
@@ -349,20 +363,70 @@ def secondary_small_batch(E, synth, ctx, model, trie, dims, dev, B, L, steps=8):
         n_launch = sum(int(v["launches"]) for v in stats.values())
         gemm_ms = stats["gemm"]["total_ms"] + stats["gemm_small"]["total_ms"]
         qps = Q / dt
+        traffic, traffic_src = _small_batch_traffic(f"q{Q}_b{B}")
         out[f"q{Q}"] = {
             "value": qps, "ms_per_search": dt * 1e3, "padded_len": Lq, "mean_query_tokens": lq_mean,
             "forks_last_search": forks, "leftover_fallback_taken": fb, "launches_per_search": n_launch,
             "gemm_ms_event_timed": gemm_ms,
-            "roofline": {"bound": "hbm", "achieved": by_8d * qps / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
-                         "frac": by_8d * qps / 1e12 / PEAK_HBM_TBS, "traffic": None,
-                         "algorithmic_bytes_per_query": by_8d,
-                         "achieved_forced_tail": by_ft * qps / 1e9, "frac_forced_tail": by_ft * qps / 1e12 / PEAK_HBM_TBS,
-                         "algorithmic_bytes_per_query_forced_tail": by_ft,
+            "roofline": {"bound": "hbm", "achieved": by_ft * qps / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                         "frac": by_ft * qps / 1e12 / PEAK_HBM_TBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_query": by_ft,
+                         "achieved_8d_equivalent": by_8d * qps / 1e9, "frac_8d_equivalent": by_8d * qps / 1e12 / PEAK_HBM_TBS,
+                         "algorithmic_bytes_per_query_8d": by_8d,
                          "flops_per_query_forced_tail": fl_ft,
                          "mfma_frac_forced_tail": fl_ft * qps / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0),
                          "note": "whole-search figure (the path at this batch size is a chain of dependent launches, no single "
-                                 "kernel dominates): bytes = SURVEY 8(d) per query at this Q (weights once per step per batch, "
-                                 "fp32-sized operands) / the forced-tail algorithm's own bytes; traffic not collected for this leg"}}
+                                 "kernel dominates). achieved / frac = the bytes of the forced-tail algorithm actually run (weights "
+                                 "streamed fork_depth + 1 times, fp32-sized operands) x queries/s: the bandwidth the search really "
+                                 "sustains. *_8d_equivalent = SURVEY 8(d)'s bytes for the step-by-step algorithm (all len passes over "
+                                 "the decoder weights, which this path does not make) x queries/s: an equivalent-work ratio, not "
+                                 "a bandwidth. traffic = (2 FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel of one search "
+                                 "(rocprofv3 --pmc, tools/small_batch_pmc.sh), per search"}}
+    return out
+
+
+def secondary_beam1000(E, synth, ctx, model, trie, dims, dev, L):
+    """The reference retrieval script's operating point (full_evaluate_t5seq_aq_encoder.sh:191-199: --topk=1000 --batch_size=1):
+    beam 1000 at one query per search (the script's literal flags) and at the batch the evaluate CLI forms by itself
+    (ripor_amd.evaluate.search_batch_size: the KV cache of the batch in ~60 % of the free HBM). Per batch size: queries/s, ms per
+    search, and an MFMA `roofline` object over the projection GEMMs of one event-timed eager search."""
+    from ripor_amd import evaluate as ev
+    cfg = type("Cfg", (), dict(num_decoder_layers=dims.num_decoder_layers, num_heads=dims.num_heads, d_kv=dims.d_kv, d_model=dims.d_model,
+                               d_ff=dims.d_ff, decoder_vocab_sizes=list(dims.decoder_vocab_sizes)))
+    auto = ev.search_batch_size(cfg, 1, 1000, L, -1, dev)
+    out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams=1000, len={L}", "unit": "queries/s", "cli_automatic_batch": auto}
+    for tag, Q, steps in (("batch1", 1, 6), ("cli_batch", auto, 2)):
+        batches = _query_batches(synth, dims, Q, 2, dev, seed=606 + Q)
+        (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, 1000, L, steps, warmup=1))
+        forks = ctx.last_fork_stats()
+        lanes = 0 < ctx.lane_split() <= Q * 1000 and Q >= 2
+        st = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], 1000, L, use_graph=False))
+        roof = _gemm_roofline(st, PEAK_F16_MFMA_TFLOPS / 3.0, 0.5 if lanes else 1.0, "rpr::gemm_h2_pp_kernel (+ small-tile kernels)",
+                              "algorithmic 2MNK flops of every projection launch of one search / their summed event durations; 3 f16 "
+                              "MFMAs per product -> peak 2500/3 TF/s, halved per launch when the search runs as two CU-masked lanes")
+        out[tag] = {"queries_per_search": Q, "value": Q / dt, "ms_per_search": dt * 1e3, "ms_per_query": dt * 1e3 / Q, "steps": steps,
+                    "forks_last_search": forks, "leftover_fallback_taken": fb, "lanes": 2 if lanes else 1, "roofline": roof,
+                    "select_ms_event_timed": st["select"]["total_ms"], "select_launches": st["select"]["launches"],
+                    "valid_leaves": f"{int((r.row_hi > r.row_lo).sum().item())}/{Q * 1000}"}
+    return out
+
+
+def secondary_rankdata_ref_flags(E, synth, ctx, model, trie, dims, dev, steps=8):
+    """SURVEY §8 row f2 at the reference script's literal flags (full_evaluate_t5seq_aq_encoder.sh:117-147: --topk=100
+    --batch_size=4, max_new_token 4 / 8 / 16): four queries per search, beam 100. `f2` above is the same caller at the batch the
+    CLI forms by itself."""
+    out = {"workload": f"t5-base dims, {trie.N}-doc trie, beams=100, 4 queries per search, prefix search", "unit": "queries/s"}
+    batches = _query_batches(synth, dims, 4, 4, dev, seed=707)
+    for Lp in (4, 8, 16):
+        (dt, r), fb = _leftover_guard(ctx, lambda: _time_search(E, model, trie, batches, 100, Lp, steps, warmup=2))
+        st = _profiled(ctx, lambda: E.search(model, trie, batches[0][0], batches[0][1], 100, Lp, use_graph=False))
+        roof = _gemm_roofline(st, PEAK_F16_MFMA_TFLOPS / 3.0, 1.0, "rpr::gemm_h2_wsplit_kernel / gemm_h2_dma_kernel (400 rows per step)",
+                              "algorithmic 2MNK flops of every projection launch of one search / their summed event durations; 3 f16 "
+                              "MFMAs per product -> peak 2500/3 TF/s; at 400 rows these launches are bound by the weight stream and "
+                              "the launch chain, not by the matrix pipe")
+        out[f"len{Lp}"] = {"value": 4 / dt, "ms_per_search": dt * 1e3, "forks_last_search": ctx.last_fork_stats(),
+                           "leftover_fallback_taken": fb, "launches_per_search": sum(int(v["launches"]) for v in st.values()),
+                           "select_ms_event_timed": st["select"]["total_ms"], "roofline": roof}
     return out
 
 
@@ -558,7 +622,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5, dest="train_steps", help="timed steps of the secondary train legs")
     ap.add_argument("--train-bz", type=int, default=128, dest="train_bz", help="examples per GPU and step of the secondary train legs")
-    ap.add_argument("--secondary", default="train,config4,f2,skew,latency,small_batch,heavy_tail,v1024",
+    ap.add_argument("--secondary", default="train,config4,f2,rankdata_ref_flags,skew,latency,beam1000,small_batch,heavy_tail,v1024",
                     help="comma list of secondary legs to append to the JSON line (train = BASELINE config 5 step, config4 = "
                          "t5-large beam 100, f2 = prefix search at topk 100, skew = clustered trie, latency = one query at beams 10 and "
                          "1000, t5_3b = opt-in: t5-3b dims at beam 10); '' = none. config4 / f2 / skew / latency run at --gpus 1 only, train on every rank (its gradient all-reduce is the RCCL leg)")
@@ -587,11 +651,18 @@ def main():
     backend = os.environ.get("RPR_BENCH_BACKEND", "nccl")   # "nccl" = RCCL on ROCm; tests use gloo on CPU for the launcher
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a job that has a GPU per rank runs over RCCL, whatever the environment says: the scaling bench must never fall to gloo
+        # silently (RPR_BENCH_BACKEND=gloo is the hook of the one-GPU rehearsals in tests/)
+        if backend != "nccl" and torch.cuda.device_count() >= world:
+            raise SystemExit(f"[bench] {torch.cuda.device_count()} GPUs visible for {world} ranks but RPR_BENCH_BACKEND={backend}: "
+                             "refusing to measure the multi-GPU path over anything but RCCL ('nccl')")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    if world > 1 and torch.cuda.device_count() >= world:
+        assert dist.get_backend() == "nccl", dist.get_backend()
     if os.environ.get("RPR_BENCH_LAUNCH_ONLY"):   # launcher self-test (tests/test_dist_gloo.py): rendezvous, report, exit
         if world > 1:
             t = torch.tensor([rank], dtype=torch.int64)
@@ -765,6 +836,7 @@ def main():
             "dtype": "f32" if args.precision == "f32" else "f32 via f16x2-split MFMA (fp32 accumulate)", "data": "synthetic",
             "value_pcie_inclusive": world * Q * K / elapsed_pcie,
             "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": dist.get_backend() if world > 1 else None,
             "gather_bytes_per_rank": int(tok.numel() * tok.element_size() + sc.numel() * sc.element_size()) if world > 1 else 0,
             "gathered_bytes_total": gathered["bytes"], "distinct_shards": distinct_shards,
             "saturated": bool(status_flags & 1), "model_f32_only": bool(model.f32_only),
@@ -1005,7 +1077,7 @@ def main():
             sec[name] = {"error": repr(e)}
         if rank == 0:
             log(f"[bench] secondary {name}: {time.time() - t0:.1f}s -> "
-                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000", "q1", "q8", "q64", "saturated")}))
+                + json.dumps({k: v for k, v in sec[name].items() if k in ("value", "unit", "ms_per_step", "error", "len8", "beams10", "beams1000", "q1", "q8", "q64", "saturated", "batch1", "cli_batch")}))
 
     if "train" in legs:
         leg("train_step", lambda: secondary_train_step(E, synth, ctx, dev, world, rank, bz=args.train_bz, steps=args.train_steps))
@@ -1021,6 +1093,10 @@ def main():
             leg("v1024", lambda: secondary_v1024(E, synth, ctx, dev, args.docs, B, Q))
         if "latency" in legs and args.model == "t5-base":
             leg("latency", lambda: secondary_latency(E, synth, ctx, model, trie, dims, dev, L))
+        if "beam1000" in legs and args.model == "t5-base":
+            leg("beam1000", lambda: secondary_beam1000(E, synth, ctx, model, trie, dims, dev, L))
+        if "rankdata_ref_flags" in legs and args.model == "t5-base":
+            leg("rankdata_ref_flags", lambda: secondary_rankdata_ref_flags(E, synth, ctx, model, trie, dims, dev))
         if "heavy_tail" in legs and args.model == "t5-base":
             leg("heavy_tail", lambda: secondary_heavy_tail(E, synth, ctx, trie, dims, dev, B, L, Q))
         if "small_batch" in legs and args.model == "t5-base":

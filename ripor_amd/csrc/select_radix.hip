@@ -42,6 +42,7 @@ constexpr int RS_PREFIX = RS_D0 + RS_D1 + RS_D2;      // key bits the passes fix
 constexpr int RS_BPB = 8;                             // beams per block of the candidate passes
 constexpr int RS_NARROW = TRIE_NARROW;                // rows of a trie node one wave enumerates directly (one row per lane)
 constexpr int RS_SORT_CAP = 8192;                     // entries of the finish kernel's LDS sort (12 bytes each)
+constexpr int RS_MAX_V = 2048;                        // widest token axis (the step-0 kernel sorts 2 V entries in LDS: 82 KB)
 
 __device__ __forceinline__ unsigned long long key_of_score(double s) {
   s = s + 0.0;                                        // -0.0 -> +0.0: equal doubles have equal keys
@@ -560,7 +561,7 @@ bool select_radix_wanted(int B, int V) {
   return B >= 256;
 }
 
-bool select_radix_fits(int B, int V) { return V % 64 == 0 && V <= 4096 && B >= 1 && B <= RS_SORT_CAP && (long)B * V < (1L << 29); }
+bool select_radix_fits(int B, int V) { return V % 64 == 0 && V <= RS_MAX_V && B >= 1 && B <= RS_SORT_CAP && (long)B * V < (1L << 29); }
 
 // bytes of RadixWs scratch for Q queries (everything but chi, which has the shape of SelectArgs::lb_scratch)
 size_t select_radix_ws_bytes(int Q, int B, int V) {
@@ -590,7 +591,7 @@ static size_t step0_smem(int V) {
 hipError_t init_select_radix_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rs_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SORT_CAP * 12);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(rs_step0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step0_smem(4096));
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(rs_step0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step0_smem(RS_MAX_V));
 }
 
 // zero the histograms and counters of Q queries (once per search; rs_finish_kernel re-zeroes them after every step)

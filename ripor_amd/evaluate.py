@@ -115,7 +115,18 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
         rankdata_from_ranges(qids, lo.tolist(), hi.tolist(), sc.tolist(), perm, smtid_to_docids.docids, max_new_token,
                              apply_log_softmax_for_scores, into=qid_to_rankdata)
 
-    for batch in dataloader:
+    # where the wall clock of the call goes (printed once at the end: host-side share of an end-to-end run, tools/cli_end_to_end.py)
+    import time
+    tm = {"batches": 0, "queries": 0, "tokenize_and_batch_s": 0.0, "enqueue_search_s": 0.0, "wait_and_fanout_s": 0.0, "write_json_s": 0.0}
+    t_call = time.perf_counter()
+    loader_it = iter(dataloader)
+    while True:
+        t0 = time.perf_counter()
+        batch = next(loader_it, None)
+        tm["tokenize_and_batch_s"] += time.perf_counter() - t0
+        if batch is None:
+            break
+        t0 = time.perf_counter()
         with torch.no_grad():
             inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
             outputs = generate_for_constrained_prefix_beam_search(
@@ -125,6 +136,10 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                 apply_log_softmax_for_scores=apply_log_softmax_for_scores,
                 defer_status=copier is not None)   # the side-stream path checks the guards in finish(), one batch later
         batch_qids = batch["id"].cpu().tolist()
+        tm["enqueue_search_s"] += time.perf_counter() - t0
+        tm["batches"] += 1
+        tm["queries"] += len(batch_qids)
+        t0 = time.perf_counter()
         if gather:
             kept.append((batch["id"].to(outputs.row_lo.device), outputs.row_lo.view(-1, topk), outputs.row_hi.view(-1, topk),
                          outputs.sequences_scores.view(-1, topk)))
@@ -137,6 +152,7 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
             if pending is not None:
                 finish(pending)
             pending = nxt
+            tm["wait_and_fanout_s"] += time.perf_counter() - t0
         else:
             relevant_scores = outputs.sequences_scores.view(-1, topk).cpu().tolist()
             str_smtids = convert_ptsmtids_to_strsmtid(outputs.sequences.view(-1, topk, max_new_token + 1), max_new_token)
@@ -149,7 +165,9 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
                         for docid in smtid_to_docids[smtid]:
                             cur[docid] = rel_score if apply_log_softmax_for_scores else rel_score * max_new_token
     if pending is not None:
+        t0 = time.perf_counter()
         finish(pending)
+        tm["wait_and_fanout_s"] += time.perf_counter() - t0
     if gather:
         gdev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if kept:
@@ -173,8 +191,12 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
         dist.barrier()
         return qid_to_rankdata
     if write:
+        t0 = time.perf_counter()
         with open(os.path.join(out_dir, f"run_{local_rank}.json"), "w") as fout:
             json.dump(qid_to_rankdata, fout)
+        tm["write_json_s"] = time.perf_counter() - t0
+    tm["total_s"] = time.perf_counter() - t_call
+    print("timing constrained_decode_doc: " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}))
     return qid_to_rankdata
 
 
@@ -423,20 +445,27 @@ def t5seq_aq_retrieve_docids(args):
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     local_rank = max(0, int(args.local_rank if args.local_rank >= 0 else os.environ.get("LOCAL_RANK", 0)))
+    import time
+    t0 = time.perf_counter()
     model = T5SeqAQEncoder.from_pretrained(args.pretrained_path)
     model.eval()
     if len(set(model.config.decoder_vocab_sizes)) != 1:
         raise ValueError("not valid decoder_vocab_size")
     max_new_token = args.max_new_token_for_docid
     device = _device_index(local_rank)
+    t1 = time.perf_counter()
     processor, table = load_docid_table(args.docid_to_smtid_path, model.config.decoder_vocab_sizes[0], max_new_token,
                                         device=device)
+    t2 = time.perf_counter()
     if rank == 0:
         print("max_new_token: ", max_new_token)
         os.makedirs(args.out_dir, exist_ok=True)
     tokenizer = AutoTokenizer.from_pretrained(args.pretrained_path)
     model.to(device)
     model.base_model.config.decoding = True
+    if rank == 0:
+        print("timing setup: " + json.dumps({"read_checkpoint_s": round(t1 - t0, 3), "docid_table_and_trie_s": round(t2 - t1, 3),
+                                             "tokenizer_and_weights_to_device_s": round(time.perf_counter() - t2, 3)}))
     for data_dir in _list_flag(args.q_collection_paths):
         coll = QueryCollection(data_dir)
         out_dir = os.path.join(args.out_dir, get_dataset_name(data_dir))

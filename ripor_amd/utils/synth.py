@@ -309,3 +309,17 @@ def make_codes_fast(N: int, L: int, V: int, seed: int = SEED, zipf: Optional[flo
         lv = min(3, L)
         out[:, :lv] = zipf_tokens(f"codes_fast_zipf/{N}x{V}", (N, lv), V, zipf, seed).astype(np.uint16)
     return out
+
+
+def patterned_state_dict(dims: ModelDims) -> Dict[str, np.ndarray]:
+    """A state dict of the checkpoint's tensor names with low-entropy, exactly representable values: element i of tensor
+    `name` = ((crc32(name) % 7) + (i % 11) - 8) / 16. For fixtures that store a checkpoint DIRECTORY (tests/golden/
+    c9_ref_checkpoint.zip, written by the reference's save_pretrained): the zip stays small and a reader can be checked
+    tensor by tensor against the formula."""
+    import zlib
+    out = {}
+    for name, arr in make_state_dict(dims, seed=1).items():
+        n = int(np.prod(arr.shape))
+        v = ((zlib.crc32(name.encode()) % 7) + (np.arange(n, dtype=np.int64) % 11) - 8).astype(np.float32) / 16.0
+        out[name] = v.reshape(arr.shape)
+    return out

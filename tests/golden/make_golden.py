@@ -952,6 +952,52 @@ def make_beam_indices_case(gen, mod, utils, shim, name="c7_beam_indices"):
     print(f"[golden] {name}: {[(k, v.shape) for k, v in out.items()]} -> {path}")
 
 
+def make_checkpoint_case(mod, name="c9_ref_checkpoint"):
+    """A checkpoint DIRECTORY written by the reference's own T5SeqAQEncoder.save_pretrained (t5_generative_retriever.py:850-851:
+    self.base_model.save_pretrained -> HF PreTrainedModel.save_pretrained of the installed transformers), zipped. The model is the
+    smallest the reference's constructor accepts (12 decoder layers x 12 heads -> d_model 768; everything else minimal) with
+    synth.patterned_state_dict values, so the zip is small and the loader under test (ripor_amd T5SeqAQEncoder.from_pretrained)
+    is checked file by file, key by key."""
+    import tempfile
+    import zipfile
+    dims = synth.ModelDims(vocab_size=16, d_model=768, d_kv=2, d_ff=4, num_layers=1, num_decoder_layers=12, num_heads=12,
+                           decoder_vocab_sizes=[64, 64])
+    sd = synth.patterned_state_dict(dims)
+    # transformers 5.x refuses to save tensors that share storage unless the class declares the tie (4.17 wrote both names);
+    # the reference ties the encoder's embedding to `shared` (:90) — declared here in 5.x's format, part of the version shim
+    mod.T5ForDocIDGeneration._tied_weights_keys = {"encoder.embed_tokens.weight": "shared.weight"}
+
+    # ... and 5.x constructs models on the meta device inside from_pretrained, where the reference constructor's
+    # `self.start_token_embed.data = <numpy-backed tensor>` (:121) cannot run: 4.17's from_pretrained (build on the CPU, then
+    # load the weight file) restated for the wrapper's call at :782
+    def from_pretrained_417(cls, path, config=None, **kw):
+        from safetensors.torch import load_file
+        model = cls(config)
+        st = os.path.join(path, "model.safetensors")
+        weights = load_file(st) if os.path.exists(st) else torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        weights.setdefault("encoder.embed_tokens.weight", weights["shared.weight"])
+        missing, unexpected = model.load_state_dict(weights, strict=False)
+        assert not unexpected and all("decoder.embed_tokens" in m for m in missing), (missing, unexpected)
+        return model.eval()
+
+    mod.T5ForDocIDGeneration.from_pretrained = classmethod(from_pretrained_417)
+    base = build_reference_model(mod, dims, sd)
+    with tempfile.TemporaryDirectory() as tmp:
+        first, second = os.path.join(tmp, "a"), os.path.join(tmp, "b")
+        base.save_pretrained(first)                                   # a directory the reference's wrapper can be built from
+        enc = mod.T5SeqAQEncoder.from_pretrained(first, shared_output_input_embeds=False)   # :853-855 -> __init__ :772-784
+        got = enc.base_model.state_dict()
+        for k, v in sd.items():                                       # the reference read back what was written
+            assert torch.equal(got[k].cpu(), torch.from_numpy(v)), k
+        enc.save_pretrained(second)                                   # :850-851
+        files = sorted(os.listdir(second))
+        out = os.path.join(HERE, name + ".zip")
+        with zipfile.ZipFile(out, "w", zipfile.ZIP_DEFLATED, compresslevel=9) as z:
+            for f in files:
+                z.write(os.path.join(second, f), f)
+    print(f"[golden] {name}: {files} -> {os.path.getsize(out)} bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -976,6 +1022,8 @@ def main():
         make_beam_indices_case(gen, mod, utils, shim)
     if not args.only or args.only in ("c8_frontend", "callers"):
         make_frontend_case()
+    if not args.only or args.only in ("c9_ref_checkpoint", "callers"):
+        make_checkpoint_case(mod)
 
 
 if __name__ == "__main__":

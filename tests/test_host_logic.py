@@ -141,6 +141,34 @@ def test_config_and_checkpoint_round_trip(tmp_path):
         T5ForDocIDGeneration(T5forDocIDConfig(num_layers=6, num_heads=8))
 
 
+def test_checkpoint_directory_written_by_the_reference_loads(tmp_path):
+    """tests/golden/c9_ref_checkpoint.zip: the files the reference's own T5SeqAQEncoder.save_pretrained wrote
+    (t5_generative_retriever.py:850-851 -> HF save_pretrained of the installed transformers: config.json + model.safetensors;
+    make_golden.py::make_checkpoint_case) for the smallest model its constructor accepts, with synth.patterned_state_dict
+    values. This repo's from_pretrained must read that directory as it is: every config field the path uses, every tensor of
+    SURVEY 8 row a14 bit for bit, the tied / HF-only tensors ignored."""
+    import zipfile
+    with zipfile.ZipFile(os.path.join(os.path.dirname(__file__), "golden", "c9_ref_checkpoint.zip")) as z:
+        assert sorted(z.namelist()) == ["config.json", "model.safetensors"]
+        z.extractall(str(tmp_path))
+    enc = T5SeqAQEncoder.from_pretrained(str(tmp_path))
+    cfg = enc.config
+    assert (cfg.d_model, cfg.d_kv, cfg.d_ff, cfg.num_layers, cfg.num_decoder_layers, cfg.num_heads, cfg.vocab_size) == (768, 2, 4, 1, 12, 12, 16)
+    assert cfg.decoder_vocab_sizes == [64, 64] and cfg.shared_output_input_embeds is False and cfg.decoding is False
+    assert cfg.feed_forward_proj == "relu" and cfg.scaleup_output_hidden is False
+    dims = synth.ModelDims(vocab_size=16, d_model=768, d_kv=2, d_ff=4, num_layers=1, num_decoder_layers=12, num_heads=12,
+                           decoder_vocab_sizes=[64, 64])
+    want = synth.patterned_state_dict(dims)
+    got = enc.base_model.state_dict()
+    assert set(got) == set(expected_keys(cfg)) == set(want)
+    for k, v in want.items():
+        assert got[k].dtype == torch.float32 and torch.equal(got[k], torch.from_numpy(v)), k
+    # and the directory this repo writes is read back by the same loader with the same tensors
+    enc.save_pretrained(str(tmp_path / "again"))
+    again = T5SeqAQEncoder.from_pretrained(str(tmp_path / "again")).base_model.state_dict()
+    assert all(torch.equal(again[k], got[k]) for k in got)
+
+
 def test_processor_from_reference_dicts_reconstructs_codes():
     codes = synth.make_codes(300, 5, 256, seed=9)
     d2s = synth.codes_to_docid_to_smtid(codes)
