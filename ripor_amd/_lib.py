@@ -9,7 +9,10 @@ import ctypes as C
 import os
 from typing import Optional
 
-LIB_NAME = "libripor_hip.so"
+# RPR_DEV_LIB=1: the development build of the same sources (-DRPR_DEV_SWITCHES: the A/B switches of kernel routes and
+# generations are live, csrc/common.h dev_getenv) — tools/ and the tests that compare kernel variants bit for bit. The
+# product library reads none of those switches.
+LIB_NAME = "libripor_hip_dev.so" if os.environ.get("RPR_DEV_LIB", "0") not in ("", "0") else "libripor_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 (K_GEMM, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_ENC_ATTN, K_RMSNORM, K_SELECT, K_OTHER, K_GEMM_SMALL, K_TAIL_SELF_ATTN, K_FORK,

@@ -134,7 +134,7 @@ void linear(Launcher& L, const LinIn& A, const LinW& W, int M, const LinOut& O, 
     g.row_ssq = A.ssq; g.inv_d_fix = A.inv_d_fix; g.eps = A.eps;
     g.resid_h = O.resid_h; g.r_ps = O.ps; g.ldrh = O.ldh; g.ssq_out = O.ssq_out;
     // timing ablations (results are wrong with any bit set): 1 = no row-sum atomics, 2 = no consumer row scale
-    static const int dbg = [] { const char* e = getenv("RPR_DEBUG_FUSED"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = dev_getenv("RPR_DEBUG_FUSED"); return e ? atoi(e) : 0; }();
     if (dbg & 1) g.ssq_out = nullptr;
     if (dbg & 2) g.row_ssq = nullptr;
     g.sat = L.c->status;
@@ -196,11 +196,7 @@ int alloc_workspace(rpr_ctx* c, const rpr_model* m, int Q, int Lq, int B, int L,
   const size_t depth0 = forks.empty() ? (size_t)L : (size_t)forks[0];   // stage 0 stops at the first fork
   E(w.kcache, nd * depth0 * R * inner * f); E(w.vcache, nd * depth0 * R * inner * f);
   E(w.lb, R * (size_t)m->Vp() * 4 * 2);   // start and end of every child's row range
-  {
-    const int G = select_groups(Q, B, m->Vp(), 256);
-    if (G > 1) E(w.sel_part, R * (size_t)G * 20);
-    if (select_radix_wanted(B, m->Vp())) E(w.sel_rs, select_radix_ws_bytes(Q, B, m->Vp()));
-  }
+  if (select_radix_wanted(B, m->Vp())) E(w.sel_rs, select_radix_ws_bytes(Q, B, m->Vp()));
   for (int i = 0; i < 2; ++i) {
     E(w.score[i], R * 8); E(w.lo[i], R * 4); E(w.hi[i], R * 4);
     E(w.tokens[i], R * (size_t)L * 2); E(w.anc[i], R * (size_t)L * 2);
@@ -472,22 +468,6 @@ void enqueue_steps(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie*
       sa.tap_valid = taps->step_valid ? reinterpret_cast<unsigned long long*>(taps->step_valid) + (size_t)t * ((size_t)R * V / 64) : nullptr;
     }
     if (sel_clk) sa.clk = sel_clk + (size_t)t * 8;
-    // few queries x many beams: G blocks per query + a merge, on the steps whose candidate sets are large — about
-    // B * min(V, docs per depth-t node) valid candidates; narrow steps go through the single block's compact path
-    const int G = (taps || sa.rs.hist) ? 1 : select_groups(sd.Q, B, Vp, 256);
-    if (G > 1 && w.sel_part.p) {
-      double per_node = (double)tr->N;
-      for (int i = 0; i < t && per_node > 1.0; ++i) per_node /= (double)V;
-      const char* fa = getenv("RPR_SELECT_GROUPS_ALL");    // tests: grouped selection on every step
-      const int force_all = fa ? atoi(fa) : 0;
-      if (force_all || (double)B * std::min((double)V, per_node) > 4096.0) {
-        const size_t n = (size_t)sd.Q * B * G;
-        sa.G = G;
-        sa.p_score = P<double>(w.sel_part);
-        sa.p_item = reinterpret_cast<int32_t*>(sa.p_score + n);
-        sa.p_lo = sa.p_item + n; sa.p_hi = sa.p_lo + n;
-      }
-    }
     Ln.run(RPR_K_SELECT, 0, (double)Ma * V * 4 + (double)Ma * 40, [&] { return launch_select(sa, s); });
   }
   Ln.account_live(nullptr, 0);   // the live counter of this stage scales THIS stage's records only (fork, tail, finalize follow)
@@ -649,7 +629,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // debug: RPR_SELECT_CLOCK=1 prints the phase durations of the selection kernel (eager launches only)
   unsigned long long* sel_clk = nullptr;
   {
-    static const bool clk_env = [] { const char* e = getenv("RPR_SELECT_CLOCK"); return e && atoi(e) != 0; }();
+    static const bool clk_env = [] { const char* e = dev_getenv("RPR_SELECT_CLOCK"); return e && atoi(e) != 0; }();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (clk_env && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
         hipMalloc(&sel_clk, (size_t)L * 8 * sizeof(unsigned long long)) == hipSuccess)
@@ -657,7 +637,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   }
   // index of the last attended key + 1 per query: row packing of the encoder and the cross-attention loop bound
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(P<int32_t>(w.mask), P<int32_t>(w.last), Q, Lq, s, c->status + 1); });
-  static const bool packed_env = [] { const char* e = getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
+  static const bool packed_env = [] { const char* e = dev_getenv("RPR_PACKED_ENCODER"); return !(e && atoi(e) == 0); }();
   const bool packed = packed_env && !taps;   // taps return the padded [Q, Lq, d] encoder output
   c->cur_no_row_split = packed ? 1 : 0;   // the packed rows' capacity says nothing about the live rows (reset below, after the cross-K/V product)
   enqueue_encoder(Ln, c, m, Q, Lq, packed);
@@ -692,7 +672,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // position-0 K/V exist in slot 0 only and every beam's ancestry points there. (The reference recomputes
   // the B identical rows; beams 1..B-1 differ only by their -1e9 initial score, generation.py:418-420.)
   // Off when debug taps are requested (they expect [Q*B, V] logits per step) or RPR_STEP0_SHARED=0.
-  static const bool step0_env = [] { const char* e = getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
+  static const bool step0_env = [] { const char* e = dev_getenv("RPR_STEP0_SHARED"); return !(e && atoi(e) == 0); }();
   const bool shared0 = step0_env && !taps && B > 1;
   // Stages: stage 0 (all queries) walks steps [0, forks[0]); at every fork the forced queries get their tail pass and
   // the others are compacted into the next stage, which walks on to the next fork (or to L); finalize ranks whoever is
@@ -700,7 +680,7 @@ void enqueue_search(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_trie
   // Everything after the first fork works on what that fork left over — usually a handful of queries in buffers sized for
   // all of them: those GEMMs are enqueued as large-tile / small-tile pairs gated on the live count (GemmH2Args.small_live)
   struct SmallLive { rpr_ctx* c; ~SmallLive() { c->cur_small_live = 0; } } small_guard{c};
-  static const int small_live_rows = [] { const char* e = getenv("RPR_SMALL_LIVE"); return e ? atoi(e) : 1024; }();
+  static const int small_live_rows = [] { const char* e = dev_getenv("RPR_SMALL_LIVE"); return e ? atoi(e) : 1024; }();
   int t0 = 0;
   for (size_t k = 0; k <= forks.size(); ++k) {
     const int t1 = k < forks.size() ? forks[k] : L;
@@ -853,7 +833,7 @@ int rpr_init(int device, rpr_ctx** out_ctx) {
       if (*p == ',') ++p;
     }
   }
-  if (getenv("RPR_GEMM_TRACE")) {
+  if (dev_getenv("RPR_GEMM_TRACE")) {
     void* p = nullptr;
     if (hipMalloc(&p, 2 << 20) == hipSuccess) { (void)hipMemset(p, 0, 2 << 20); c->trace_buf = (unsigned long long*)p; }
   }
@@ -1373,8 +1353,7 @@ int search_one(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   } else {
     // the per-call debug switches of the selection / ranking kernels are part of the key (tests flip them between calls)
     auto env_int = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-    const unsigned dbg = ((unsigned)(env_int("RPR_SELECT_GROUPS", -1) + 1) & 0x3fu) | (env_int("RPR_SELECT_GROUPS_ALL", 0) ? 0x40u : 0u) |
-                         (env_int("RPR_TAIL_RANK_REPLAY", 0) ? 0x80u : 0u) | ((unsigned)(env_int("RPR_SELECT_RADIX", -1) + 1) << 8);
+    const unsigned dbg = (env_int("RPR_TAIL_RANK_REPLAY", 0) ? 1u : 0u) | ((unsigned)(env_int("RPR_SELECT_RADIX", -1) + 1) << 1);
     GraphKey key{m, tr, Q, Lq, B, L, flags | ((unsigned)c->precision << 16) | (dbg << 20), lane, pack_forks(forks, drop_last)};
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
@@ -1607,19 +1586,19 @@ int rpr_op_linear(rpr_ctx* c, const float* A, const float* W, const float* resid
   linear(Ln, {A, At.as<__half>(), (size_t)M * K, K, 1.0f}, {W, Wt.as<__half>(), N, K}, M, out_f32(C, N, N, residual, relu));
   if (At.p) RPR_HIP(hipStreamSynchronize(s));   // the temporaries are freed when this scope ends
   if (c->trace_buf) {  // dump the stamps of this launch: K/32 tiles x 8 waves x 18 slots (gemm_h2_pp_kernel<.., TRACE>)
-    const char* we = getenv("RPR_GEMM_TRACE_W");
+    const char* we = dev_getenv("RPR_GEMM_TRACE_W");
     const size_t tw = we ? (size_t)atoi(we) : 18;
     const size_t n = (size_t)(K / 32) * 8 * tw;
     std::vector<unsigned long long> hbuf(n);
     RPR_HIP(hipMemcpy(hbuf.data(), c->trace_buf, n * 8, hipMemcpyDeviceToHost));
-    if (FILE* f = fopen(getenv("RPR_GEMM_TRACE"), "w")) {
+    if (FILE* f = fopen(dev_getenv("RPR_GEMM_TRACE"), "w")) {
       for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", hbuf[i], (i % tw == tw - 1) ? '\n' : ' ');
       fclose(f);
     }
     // per-tile wall-clock stamps of block 0 (persistent kernel): start, first K-tile landed, K-loop done, epilogue issued
     std::vector<unsigned long long> tb(4 * 4096);
     RPR_HIP(hipMemcpy(tb.data(), c->trace_buf + 100000, tb.size() * 8, hipMemcpyDeviceToHost));
-    if (FILE* f = fopen((std::string(getenv("RPR_GEMM_TRACE")) + ".tiles").c_str(), "w")) {
+    if (FILE* f = fopen((std::string(dev_getenv("RPR_GEMM_TRACE")) + ".tiles").c_str(), "w")) {
       for (size_t i = 0; i + 3 < tb.size() && tb[i]; i += 4) fprintf(f, "%llu %llu %llu %llu\n", tb[i], tb[i + 1], tb[i + 2], tb[i + 3]);
       fclose(f);
     }

@@ -71,14 +71,11 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
 template <int TK>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // Grouped launch (a.G > 1: few queries with many beams, e.g. the evaluation script's batch 1 x beam 1000): G blocks per
-  // query, block g selects the Bw = a.B best candidates of ITS B = a.B / G beams and writes them, in rank order, to the
-  // partial arrays; select_merge_kernel merges the G sorted lists (top-Bw of the union == top-Bw of all candidates) and
-  // writes the next beam state. Below, B is the number of source beams of this block and Bw the number of winners.
-  const int G = a.G > 1 ? a.G : 1;
-  const int Bw = a.B, B = a.B / G, V = a.V, t = a.t, Lc = a.Lc;
+  // (Many beams per query — the evaluation script's --topk=1000 — go through the radix selection, select_radix.hip; this
+  // kernel is the path of small beams and, from 256 beams on, the single-block reference the radix path is tested against.)
+  const int Bw = a.B, B = a.B, V = a.V, t = a.t, Lc = a.Lc;
   const int Vr = a.Vreal > 0 ? a.Vreal : V;   // real vocab; columns Vr..V-1 of a logits row are padding (zero logits)
-  const int q = blockIdx.x / G, grp = blockIdx.x - q * G;
+  const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.nq_dev && q >= *a.nq_dev) return;   // compacted stage: block-uniform
   const int items = B * V, words = items >> 6;
@@ -97,7 +94,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   float* lsum = lmax + B;                                                // [B] log(sum exp)
   float* slog = lsum + B;                                                // [B*V] logits of the query (a.lds_logits)
 
-  const int r0 = q * Bw + grp * B;          // first source beam row of this block
+  const int r0 = q * B;                     // first beam row of this query
   auto stamp = [&](int k) { if (a.clk && blockIdx.x == 0 && tid == 0) a.clk[k] = wall_clock64(); };
   stamp(0);
   for (int b = tid; b < B; b += 256) {
@@ -486,11 +483,6 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
         nhi = (c + 1 < V) ? lb_q[item + 1] : bhi[b];
       }
     }
-    if (G > 1) {        // partial result of this group, rank order; global candidate index
-      const size_t o = ((size_t)q * G + grp) * Bw + j;
-      a.p_score[o] = wscore[j]; a.p_item[o] = item + grp * items; a.p_lo[o] = nlo; a.p_hi[o] = nhi;
-      continue;
-    }
     const int r = r0 + j;
     a.nxt.score[r] = wscore[j];
     a.nxt.lo[r] = nlo;
@@ -501,7 +493,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     if (a.tap_tokens) a.tap_tokens[r] = c;
     if (a.tap_parent) a.tap_parent[r] = b;
   }
-  for (int i = tid; i < B * t && G == 1; i += 256) {
+  for (int i = tid; i < B * t; i += 256) {
     const int j = i / t, p = i - j * t;
     const int b = widx[j] / V;
     a.nxt.tokens[(size_t)(r0 + j) * ld + p] = a.cur.tokens[(size_t)(r0 + b) * ld + p];
@@ -520,85 +512,9 @@ static size_t select_smem(int Bs, int Bw, int V) {
 
 bool select_fits(int B, int V) { return V % 64 == 0 && select_smem(B, B, V) <= 160 * 1024; }
 
-constexpr int MERGE_MAX = 8192;   // entries of the merge kernel's LDS sort (12 bytes each)
-
-int select_groups(int Q, int B, int V, int cus) {
-  // RPR_SELECT_GROUPS: 0/1 = off, n = force n groups (read per call, so a test can switch it between contexts)
-  const char* env_s = getenv("RPR_SELECT_GROUPS");
-  const int env = env_s ? atoi(env_s) : -1;
-  if (env == 0 || env == 1 || V % 64 != 0) return 1;
-  const size_t sort_bytes = (size_t)256 * SEL_TK_HOST * (sizeof(double) + sizeof(int));
-  auto ok = [&](int g) {
-    return g > 1 && B % g == 0 && (long)g * B <= MERGE_MAX && (long)(B / g) * V >= B && B <= 256 * SEL_TK_HOST &&
-           ((select_smem(B / g, B, V) + 15) & ~(size_t)15) + sort_bytes <= 160 * 1024;
-  };
-  if (env > 1) return ok(env) ? env : 1;
-  if (B < 256) return 1;                     // small beams: the single block is already cheap
-  for (int g : {16, 10, 8, 5, 4, 2})
-    if (ok(g) && (long)Q * g <= 2L * cus) return g;
-  return 1;
-}
-
-// Merge of a grouped selection: one block per query sorts the G rank-ordered partial lists (G * B entries) and writes
-// the next beam state (select_kernel's phase D). Entry order: (score desc, candidate index asc); within a list equal
-// scores are already in index order and the lists cover ascending index ranges, so the position g * B + rank orders
-// ties like the candidate index does.
-__global__ __launch_bounds__(1024) void select_merge_kernel(SelectArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int B = a.B, G = a.G, V = a.V, t = a.t, n = G * B;
-  const int q = blockIdx.x, tid = threadIdx.x;
-  if (a.nq_dev && q >= *a.nq_dev) return;
-  int P2 = 1024;
-  while (P2 < n) P2 <<= 1;
-  double* cs = reinterpret_cast<double*>(smem_raw);   // [P2]
-  int* ci = reinterpret_cast<int*>(cs + P2);          // [P2] position in the partial arrays
-  const size_t p0 = (size_t)q * n;
-  for (int i = tid; i < P2; i += 1024) {
-    cs[i] = i < n ? a.p_score[p0 + i] : -INFINITY;
-    ci[i] = i < n ? i : 0x7fffffff;
-  }
-  __syncthreads();
-  for (int k = 2; k <= P2; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int p = tid; p < P2 / 2; p += 1024) {
-        const int lo_i = 2 * p - (p & (jj - 1));
-        const int hi_i = lo_i + jj;
-        const bool desc = (lo_i & k) == 0;
-        Cand x; x.s = cs[lo_i]; x.item = ci[lo_i];
-        Cand y; y.s = cs[hi_i]; y.item = ci[hi_i];
-        if (better(y, x) == desc) { cs[lo_i] = y.s; ci[lo_i] = y.item; cs[hi_i] = x.s; ci[hi_i] = x.item; }
-      }
-      __syncthreads();
-    }
-  }
-  const int ld = a.cur.ld, r0 = q * B;
-  for (int j = tid; j < B; j += 1024) {
-    const size_t src = p0 + ci[j];
-    const int item = a.p_item[src];
-    const int b = item / V, c = item - b * V;
-    const int r = r0 + j;
-    a.nxt.score[r] = cs[j];
-    a.nxt.lo[r] = a.p_lo[src];
-    a.nxt.hi[r] = a.p_hi[src];
-    a.nxt.tokens[(size_t)r * ld + t] = (uint16_t)c;
-    a.nxt.anc[(size_t)r * ld + t] = (uint16_t)(a.shared0 ? 0 : b);
-    ci[j] = b;                                        // parent slot, for the history copy below
-  }
-  __syncthreads();
-  for (int i = tid; i < B * t; i += 1024) {
-    const int j = i / t, p = i - j * t;
-    const int b = ci[j];
-    a.nxt.tokens[(size_t)(r0 + j) * ld + p] = a.cur.tokens[(size_t)(r0 + b) * ld + p];
-    a.nxt.anc[(size_t)(r0 + j) * ld + p] = a.cur.anc[(size_t)(r0 + b) * ld + p];
-  }
-}
-
 hipError_t init_beam_kernel_attributes() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          MERGE_MAX * 12);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<SEL_TK_HOST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024);
@@ -610,30 +526,20 @@ hipError_t launch_select(const SelectArgs& a_in, hipStream_t s) {
   SelectArgs a = a_in;
   if (a.V % 64 != 0) return hipErrorInvalidValue;
   if (a.rs.hist && select_radix_wanted(a.B, a.V)) return launch_select_radix(a, s);   // many beams: select_radix.hip
-  const int G = a.G > 1 ? a.G : 1;
-  if (G > 1 && (a.B % G != 0 || !a.p_score || !a.p_item || !a.p_lo || !a.p_hi || (long)G * a.B > MERGE_MAX || a.tap_scores ||
-                a.tap_tokens || a.tap_parent || a.tap_valid))
-    return hipErrorInvalidValue;
-  size_t smem = select_smem(a.B / G, a.B, a.V);
+  size_t smem = select_smem(a.B, a.B, a.V);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
   smem = (smem + 15) & ~(size_t)15;
   const size_t sort_bytes = (size_t)256 * SEL_TK_HOST * (sizeof(double) + sizeof(int));
   // measured: B = 100 -> rounds 8.8 ms per search vs sort 10.9 ms; B = 1000 -> rounds 87 ms vs sort 62 ms
   a.sort_lds = (a.B > 256 && a.B <= 256 * SEL_TK_HOST && smem + sort_bytes <= 160 * 1024) ? 1 : 0;
-  if (G > 1 && !a.sort_lds && a.B > 256) return hipErrorInvalidValue;
   a.sort_off = (int)smem;
-  const size_t logits_bytes = (size_t)(a.B / G) * a.V * sizeof(float);
+  const size_t logits_bytes = (size_t)a.B * a.V * sizeof(float);
   // the logits strip sits right behind the fixed carve (slog = lsum + B in the kernel); the sort buffer follows it
   a.lds_logits = (smem + logits_bytes + (a.sort_lds ? sort_bytes : 0) <= 160 * 1024) ? 1 : 0;
   if (a.lds_logits) { smem = (smem + logits_bytes + 15) & ~(size_t)15; a.sort_off = (int)smem; }
   if (a.sort_lds) smem += sort_bytes;
-  if (a.sort_lds) hipLaunchKernelGGL(select_kernel<SEL_TK_HOST>, dim3(a.Q * G), dim3(256), smem, s, a);
-  else hipLaunchKernelGGL(select_kernel<8>, dim3(a.Q * G), dim3(256), smem, s, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || G == 1) return e;
-  int P2 = 1024;
-  while (P2 < G * a.B) P2 <<= 1;
-  hipLaunchKernelGGL(select_merge_kernel, dim3(a.Q), dim3(1024), (size_t)P2 * 12, s, a);
+  if (a.sort_lds) hipLaunchKernelGGL(select_kernel<SEL_TK_HOST>, dim3(a.Q), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(select_kernel<8>, dim3(a.Q), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 

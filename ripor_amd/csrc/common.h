@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/ripor_hip.h"
@@ -14,6 +15,19 @@ constexpr int MAX_LQ = 256;          // encoder tokens per query supported by th
 constexpr int MAX_DEC_LEN = 64;      // decoder positions supported (reference uses 32 or 16)
 constexpr int DKV = 64;              // head dim the fast attention kernels are written for (t5-base/large); d_kv = 128 (t5-3b) runs
                                      // on the generic kernels enc_attn_kernel<128> / dec_attn_kernel<., 128> without the forced tail
+
+// Environment switches. The product library reads a handful (README: precision, forced tail, fork depths, lane split, trie
+// threads, and the three selectors the test-suite compares bit for bit against the default: RPR_SELECT_RADIX,
+// RPR_SELECT_LEVELS, RPR_TAIL_RANK_REPLAY) through getenv. Everything else — A/B switches of kernel routes and generations,
+// tuning constants, debug traces — goes through dev_getenv, which is getenv only in a build with -DRPR_DEV_SWITCHES
+// (ripor_amd/libripor_hip_dev.so: tools/ and the tests that compare kernel variants, loaded with RPR_DEV_LIB=1) and nullptr
+// in the product library: there every such switch is its default and its name is not even in the binary
+// (tests/test_abi.py checks the names the .so carries).
+#ifdef RPR_DEV_SWITCHES
+inline const char* dev_getenv(const char* name) { return getenv(name); }
+#else
+inline const char* dev_getenv(const char*) { return nullptr; }
+#endif
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -333,10 +347,6 @@ struct SelectArgs {
   unsigned long long* tap_valid;                                   // [Q, B*V/64] phase-A child bitmap (bit = beam*V + token)
   unsigned long long* clk;   // debug (RPR_SELECT_CLOCK=1, eager mode): 8 wall-clock stamps of block 0 at the phase boundaries
   const int* nq_dev;         // nullable: live query count on the device; blocks past it exit
-  // grouped launch (few queries x many beams): G blocks per query select among B / G beams each, select_merge_kernel
-  // merges their rank-ordered partial lists [Q, G, B]. G <= 1: one block per query writes the next state itself.
-  int G;
-  double* p_score; int32_t* p_item; int32_t* p_lo; int32_t* p_hi;
 };
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 // radix selection (select_radix.hip): many beams per query — five launches over all the CUs instead of one block per query
@@ -348,8 +358,6 @@ hipError_t init_select_radix_attributes();
 hipError_t launch_select_radix_reset(const RadixWs& w, int Q, hipStream_t s);
 hipError_t launch_select_radix(const SelectArgs& a, hipStream_t s);
 bool select_fits(int B, int V);   // the beam's candidate bitmaps and state fit the 160 KB of LDS
-// number of blocks per query a grouped launch would use for Q queries of B beams (1 = not worth it / not possible)
-int select_groups(int Q, int B, int V, int cus);
 
 struct FinalizeArgs {
   BeamState st;

@@ -195,7 +195,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if ((a.resid && ((a.N & 3) || (a.ldr & 3))) || (a.split_n < a.N && ((a.split_n & 3) || (a.ldo[0] & 3) || (a.ldo[1] & 3) || (a.ldo[2] & 3))) ||
       (a.rm_B && ((a.rm_stride & 3) || (a.rm_slot & 3) || (a.rm_head & 3))))
     return hipErrorInvalidValue;
-  static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int force = [] { const char* e = dev_getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   // 128x128 tiles unless that leaves the 256 CUs with less than ~1.5 blocks each
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool narrow = force ? (force == 64) : (t128 < 384);

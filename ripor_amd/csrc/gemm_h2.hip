@@ -1077,8 +1077,8 @@ static hipError_t launch_wsplit_cfg(const GemmH2Args& k, hipStream_t s) {
 // cfg 0: 32 x 32 (four stages), 1: 64 x 32 (three), 2: 64 x 64 (two).
 struct WsplitChoice { int cfg, ks; double us; long rounds; };
 static WsplitChoice choose_wsplit(int M, int N, int K, int cus, bool can_split, size_t part_cap) {
-  static const double lat_us = [] { const char* e = getenv("RPR_WSPLIT_LAT_US"); return e ? atof(e) : 3.0; }();
-  static const double split_us = [] { const char* e = getenv("RPR_WSPLIT_SPLIT_US"); return e ? atof(e) : 4.5; }();
+  static const double lat_us = [] { const char* e = dev_getenv("RPR_WSPLIT_LAT_US"); return e ? atof(e) : 3.0; }();
+  static const double split_us = [] { const char* e = dev_getenv("RPR_WSPLIT_SPLIT_US"); return e ? atof(e) : 4.5; }();
   const int bm[3] = {32, 64, 64}, bn[3] = {32, 32, 64};
   const double rate_gbs[3] = {48.0, 48.0, 41.0};
   WsplitChoice best{0, 1, 1e30, 1};
@@ -1103,7 +1103,7 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
   const bool full = (a.M % BM == 0) && (a.N % BN == 0) && !a.m_dev;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const dim3 grid(tiles_m * tiles_n, ks), blk(64 * WM * WN);
-  static const int deep_max = [] { const char* e = getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
+  static const int deep_max = [] { const char* e = dev_getenv("RPR_GEMM_DEEP"); return e ? atoi(e) : 128; }();
   if ((tiles_m * tiles_n * ks <= deep_max || BM < 128) && (!a.m_dev || a.live_hi > 0)) {   // fewer tiles than CUs: one block per CU, 3 K-tiles in flight
     if (full)
       hipLaunchKernelGGL((gemm_h2_dma_kernel<BM, BN, WM, WN, true, 4, BF16>), grid, blk, 0, s, a, tiles_m, tiles_n);
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue4_kernel(GemmH2Args g, con
 // splitk_reduce_kernel adds them in split order (bitwise reproducible). Returns hipErrorNotSupported when the shape does
 // not qualify (the caller falls back to the 128x64 split-K route).
 static hipError_t launch_256_splitk(const GemmH2Args& a, hipStream_t s) {
-  static const int on = [] { const char* e = getenv("RPR_GEMM_PP_SPLITK"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* e = dev_getenv("RPR_GEMM_PP_SPLITK"); return e ? atoi(e) : 1; }();
   const int kstep = a.bf16 ? 2 * HBK : HBK;
   if (!on || !a.part || (a.M & 255) || (a.N & 255) || (a.K % kstep) || a.relu || a.out_h || a.row_ssq || a.ssq_out || a.resid_h ||
       a.m_dev || a.rm_B || a.split_n < a.N || (a.ldo[0] & 3) || (a.resid && (a.ldr & 3)))
@@ -1328,8 +1328,8 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   a_in.kernel_cls = RPR_K_GEMM_SMALL;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % HBK != 0 || a.K <= 0 || (a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
-  static const int skinny = [] { const char* e = getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
-  static const int skinny16 = [] { const char* e = getenv("RPR_GEMM_SKINNY16"); return e ? atoi(e) : 1; }();
+  static const int skinny = [] { const char* e = dev_getenv("RPR_GEMM_SKINNY"); return e ? atoi(e) : 352; }();   // max rows (measured per search: 320 rows skinny 66.0 vs split-K route 68.5 ms, 400 rows 95.5 vs 71.8)
+  static const int skinny16 = [] { const char* e = dev_getenv("RPR_GEMM_SKINNY16"); return e ? atoi(e) : 1; }();
   auto launch_skinny = [&](const GemmH2Args& k) {
     if (skinny16 && k.M <= 32 && (k.N & 15) == 0) {   // one query in flight: 16 x 16 tiles, all of K = 768 in flight
       const int tiles_n = k.N / 16;
@@ -1374,7 +1374,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // of a K-tile are issued by the wave that also issues the 64 MFMAs, in series: ~2.2 us per K-tile again. Source kept
     // as tools/gemm_bf16_w128.hip.txt; HISTORY.md.)
     if (a.prefer_pp) {
-      static const int dwk = [] { const char* e = getenv("RPR_TRAIN_DW_TILE"); return e ? atoi(e) : 256; }();   // experiment: 128 / 64
+      static const int dwk = [] { const char* e = dev_getenv("RPR_TRAIN_DW_TILE"); return e ? atoi(e) : 256; }();   // experiment: 128 / 64
       if (dwk == 128) return launch_cfg<128, 128, 2, 2, true>(a, s);
       if (dwk == 64) return launch_cfg<128, 64, 2, 2, true>(a, s);
       a_in.kernel_cls = RPR_K_GEMM;
@@ -1404,11 +1404,11 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
       }
     }
     const long t256b = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    static const int bf_pp = [] { const char* e = getenv("RPR_BF16_PP"); return e ? atoi(e) : 200; }();   // min tiles of 256^2 (0 = never)
+    static const int bf_pp = [] { const char* e = dev_getenv("RPR_BF16_PP"); return e ? atoi(e) : 200; }();   // min tiles of 256^2 (0 = never)
     if (bf_pp > 0 && t256b >= bf_pp) return launch_256(a, s);     // ping-pong 256x256 tiles when they fill the chip
     return t128b < 256 ? launch_cfg<128, 64, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, true>(a, s);
   }
-  static const int force = [] { const char* e = getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int force = [] { const char* e = dev_getenv("RPR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   // 256-tile rounds on the 256 CUs: a launch just over a whole number of rounds (e.g. 288 tiles) leaves most of the
   // chip idle in its last round; the 128-tile kernels quantise finer (measured M = 8192, N = 2304: 135 vs 151 us)
@@ -1424,7 +1424,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // in front of them, profiles/r05x_rowsplit_gemm.txt) + ~6 us for the second launch — is under 0.9 of the rounds the
     // ping-pong kernel alone would need. RPR_GEMM_ROWSPLIT=0: off; =2 (tests): every launch of this route with two or more
     // row tiles is split in the middle.
-    static const int row_split = [] { const char* e = getenv("RPR_GEMM_ROWSPLIT"); return e ? atoi(e) : 1; }();
+    static const int row_split = [] { const char* e = dev_getenv("RPR_GEMM_ROWSPLIT"); return e ? atoi(e) : 1; }();
     const bool split_all = row_split == 2 && a.M > 256;
     if (row_split && (force == 0 || split_all) && !a.prefer_pp && !a.rm_B && a.ksplit <= 1 && !a.trace && a.small_live == 0 && (!a.no_row_split || split_all) &&
         (t256 > cus || split_all)) {
@@ -1436,7 +1436,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
         const double tile_us = 78.0 * a.K / 768.0;
         const double cost_split = (double)rounds + 0.43 * (double)((t128r + cus - 1) / cus) + 6.0 / tile_us;
         if (split_all || cost_split < 0.9 * (double)(rounds + 1)) {
-          static const int log_split = [] { const char* e = getenv("RPR_GEMM_ROWSPLIT_LOG"); return e ? atoi(e) : 0; }();
+          static const int log_split = [] { const char* e = dev_getenv("RPR_GEMM_ROWSPLIT_LOG"); return e ? atoi(e) : 0; }();
           if (log_split) fprintf(stderr, "[rowsplit] M=%d N=%d K=%d: %d rows on 256x256 tiles, %d on 128x128\n", a.M, a.N, a.K, rows_main, m_rest);
           GemmH2Args main_p = a, rest = a;
           main_p.M = rows_main;
@@ -1460,9 +1460,9 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   // most of the per-CU LDS-DMA rate (~25 GB/s) on padding rows, and 32-wide column tiles give 4x the blocks
   // 33 .. ~1500 rows (a handful to ~150 queries in flight, the tail pass of one query, beam 1000 at batch 1): wave-split tiles,
   // shape and K split from choose_wsplit (RPR_WSPLIT_CFG / RPR_WSPLIT_KS force them; RPR_GEMM_WSPLIT_MAX = 0: the routes below)
-  static const int wsplit_max = [] { const char* e = getenv("RPR_GEMM_WSPLIT_MAX"); return e ? atoi(e) : 768; }();
-  static const int wsplit_cfg = [] { const char* e = getenv("RPR_WSPLIT_CFG"); return e ? atoi(e) : -1; }();
-  static const int wsplit_ks = [] { const char* e = getenv("RPR_WSPLIT_KS"); return e ? atoi(e) : 0; }();
+  static const int wsplit_max = [] { const char* e = dev_getenv("RPR_GEMM_WSPLIT_MAX"); return e ? atoi(e) : 1400; }();
+  static const int wsplit_cfg = [] { const char* e = dev_getenv("RPR_WSPLIT_CFG"); return e ? atoi(e) : -1; }();
+  static const int wsplit_ks = [] { const char* e = dev_getenv("RPR_WSPLIT_KS"); return e ? atoi(e) : 0; }();
   if (force == 0 && a.M > 32 && a.M <= wsplit_max) {
     const bool can_split = a.part && a.mid_split && !a.m_dev && (a.N & 63) == 0;
     WsplitChoice ch = choose_wsplit(a.M, a.N, a.K, a.cus > 0 ? a.cus : 256, can_split, a.part_cap);
@@ -1496,11 +1496,11 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
   // A few hundred to a few thousand rows in flight (beam 1000 with one query, beam 100 with a dozen, beam 10 with
   // 40-400): the 128x64 launch has fewer blocks than CUs and each walks all of K alone (24-96 K-tiles at ~1 us).
   // Split K over blockIdx.y into the caller's scratch and run the fused epilogue as its own launch.
-  static const int mid_split = [] { const char* e = getenv("RPR_GEMM_MIDSPLIT"); return e ? atoi(e) : 1; }();
+  static const int mid_split = [] { const char* e = dev_getenv("RPR_GEMM_MIDSPLIT"); return e ? atoi(e) : 1; }();
   if (mid_split && force == 0 && a.part && a.mid_split && !a.m_dev && (a.N & 63) == 0 && a.K >= 512) {
     const long t = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
     const int cus = a.cus > 0 ? a.cus : 256;
-    static const int ks_cap = [] { const char* e = getenv("RPR_GEMM_MIDSPLIT_CAP"); return e ? atoi(e) : 4; }();
+    static const int ks_cap = [] { const char* e = dev_getenv("RPR_GEMM_MIDSPLIT_CAP"); return e ? atoi(e) : 4; }();
     long ks = std::min<long>(std::min<long>((3L * cus / 2 + t - 1) / t, ks_cap), a.K / 128);
     ks = std::min<long>(ks, (long)(a.part_cap / ((size_t)a.M * a.N)));
     const int nkt = a.K / HBK;
@@ -1522,7 +1522,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     }
   }
   // split-K: the caller lent scratch for partial results and the launch is a long reduction into few tiles
-  static const int split_target = [] { const char* e = getenv("RPR_GEMM_SPLITK"); return e ? atoi(e) : 640; }();
+  static const int split_target = [] { const char* e = dev_getenv("RPR_GEMM_SPLITK"); return e ? atoi(e) : 640; }();
   if (a.part && split_target > 0 && a.K >= 2048 && t128 * 2 < split_target && !a.mid_split) {
     const hipError_t e = launch_256_splitk(a, s);
     if (e != hipErrorNotSupported) { if (e == hipSuccess) a_in.kernel_cls = RPR_K_GEMM; return e; }

@@ -136,7 +136,6 @@ struct Workspace {
   DevBuf ids, mask, last, offs, row_src, ex, eh, eqkv, eattn, eff, enc_out, xkv;
   // decoder
   DevBuf x, h, q, attn, ff, logits, kcache, vcache, lb;
-  DevBuf sel_part;        // grouped selection (few queries x many beams): partial winners [Q, G, B] x (f64 + 3 x i32)
   DevBuf sel_rs;          // radix selection (many beams): RadixWs scratch (select_radix_carve)
   // beam state (2 ping-pong buffers)
   DevBuf score[2], lo[2], hi[2], tokens[2], anc[2];

@@ -284,7 +284,7 @@ hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(enc_attn_kernel<128>, dim3(a.Q * a.H), dim3(256), smem, s, a);
     return hipGetLastError();
   }
-  static const bool mfma_off = [] { const char* e = getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  static const bool mfma_off = [] { const char* e = dev_getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (a.mfma && !mfma_off && a.Lq <= 32 && !a.offs && !a.out_h) return launch_train_self_attn_mfma(a, s);
   if (!a.mfma) { hipError_t e; if (launch_enc_attn_mfma_v2(a, s, &e)) return e; }
   hipLaunchKernelGGL(enc_attn_kernel<64>, dim3(a.Q * a.H), dim3(256), enc_attn_smem(a.Lq, 64), s, a);

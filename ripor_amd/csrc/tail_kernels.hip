@@ -1054,13 +1054,13 @@ __global__ __launch_bounds__(256, 4) void step_cross_attn_mfma16_kernel(DecCross
 
 // Which generation of the fp32-MFMA tail attention runs: 1 = direct K / Q loads and V through LDS, 2 = K (and Q) through
 // LDS-DMA, V direct (bit-identical results). RPR_TAIL_ATTN_GEN; tools/tail_attn_probe.hip switches it per launch.
-int g_tail_attn_gen = [] { const char* e = getenv("RPR_TAIL_ATTN_GEN"); return e ? atoi(e) : 2; }();
-int g_tail_attn_opt = [] { const char* e = getenv("RPR_TAIL_ATTN_OPT"); return e ? atoi(e) : 0; }();
-int g_tail_cross_tpw = [] { const char* e = getenv("RPR_TAIL_CROSS_TPW"); return e ? atoi(e) : 0; }();   // 0 = by size
+int g_tail_attn_gen = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_GEN"); return e ? atoi(e) : 2; }();
+int g_tail_attn_opt = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_OPT"); return e ? atoi(e) : 0; }();
+int g_tail_cross_tpw = [] { const char* e = dev_getenv("RPR_TAIL_CROSS_TPW"); return e ? atoi(e) : 0; }();   // 0 = by size
 
 // the search encoder's attention on the MFMA tile (launch_enc_attn asks); false = not taken
 bool launch_enc_attn_mfma_v2(const EncAttnArgs& a, hipStream_t s, hipError_t* err) {
-  static const bool on = [] { const char* e = getenv("RPR_ENC_ATTN_MFMA"); return !e || atoi(e) != 0; }();
+  static const bool on = [] { const char* e = dev_getenv("RPR_ENC_ATTN_MFMA"); return !e || atoi(e) != 0; }();
   const int HB = (a.H + 3) / 4;
   if (!on || g_tail_attn_gen != 2 || a.causal || !a.mask || a.Lq > 32 || a.buckets > 64 || (long)a.Q * HB >= (1l << 31) / HB) return false;
   hipLaunchKernelGGL(enc_attn_mfma_v2_kernel, dim3((unsigned)(a.Q * HB)), dim3(256), 4 * (32 * 64) * sizeof(float), s, a, HB, div_magic(HB));
@@ -1069,7 +1069,7 @@ bool launch_enc_attn_mfma_v2(const EncAttnArgs& a, hipStream_t s, hipError_t* er
 }
 
 hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
-  static const bool off = [] { const char* e = getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  static const bool off = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (off || a.Lq > 64) return launch_dec_cross_attn(a, s);   // long queries: the block kernel (any Lq <= 256)
   const int tiles = (a.B + 31) / 32;
   if (g_tail_attn_gen == 2 && a.Lq <= 32) {
@@ -1104,7 +1104,7 @@ hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
 // tail (measured neutral at beam 10: 4969-4974 vs 4983 queries/s same-box, 10 of a tile's 32 rows are live); 0 = always the
 // block kernel.
 hipError_t launch_step_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
-  static const int mode = [] { const char* e = getenv("RPR_STEP_CROSS_MFMA"); return e ? atoi(e) : 2; }();
+  static const int mode = [] { const char* e = dev_getenv("RPR_STEP_CROSS_MFMA"); return e ? atoi(e) : 2; }();
   const int HB = (a.H + 3) / 4;
   if (a.dkv == 128) return launch_dec_cross_attn(a, s);   // t5-3b heads: the generic kernel
   if (mode == 2 && g_tail_attn_gen == 2 && a.Lq <= 32 && (long)a.B * a.H * DKV < (1l << 29)) {
@@ -1363,11 +1363,11 @@ static size_t tail_self_attn_smem(int L) { return ((size_t)L * 65 + (size_t)L * 
 
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
   if (a.L > MAX_DEC_LEN || a.T < 1 || a.T >= a.L) return hipErrorInvalidValue;
-  static const bool off = [] { const char* e = getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  static const bool off = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (!off) {
     const long waves = (long)a.nseq_cap * a.H;
     const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-    static const int occ = [] { const char* e = getenv("RPR_TAIL_ATTN_OCC"); return e ? atoi(e) : 2; }();
+    static const int occ = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_OCC"); return e ? atoi(e) : 2; }();
     if (g_tail_attn_gen == 2 && a.L <= 32 && a.T <= 8) {
       const int HB = (a.H + 3) / 4;
       const long blocks = (long)a.nseq_cap * HB;

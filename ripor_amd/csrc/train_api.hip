@@ -311,24 +311,24 @@ struct Bwd {
   // stream's hardware queue and the step serialises (bf16 50 ms). The split-K route on ONE side stream does not depend on
   // how the runtime maps streams to queues: it is the default, RPR_TRAIN_DW_SPLITK=0 selects the whole-K route.
   static bool whole_k() {
-    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_SPLITK"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = dev_getenv("RPR_TRAIN_DW_SPLITK"); return e ? atoi(e) : 1; }();
     return v == 0;
   }
   static int side_streams() {   // streams the whole-K products rotate over (the scratch sets always rotate over NSIDE)
-    static const int v = [] { const char* e = getenv("RPR_TRAIN_SIDE_STREAMS"); const int n = e ? atoi(e) : 2;
+    static const int v = [] { const char* e = dev_getenv("RPR_TRAIN_SIDE_STREAMS"); const int n = e ? atoi(e) : 2;
                               return n < 1 ? 1 : (n > TrainWs::NSIDE ? TrainWs::NSIDE : n); }();
     return whole_k() ? v : 1;
   }
   // bf16 mode: the weight gradients of a layer as one grouped launch (gemm_h2_pp_group_kernel); RPR_TRAIN_DW_GROUP=0 selects
   // the per-product routes above. Measured, t5-base bz 128: see DESIGN.md section 9.
   static bool grouped() {
-    static const int v = [] { const char* e = getenv("RPR_TRAIN_DW_GROUP"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = dev_getenv("RPR_TRAIN_DW_GROUP"); return e ? atoi(e) : 1; }();
     return v != 0;
   }
   // enqueue the products collected since the last flush on the side stream; the main stream goes on
   void flush_group() {
     if (w.grp.n == 0 || Ln.err) return;
-    static const bool side_on = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();   // 0: in line on the main stream (diagnostic)
+    static const bool side_on = [] { const char* e = dev_getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();   // 0: in line on the main stream (diagnostic)
     hipStream_t s = Ln.s, side = side_on ? w.side[0] : Ln.s;
     const int gs = w.gset;
     if (hipEventRecord(w.ev_gfork[gs], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_gfork[gs], 0) != hipSuccess) { Ln.err = RPR_ERR_HIP; return; }
@@ -400,7 +400,7 @@ struct Bwd {
       if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_fork[f], 0) != hipSuccess) {
         Ln.err = RPR_ERR_HIP; return;
       }
-      static const bool side_on_b = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
+      static const bool side_on_b = [] { const char* e = dev_getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
       {
         Launcher L2{c, side_on_b ? side : s};
         gemm_bf16(L2, pyt, Mp, pxt, saved_xt ? Ml : Mp, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
@@ -439,7 +439,7 @@ struct Bwd {
       if (hipEventRecord(w.ev_fork[f], s) != hipSuccess || hipStreamWaitEvent(side, w.ev_fork[f], 0) != hipSuccess) {
         Ln.err = RPR_ERR_HIP; return;
       }
-      static const bool side_on = [] { const char* e = getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
+      static const bool side_on = [] { const char* e = dev_getenv("RPR_TRAIN_SIDE"); return !(e && atoi(e) == 0); }();
       {
         Launcher L2{c, side_on ? side : s};
         gemm_planes(L2, {pyt, (size_t)N * Mp, Mp, am}, {pxt, (size_t)K * Mp, Mp, am_x}, dW, K, N, K, Mp, nullptr, 0, &w.part2, whole_k());
@@ -560,7 +560,7 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
   // out = act(norm(x) W^T): in bf16 mode the norm writes the product's bf16 operand and its transposed copy itself
   // (rmsnorm_bf16_T_kernel); otherwise norm into h, then gemm() converts. RPR_TRAIN_NORM_FUSE=0: the two-kernel route.
-  static const bool norm_fuse = [] { const char* e = getenv("RPR_TRAIN_NORM_FUSE"); return !(e && atoi(e) == 0); }();
+  static const bool norm_fuse = [] { const char* e = dev_getenv("RPR_TRAIN_NORM_FUSE"); return !(e && atoi(e) == 0); }();
   auto norm_gemm = [&](const float* x, const float* ln, const float* W, float* C, int rows, int N, int relu, void* save_xt) {
     auto it = w.wc_off.find(W);
     if (norm_fuse && c->precision == RPR_PREC_BF16 && save_xt && it != w.wc_off.end() && w.wc.p && dm <= 1024 && (dm & 63) == 0) {
@@ -890,7 +890,7 @@ int rpr_adamw_step(rpr_ctx* c, rpr_model* m, const float* flat_grads, float* exp
   // not an nn.LayerNorm in that version, so the T5 layer-norm weights DO decay; `relative_attention_bias.weight` is
   // excluded by its name. (Restated from memory of transformers 4.17 — its source is not available offline; the
   // reference's default weight_decay is 0, where the rule is moot.)
-  static const bool per_tensor = [] { const char* e = getenv("RPR_ADAMW_PER_TENSOR"); return e && atoi(e) != 0; }();
+  static const bool per_tensor = [] { const char* e = dev_getenv("RPR_ADAMW_PER_TENSOR"); return e && atoi(e) != 0; }();
   if (per_tensor) {
     for (const auto& p : m->params) {
       const float wd = (p.kind == K_ENC_REL || p.kind == K_DEC_REL) ? 0.0f : weight_decay;

@@ -568,7 +568,7 @@ hipError_t launch_self_attn_bwd(const float* qkv, const float* dO, const int32_t
                                 hipStream_t s) {
   const size_t smem = self_attn_bwd_smem(Ls, buckets);
   if (smem > 160 * 1024 || buckets > 64) return hipErrorInvalidValue;
-  static const bool mfma_off = [] { const char* e = getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
+  static const bool mfma_off = [] { const char* e = dev_getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (Ls <= 32 && !mfma_off) {   // one wave per (sequence, head) on the fp32 matrix cores (tail_kernels.hip)
     const hipError_t e = launch_train_self_attn_bwd_mfma(qkv, dO, mask, rel_bias, bucket, dqkv, dbias_part, S, Ls, H, buckets, causal, s);
     if (e != hipSuccess) return e;

@@ -72,6 +72,26 @@ def test_no_gpu_fails_loudly(lib):
                                                     return_dict_in_generate=True, output_scores=True)
 
 
+def test_environment_variables_the_product_library_reads():
+    """The product library reads eight environment variables (README): the documented knobs and the three selectors the
+    GPU suite compares bit for bit with the default path. Every other switch of the sources (A/B routes, kernel
+    generations, tuning constants, traces) goes through dev_getenv (csrc/common.h), which is compiled out of the product
+    build — its name is not even in the binary. The development build of the same sources carries them all."""
+    import __graft_entry__ as ge
+
+    def names(path):
+        return set(re.findall(rb"RPR_[A-Z][A-Z0-9_]+", open(path, "rb").read()))
+
+    got = {n.decode() for n in names(ge.LIB)}
+    assert got == {"RPR_PRECISION", "RPR_FORCED_TAIL", "RPR_FORK_DEPTHS", "RPR_LANE_MIN_ROWS", "RPR_TRIE_THREADS", "RPR_SELECT_RADIX",
+                   "RPR_SELECT_LEVELS", "RPR_TAIL_RANK_REPLAY"}, sorted(got)
+    dev = {n.decode() for n in names(ge.LIB_DEV)}
+    assert got < dev and len(dev) >= 40, sorted(dev)
+    srcs = b"".join(open(os.path.join(ge.CSRC, f), "rb").read() for f in ge.SOURCES)
+    in_src = {m.decode() for m in re.findall(rb'getenv\("(RPR_[A-Z0-9_]+)"\)', srcs)}
+    assert in_src <= dev, sorted(in_src - dev)
+
+
 def test_product_path_never_imports_oracle():
     """The oracle is test infrastructure: nothing under ripor_amd/ or t5_pretrainer/ may import it."""
     bad = []

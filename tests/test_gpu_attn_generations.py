@@ -1,7 +1,7 @@
 """The second-generation fp32-MFMA attention kernels (tail self / cross attention, search encoder attention;
 ripor_amd/csrc/tail_kernels.hip) against the kernels they replace, through the product path: the same searches in
-subprocesses that differ only in RPR_TAIL_ATTN_GEN / RPR_ENC_ATTN_MFMA / RPR_STEP_CROSS_MFMA (read once, when the library
-loads). The tail kernels issue the same MFMAs in the same order and must give the same bits; the encoder and the step
+subprocesses that load the development build of the library (RPR_DEV_LIB=1) and differ only in RPR_TAIL_ATTN_GEN /
+RPR_ENC_ATTN_MFMA / RPR_STEP_CROSS_MFMA (read once, when the library loads). The tail kernels issue the same MFMAs in the same order and must give the same bits; the encoder and the step
 cross-attention move from VALU sums to MFMA sums (fp32 rounding order changes): same ranked smtids, scores within 1e-5.
 Reference semantics: T5Attention inside t5_pretrainer/modeling/t5_generative_retriever.py (softmax(QK^T + bias) V in fp32)."""
 import os
@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 def _dump(tmp_path, name, beams, L=32, **env):
     out = str(tmp_path / (name + ".npz"))
-    e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), **{k: str(v) for k, v in env.items()})
+    # RPR_DEV_LIB=1: the switches below are development switches, live only in libripor_hip_dev.so (same sources, -DRPR_DEV_SWITCHES)
+    e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), RPR_DEV_LIB="1", **{k: str(v) for k, v in env.items()})
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "attn_gen_dump.py"), out, str(beams), str(L)], cwd=REPO, env=e,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]

@@ -199,7 +199,7 @@ def test_eight_rank_rehearsal_of_the_scaling_bench_and_the_cli(tmp_path):
 @pytest.mark.gpu
 def test_randomised_parity_sweep():
     """tools/fuzz_parity.py, 16 seeded random cases (trie size, length, beams, V, skew, duplicates, log-softmax, explicit forks,
-    grouped selection; the small ones also against the CPU oracle): forced tail == step loop, grouped == single block."""
+    radix selection; the small ones also against the CPU oracle): forced tail == step loop, radix selection == single block."""
     import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_parity.py"), "16", "77"], capture_output=True, text=True,

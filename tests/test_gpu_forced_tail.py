@@ -311,10 +311,9 @@ def test_rank_replay_path_equals_single_ranking_pass(E, monkeypatch):
         assert torch.equal(a.row_lo, b.row_lo) and torch.equal(a.row_hi, b.row_hi)
 
 
-def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
-    """Beam 512 / 1000 with 2 queries: the radix selection (the default from 256 beams on, select_radix.hip) and the grouped
-    selection it replaces (16 / 8 blocks per query on the wide steps + merge; RPR_SELECT_RADIX=0) return the bits of the
-    single-block kernel, with and without the forced tail; so does grouping forced onto every step."""
+def test_many_beams_few_queries_radix_selection_equals_the_single_block(E, monkeypatch):
+    """Beam 512 / 1000 with 2 queries on a 300 000-doc trie: the radix selection (the default from 256 beams on,
+    select_radix.hip) returns the bits of the single-block select_kernel (RPR_SELECT_RADIX=0), with and without the forced tail."""
     from ripor_amd.utils import synth
     L, V, N = 12, 256, 300_000
     codes = synth.make_codes(N, L, V, seed=9)
@@ -325,20 +324,12 @@ def test_grouped_selection_large_beams_few_queries(E, monkeypatch):
             for ft in (False, True):
                 ctx.set_forced_tail(ft)
                 monkeypatch.setenv("RPR_SELECT_RADIX", "0")
-                monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
-                monkeypatch.delenv("RPR_SELECT_GROUPS_ALL", raising=False)
                 ref = E.search(model, trie, ti, tm, B, L)
-                monkeypatch.delenv("RPR_SELECT_GROUPS")
-                grouped = E.search(model, trie, ti, tm, B, L)
-                monkeypatch.setenv("RPR_SELECT_GROUPS_ALL", "1")
-                every = E.search(model, trie, ti, tm, B, L)
-                monkeypatch.delenv("RPR_SELECT_GROUPS_ALL")
                 monkeypatch.delenv("RPR_SELECT_RADIX")
                 radix = E.search(model, trie, ti, tm, B, L)
                 torch.cuda.synchronize()
-                for r, lab in ((grouped, "grouped"), (every, "grouped on every step"), (radix, "radix (default)")):
-                    assert torch.equal(r.tokens, ref.tokens) and torch.equal(r.scores, ref.scores), (B, ft, lab)
-                    assert torch.equal(r.row_lo, ref.row_lo) and torch.equal(r.row_hi, ref.row_hi), (B, ft, lab)
+                assert torch.equal(radix.tokens, ref.tokens) and torch.equal(radix.scores, ref.scores), (B, ft)
+                assert torch.equal(radix.row_lo, ref.row_lo) and torch.equal(radix.row_hi, ref.row_hi), (B, ft)
     finally:
         ctx.set_forced_tail(True)
 
@@ -349,7 +340,7 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
     position: ties inside the steps) and, in a second model, all-zero codebooks from position 1 on (every candidate under the
     best first token ties, up to the final ranking) force those rules
     through every implementation of them: the step-by-step loop, the forced tail with its single ranking pass (which must
-    detect the ties and replay the steps), the forced replay, and the grouped selection — all must return the same bits."""
+    detect the ties and replay the steps), the forced replay, and the radix selection — all must return the same bits."""
     from ripor_amd.utils import synth
     L, V, N, B = 12, 256, 40_000, 12
     codes = synth.make_codes(N, L, V, seed=21)
@@ -370,10 +361,8 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
         results = {}
         try:
             for name, ft, env in (("plain", False, {}), ("forced", True, {}), ("forced+replay", True, {"RPR_TAIL_RANK_REPLAY": "1"}),
-                                  ("grouped", False, {"RPR_SELECT_GROUPS": "4", "RPR_SELECT_GROUPS_ALL": "1"}),
-                                  ("grouped+forced", True, {"RPR_SELECT_GROUPS": "3", "RPR_SELECT_GROUPS_ALL": "1"}),
                                   ("radix", False, {"RPR_SELECT_RADIX": "1"}), ("radix+forced", True, {"RPR_SELECT_RADIX": "1"})):
-                for k in ("RPR_TAIL_RANK_REPLAY", "RPR_SELECT_GROUPS", "RPR_SELECT_GROUPS_ALL", "RPR_SELECT_RADIX"):
+                for k in ("RPR_TAIL_RANK_REPLAY", "RPR_SELECT_RADIX"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -394,7 +383,7 @@ def test_exact_score_ties_resolve_identically_on_every_path(E, monkeypatch):
         # The step loop takes its logits from the split-precision GEMM, the tail pass from an exact fp32 dot product: with
         # non-zero codebooks the two families agree to ~1e-5, not to the bit, so bits are compared inside a family; with the
         # zero codebooks every tail logit is exactly 0 on both sides and all five paths must agree bit for bit.
-        families = ([("plain", "grouped", "radix"), ("forced", "forced+replay", "grouped+forced", "radix+forced")] if variant == "paired rows"
+        families = ([("plain", "radix"), ("forced", "forced+replay", "radix+forced")] if variant == "paired rows"
                     else [tuple(results)])
         for fam in families:
             base = results[fam[0]]

@@ -349,7 +349,7 @@ def _wsplit_run(env):
     import json
     import subprocess
     import sys
-    e = dict(os.environ, **env)
+    e = dict(os.environ, RPR_DEV_LIB="1", **env)   # development switches: live only in libripor_hip_dev.so
     p = subprocess.run([sys.executable, "-c", _WSPLIT_SCRIPT % REPO], env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -372,37 +372,10 @@ def test_wave_split_gemm_tiles_agree_with_each_other_and_with_fp64():
         for k, v in got.items():
             assert v["err"] < 2e-5 * v["scale"], (cfg, ks, k, v)
     auto = _wsplit_run({})
+    assert auto == _wsplit_run({"RPR_DEV_LIB": "0"}), "the product library differs from the development build on its default route"
     old = _wsplit_run({"RPR_GEMM_WSPLIT_MAX": "0"})
     for k, v in auto.items():
         assert v["err"] < 2e-5 * v["scale"] and old[k]["err"] < 2e-5 * old[k]["scale"], (k, v, old[k])
-
-
-@pytest.mark.parametrize("name", [n for n in golden_names() if "b100" in n])
-def test_grouped_selection_matches_golden(engine, golden_cache, name, monkeypatch):
-    """Few queries x many beams launch select_kernel as G blocks per query + select_merge_kernel (beam_kernels.hip). The
-    beam-100 goldens run it forced on every step (4 and 5 groups of 25 / 20 beams) with and without the forced tail:
-    same bar as the single block, and bit-identical to it (same candidates, same float64 arithmetic, same order)."""
-    g = golden_cache(name)
-    ctx, model, trie = _build(engine, g)
-    monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
-    ref = {}
-    for ft in (False, True):
-        ctx.set_forced_tail(ft)
-        ref[ft] = _run(engine, g, model, trie)
-    try:
-        for G in (4, 5):
-            monkeypatch.setenv("RPR_SELECT_GROUPS", str(G))
-            monkeypatch.setenv("RPR_SELECT_GROUPS_ALL", "1")
-            for ft in (False, True):
-                ctx.set_forced_tail(ft)
-                r = _run(engine, g, model, trie)
-                compare_ranked(g, r.tokens.cpu().numpy(), r.scores.cpu().numpy(), label=f" (select groups {G}, forced tail {ft})")
-                assert torch.equal(r.tokens, ref[ft].tokens) and torch.equal(r.scores, ref[ft].scores)
-                assert torch.equal(r.row_lo, ref[ft].row_lo) and torch.equal(r.row_hi, ref[ft].row_hi)
-            r = _run(engine, g, model, trie, use_graph=False)
-            assert torch.equal(r.tokens, ref[True].tokens) and torch.equal(r.scores, ref[True].scores)
-    finally:
-        ctx.set_forced_tail(True)
 
 
 def test_vocab_sizes_off_the_64_grid(engine):

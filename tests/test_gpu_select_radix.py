@@ -139,7 +139,7 @@ def test_radix_selection_reads_the_child_arrays_of_every_level():
     binary searches) and the single-block kernel return the same bits."""
     got = {}
     for tag, env in (("radix", {"RPR_SELECT_RADIX": "1"}), ("radix, no child arrays", {"RPR_SELECT_RADIX": "1", "RPR_SELECT_LEVELS": "0"}),
-                     ("single block", {"RPR_SELECT_RADIX": "0", "RPR_SELECT_GROUPS": "0"})):
+                     ("single block", {"RPR_SELECT_RADIX": "0"})):
         p = subprocess.run([sys.executable, "-c", _DEEP_SCRIPT % REPO], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=1200)
         assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
@@ -171,7 +171,6 @@ def test_radix_selection_when_whole_codebooks_tie(E, monkeypatch):
             for ft in (False, True):
                 ctx.set_forced_tail(ft)
                 monkeypatch.setenv("RPR_SELECT_RADIX", "0")
-                monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
                 ref = E.search(model, trie, ti, tm, B, L)
                 monkeypatch.setenv("RPR_SELECT_RADIX", "1")
                 got = E.search(model, trie, ti, tm, B, L)
@@ -201,7 +200,6 @@ def test_radix_selection_in_compacted_stages(E, monkeypatch):
     ctx.set_fork_depths([2, 3])
     try:
         monkeypatch.setenv("RPR_SELECT_RADIX", "0")
-        monkeypatch.setenv("RPR_SELECT_GROUPS", "0")
         ref = E.search(model, trie, ti, tm, B, L)
         st_ref = ctx.last_fork_stats()
         monkeypatch.setenv("RPR_SELECT_RADIX", "1")

@@ -6,7 +6,7 @@ raw-logit and log-softmax scores. Every case compares
 
   * the forced tail (automatic depths, then random explicit forks, exact and optimistic mode) with the step-by-step loop:
     same sequences and row ranges outside score near-ties, scores within 0.3e-4;
-  * grouped selection (forced onto every step) with the single-block selection: identical bits;
+  * the radix selection (forced onto every step, RPR_SELECT_RADIX=1) with the single-block selection: identical bits;
   * small cases with the CPU oracle (KV-cached restatement of the reference loop): ranked comparison at 1e-4.
 
 Prints one line per case and a summary; exits non-zero on the first mismatch."""
@@ -86,7 +86,7 @@ for case in range(n_cases):                 # every random draw up front, so tha
     skew, dup, lsm = rng.random() < 0.4, rng.random() < 0.3, rng.random() < 0.3
     seed = rng.randint(1, 10_000)
     shape = rng.random()
-    if shape < 0.08:        # few queries x many beams: automatic grouped selection, 1024-thread tail ranking
+    if shape < 0.08:        # few queries x many beams: 1024-thread tail ranking
         B, Q, N, V = rng.choice([256, 500, 1000]), rng.randint(1, 2), rng.choice([60_000, 300_000]), 256
     elif shape < 0.12:      # >= 10 240 decoder rows: the call runs as two lanes
         B, Q = 10, rng.randint(1030, 1300)
@@ -111,8 +111,7 @@ for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths, wide) in enumerate(param
     kw = dict(apply_log_softmax_for_scores=lsm)
     CASE.update(sd=sd, dims=dims, ids=ids, mask=mask, B=B, L=L, lsm=lsm,
                 pm=lambda codes=codes, V=V: beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V))
-    for k in ("RPR_SELECT_GROUPS", "RPR_SELECT_GROUPS_ALL"):
-        os.environ.pop(k, None)
+    os.environ["RPR_SELECT_RADIX"] = "0"          # the single-block selection first; the radix selection is compared with it below
     ctx.set_fork_depths(None)
     ctx.set_forced_tail(0)
     plain = E.search(model, trie, ti, tm, B, L, **kw)
@@ -129,14 +128,13 @@ for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths, wide) in enumerate(param
         same_as(forced, plain, f"case {case} forks {depths}")
         notes.append(f"forks {depths} -> {[(f['forced'], f['left']) for f in ctx.last_fork_stats()]}")
         ctx.set_fork_depths(None)
-    G = next((g for g in (5, 4, 3, 2) if B % g == 0 and B // g >= 1 and (B // g) * V >= B), None)
-    if G and B >= 4:
-        os.environ["RPR_SELECT_GROUPS"], os.environ["RPR_SELECT_GROUPS_ALL"] = str(G), "1"
+    if True:                                      # every selection on the radix path (select_radix.hip): the single block's bits
+        os.environ["RPR_SELECT_RADIX"] = "1"
         ctx.set_forced_tail(0)
-        grouped = E.search(model, trie, ti, tm, B, L, **kw)
-        same_as(grouped, plain, f"case {case} grouped G={G}", bits=True)
-        notes.append(f"grouped G={G}")
-        os.environ.pop("RPR_SELECT_GROUPS"); os.environ.pop("RPR_SELECT_GROUPS_ALL")
+        radix = E.search(model, trie, ti, tm, B, L, **kw)
+        same_as(radix, plain, f"case {case} radix selection", bits=True)
+        notes.append("radix == single block")
+        os.environ["RPR_SELECT_RADIX"] = "0"
     if Q <= 6 and B <= 10 and N <= 60_000:
         pm = beam_ref.PrefixMaskRef(beam_ref.build_list_smtid_to_nextids(synth.codes_to_docid_to_smtid(codes)), V)
         seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, apply_log_softmax_for_scores=lsm,
@@ -157,4 +155,5 @@ for case, (N, L, V, B, Q, skew, dup, lsm, seed, depths, wide) in enumerate(param
     print(f"case {case:3d}: N={N} L={L} V={V} B={B} Q={Q} skew={int(skew)} dup={int(dup)} logsm={int(lsm)} dkv={dims.d_kv}: " + "; ".join(notes), flush=True)
     del model, trie
 ctx.set_forced_tail(1)
+os.environ.pop("RPR_SELECT_RADIX", None)
 print(f"{n_cases} cases passed ({n_oracle} also against the CPU oracle; {n_excused} queries excused at a pruning margin below {BOUNDARY_TOL})")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # via gpurun: row split of ragged 256-tile launches (launch_gemm_h2, RPR_GEMM_ROWSPLIT) on / off at the row counts where the
 # last round is badly filled, the two parts alone, and the single-query / 64-query searches of the bench
+export RPR_DEV_LIB=1   # the switches below are development switches: libripor_hip_dev.so (same sources, -DRPR_DEV_SWITCHES)
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-rowsplit}; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 for rs in 0 1; do

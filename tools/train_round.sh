@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU: training tests, then the step time in every precision (and the earlier split-K weight-gradient route beside it)
+export RPR_DEV_LIB=1   # the switches below are development switches: libripor_hip_dev.so (same sources, -DRPR_DEV_SWITCHES)
 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -4
 for prec in bf16 f16x2; do
   for legacy in 0 1; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # via gpurun: per-shape launch times of the projection GEMMs at 80 .. 1500 rows, old routes vs wave-split tile shapes
+export RPR_DEV_LIB=1   # the switches below are development switches: libripor_hip_dev.so (same sources, -DRPR_DEV_SWITCHES)
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-wsplit}; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 MS="80 160 280 640 1000 1500"
