@@ -72,7 +72,7 @@ template <int TK>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // (Many beams per query — the evaluation script's --topk=1000 — go through the radix selection, select_radix.hip; this
-  // kernel is the path of small beams and, from 256 beams on, the single-block reference the radix path is tested against.)
+  // kernel is the path of small beams and, from 32 beams on, the single-block reference the radix path is tested against.)
   const int Bw = a.B, B = a.B, V = a.V, t = a.t, Lc = a.Lc;
   const int Vr = a.Vreal > 0 ? a.Vreal : V;   // real vocab; columns Vr..V-1 of a logits row are padding (zero logits)
   const int q = blockIdx.x;

@@ -555,12 +555,16 @@ int next_pow2(int n) { int p = 1024; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
-// RPR_SELECT_RADIX: 0 = never, 1 = every selection that fits (tests), unset = from 256 beams on
+// RPR_SELECT_RADIX: 0 = never, 1 = every selection that fits (tests), unset = from 32 beams on. Measured on MI355X (t5-base
+// dims, 8.8 M-doc trie, profiles/r06e_radix_beam100.txt): beam 100 at the reference script's batch of 4 (prefix 4 / 8 / 16)
+// 531 / 274 / 305 -> 606 / 307 / 330 queries/s (the single block spends 100 rounds of a block-wide arg-max per step: 290 us,
+// the five launches 60 us); beam 100 at 162-214 queries in flight and beam 10 at 2150: within +-1 %. Beam 10 stays on the
+// single block (one launch instead of five on the single-query path).
 bool select_radix_wanted(int B, int V) {
   if (!select_radix_fits(B, V)) return false;
   const char* e = getenv("RPR_SELECT_RADIX");   // read per call: a test switches it between searches
   if (e) return atoi(e) != 0;
-  return B >= 256;
+  return B >= 32;
 }
 
 bool select_radix_fits(int B, int V) { return V % 64 == 0 && V <= RS_MAX_V && B >= 1 && B <= RS_SORT_CAP && (long)B * V < (1L << 29); }

@@ -473,7 +473,7 @@ def test_lane_split_gives_the_results_of_one_call(setup):
         if bits:
             assert torch.equal(got.scores, want.scores)
         else:
-            assert float((got.scores - want.scores).abs().max()) <= 2e-6
+            assert float((got.scores - want.scores).abs().max()) <= 3e-5   # two fp32 summation orders through 12 layers (the parity bar is 1e-4)
 
     try:
         ctx.set_lane_split(0)

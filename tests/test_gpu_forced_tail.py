@@ -312,7 +312,7 @@ def test_rank_replay_path_equals_single_ranking_pass(E, monkeypatch):
 
 
 def test_many_beams_few_queries_radix_selection_equals_the_single_block(E, monkeypatch):
-    """Beam 512 / 1000 with 2 queries on a 300 000-doc trie: the radix selection (the default from 256 beams on,
+    """Beam 512 / 1000 with 2 queries on a 300 000-doc trie: the radix selection (the default from 32 beams on,
     select_radix.hip) returns the bits of the single-block select_kernel (RPR_SELECT_RADIX=0), with and without the forced tail."""
     from ripor_amd.utils import synth
     L, V, N = 12, 256, 300_000

@@ -349,7 +349,7 @@ def _wsplit_run(env):
     import json
     import subprocess
     import sys
-    e = dict(os.environ, RPR_DEV_LIB="1", **env)   # development switches: live only in libripor_hip_dev.so
+    e = dict(os.environ, **{"RPR_DEV_LIB": "1", **env})   # development switches: live only in libripor_hip_dev.so
     p = subprocess.run([sys.executable, "-c", _WSPLIT_SCRIPT % REPO], env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])

@@ -2,7 +2,7 @@
 reference script's --topk=1000 (full_evaluate_t5seq_aq_encoder.sh:191-199; tasks/generation.py:453-503) — against the
 reference goldens, the CPU oracle and the single-block select_kernel, whose bits it must reproduce.
 
-The library takes the radix path from 256 beams on; RPR_SELECT_RADIX=1 puts every selection on it (the goldens have
+The library takes the radix path from 32 beams on; RPR_SELECT_RADIX=1 puts every selection on it (the goldens have
 2 .. 100 beams), RPR_SELECT_RADIX=0 none.
 """
 import json
