@@ -159,6 +159,12 @@ struct GemmH2Args {
   int no_row_split;                        // 1: never split the rows of this launch over two kernels (packed encoder: M is a capacity far above
                                            // the live row count, which only the device knows)
   int kernel_cls;                          // out (host side): profile class of the kernel chosen (RPR_K_GEMM = 256x256 ping-pong, RPR_K_GEMM_SMALL = the others)
+  // bf16 launches on the 256x256 kernel only (training step, round 6): the result leaves the epilogue in the operand formats
+  // of the products that consume it, instead of one conversion launch per consumer reading the fp32 result back —
+  // out_b [M][ldob] bf16 rows, out_bt [N][ldobt] bf16 = the transposed copy (the X^T / dY^T operand of a weight-gradient
+  // product); mask_src [M][ldmask] fp32 (nullable): elements whose mask_src is not positive are written as zero (the ReLU
+  // backward of the feed-forward block). out[0] may then be null (no fp32 result). M % 256 == 0, N % 256 == 0.
+  void* out_b; int ldob; void* out_bt; int ldobt; const float* mask_src; int ldmask;
 };
 
 // f16 has 5 exponent bits: a plane element below 2^-14 is subnormal, so the lo plane of x = hi + lo (|lo| ~ 2^-11 |x|)

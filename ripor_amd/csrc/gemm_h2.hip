@@ -41,7 +41,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // the LDS-transposed epilogue of the tile kernels (defined behind gemm_h2_dma_kernel)
-template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN>
+template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN, bool BOUT = false>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave, int lane, int bm,
                                                 int bn, int wm, int wn, const float* rs_tile, float acc_scale);
 
@@ -295,7 +295,7 @@ void gemm_h2_dma_kernel(GemmH2Args g, int tiles_m, int tiles_n) {
 // One strip (64 rows of a wave's 128 x 64 outputs) of the epilogue below. The strip index is a template parameter: the
 // accumulators are indexed with it, and a strip loop the compiler declines to unroll — it did once the output paths had
 // grown — puts all 128 of them into scratch.
-template <bool FULL, int TM, int TN, int WM, int WN, int strip, int BM = 256, int BN = 256>
+template <bool FULL, int TM, int TN, int WM, int WN, int strip, int BM = 256, int BN = 256, bool BOUT = false>
 __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&acc)[TM][TN], float* stg, int lane, int bm, int bn,
                                                   int wm, int wn, const float* rs_tile, float acc_scale, int Mlim) {
   constexpr int SH = 64, SW = TN * 32;
@@ -450,7 +450,87 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
         }
       }
     };
-    if (g.out_h) {
+    // ---- bf16 outputs (BOUT instantiations = the bf16 256x256 kernel of the training step; GemmH2Args::out_b / out_bt):
+    // the staged rows leave as bf16 rows (8 columns = one 16-byte store per lane) and, after the final values have gone back
+    // into the strip, as the transposed copy: a lane owns one column of a 32-row half of the strip (conflict-free 4-byte LDS
+    // reads, bank = column), packs row pairs and stores 4 x 16 bytes; the two halves complete a column's 128-byte line.
+    auto bf16_path = [&](auto mask_tag) __attribute__((always_inline)) {
+      constexpr bool MASK = decltype(mask_tag)::value;
+      constexpr int LPR = SW / 8, RPI = 64 / LPR, NK = SH / RPI, KB = MASK ? 2 : 4;
+      const int rrow = lane / LPR, rc8 = (lane % LPR) * 8;
+      const int n0 = bn + wn * (BN / WN) + rc8;
+      const float relu_lo = g.relu ? 0.f : -INFINITY;
+      __bf16* ob = reinterpret_cast<__bf16*>(g.out_b);
+      float* of = g.out[0];
+      float4 ma[MASK ? NK : 1], mb[MASK ? NK : 1];
+      if (MASK) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {   // every mask piece of the strip requested before the first store (see planes_path)
+          const float* mp = g.mask_src + (size_t)(mrow0 + k * RPI + rrow) * g.ldmask + n0;
+          ma[k] = *reinterpret_cast<const float4*>(mp);
+          mb[k] = *reinterpret_cast<const float4*>(mp + 4);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < NK; kb += KB) {
+        float4 sa[KB], sb[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow;
+          sa[k] = *reinterpret_cast<const float4*>(stg + rl * SW + rc8);
+          sb[k] = *reinterpret_cast<const float4*>(stg + rl * SW + rc8 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int rl = (kb + k) * RPI + rrow, m = mrow0 + rl;
+          float v[8] = {sa[k].x, sa[k].y, sa[k].z, sa[k].w, sb[k].x, sb[k].y, sb[k].z, sb[k].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * acc_scale, relu_lo);
+          if (MASK) {
+            const float mk[8] = {ma[MASK ? kb + k : 0].x, ma[MASK ? kb + k : 0].y, ma[MASK ? kb + k : 0].z, ma[MASK ? kb + k : 0].w,
+                                 mb[MASK ? kb + k : 0].x, mb[MASK ? kb + k : 0].y, mb[MASK ? kb + k : 0].z, mb[MASK ? kb + k : 0].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+          }
+          if (g.out_bt) {   // the final values back into the strip for the transposed pass
+            *reinterpret_cast<float4*>(stg + rl * SW + rc8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(stg + rl * SW + rc8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+          if (ob) {
+            __bf16 b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[e];
+            *reinterpret_cast<uint4*>(ob + (size_t)m * g.ldob + n0) = *reinterpret_cast<uint4*>(b);
+          }
+          if (of) {
+            *reinterpret_cast<float4*>(of + (size_t)m * g.ldo[0] + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(of + (size_t)m * g.ldo[0] + n0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
+      }
+      if (g.out_bt) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the rewritten strip has landed
+        __builtin_amdgcn_wave_barrier();
+        __bf16* obt = reinterpret_cast<__bf16*>(g.out_bt);
+        const int c = lane & 31, hrow = 32 * (lane >> 5);
+#pragma unroll
+        for (int cc = 0; cc < SW; cc += 32) {
+          float col[32];
+#pragma unroll
+          for (int r = 0; r < 32; ++r) col[r] = stg[(hrow + r) * SW + cc + c];
+          __bf16 b[32];
+#pragma unroll
+          for (int r = 0; r < 32; ++r) b[r] = (__bf16)col[r];
+          __bf16* dst = obt + (size_t)(bn + wn * (BN / WN) + cc + c) * g.ldobt + mrow0 + hrow;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) reinterpret_cast<uint4*>(dst)[j] = reinterpret_cast<const uint4*>(b)[j];
+        }
+      }
+    };
+    if (BOUT && (g.out_b || g.out_bt)) {
+      if (g.mask_src) bf16_path(std::true_type{}); else bf16_path(std::false_type{});
+    } else if (g.out_h) {
       if (g.resid_h) planes_path(std::true_type{}); else planes_path(std::false_type{});
     } else {
       if (g.rm_B) { if (g.resid) fp32_path(std::true_type{}, std::true_type{}); else fp32_path(std::false_type{}, std::true_type{}); }
@@ -460,7 +540,7 @@ __device__ __forceinline__ void h2_epilogue_strip(const GemmH2Args& g, f32x16 (&
     __builtin_amdgcn_wave_barrier();                  // stg is rewritten by the next strip
 }
 
-template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN>
+template <bool FULL, int TM, int TN, int WM, int WN, int BM, int BN, bool BOUT>
 __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&acc)[TM][TN], __half* smem, int wave,
                                                 int lane, int bm, int bn, int wm, int wn, const float* rs_tile,
                                                 float acc_scale) {
@@ -483,8 +563,8 @@ __device__ __forceinline__ void h2_epilogue_256(const GemmH2Args& g, f32x16 (&ac
   const int ncol = lane & 31, rsub = 4 * (lane >> 5);
   static_assert(NS == 1 || NS == 2, "one or two strips of 64 rows per wave");
   (void)ncol; (void)rsub;
-  h2_epilogue_strip<FULL, TM, TN, WM, WN, 0, BM, BN>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
-  if (NS == 2) h2_epilogue_strip<FULL, TM, TN, WM, WN, NS - 1, BM, BN>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
+  h2_epilogue_strip<FULL, TM, TN, WM, WN, 0, BM, BN, BOUT>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
+  if (NS == 2) h2_epilogue_strip<FULL, TM, TN, WM, WN, NS - 1, BM, BN, BOUT>(g, acc, stg, lane, bm, bn, wm, wn, rs_tile, acc_scale, Mlim);
 }
 
 // ---- ping-pong 256x256 variant -------------------------------------------------------------------------
@@ -1367,6 +1447,14 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     if (a.out_h || a.row_ssq || a.ssq_out || a.resid_h || a.m_dev || a.rm_B || (a.K & 63) || (a.N & 3) || (a.ldo[0] & 3) ||
         (a.resid && (a.ldr & 3)) || a.split_n < a.N)
       return hipErrorInvalidValue;                       // (the bf16 kernels' epilogues store 16-byte pieces of ONE fp32 output)
+    if (a.out_b || a.out_bt) {
+      // bf16 operands for the consumers straight from the epilogue (GemmH2Args::out_b): the 256 x 256 kernel's FULL instantiation only
+      if ((a.M & 255) || (a.N & 255) || a.resid || a.ksplit > 1 || (a.out_b && (a.ldob & 7)) || (a.out_bt && ((a.ldobt & 7) || a.ldobt < a.M)) ||
+          (a.mask_src && (a.ldmask & 3)))
+        return hipErrorInvalidValue;
+      a_in.kernel_cls = RPR_K_GEMM;
+      return launch_256(a, s);
+    }
     const long t128b = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     // (A kernel with 128x128 wave tiles — 256x256 block, four waves, one per SIMD, 512 registers: two thirds of the LDS reads
     // per MFMA — was built and measured: 31-34 us per 256x256x768 tile against 23 us for this shape on the 128-row kernel

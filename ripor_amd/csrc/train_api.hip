@@ -46,6 +46,11 @@ struct TrainWs {
   // `grp` while the layer's input-gradient chain is enqueued and go out as ONE launch on the side stream (gtab = the
   // device table the launch reads its argument structs from)
   DevBuf dyT[2], gtab;
+  // bf16 mode, round 6: the feed-forward block's wide intermediate leaves its producing GEMM's epilogue in bf16 (rows here, the
+  // transposed copy in the consumer's X^T / dY^T slot) instead of through a conversion launch: relu(h Wi^T) in the forward
+  // pass, the masked gradient w.r.t. it in the backward pass (GemmH2Args::out_b / out_bt / mask_src)
+  DevBuf bfb;
+  struct Pre { const float* dY = nullptr; const void* py = nullptr; __half* pyt = nullptr; int gset = -1; } pre;   // a dY the producer left converted
   hipEvent_t ev_gfork[2] = {}, ev_gdone[2] = {};
   bool gdone_pending[2] = {};
   GemmGroupArgs grp = {};
@@ -164,13 +169,26 @@ void gemm_planes(Launcher& Ln, const Planes& A, const Planes& B, float* C, int l
 
 // C[M, N] = act(A[M, K] B[N, K]^T) (+ resid): exact fp32 MFMA, or (split-precision mode) f16x2 planes with dynamic scales
 // one bf16 plane per operand, one MFMA per product (RPR_PREC_BF16)
+// bf16 outputs of the epilogue (256 x 256 kernel only; see GemmH2Args::out_b): rows [M][N], transposed [N][ldt], optional mask
+struct BOut { void* rows = nullptr; void* tr = nullptr; int ldt = 0; const float* mask = nullptr; };
+// a product whose result may leave its epilogue as bf16 operands: whole 256 x 256 tiles, and as many of them as send a bf16
+// product to the ping-pong kernel anyway (launch_gemm_h2: 200) — the fusion never changes which kernel computes the product,
+// so the gradients are the conversion launches' bit for bit (RPR_TRAIN_FUSE_FF=0, development builds, selects those).
+// Measured, t5-base bz 128 (profiles/r06f_train_fuse_ab.txt): 23.2 -> 22.6 ms per step; the conversion launches of the
+// feed-forward blocks were 1.8 ms, the two extra output formats cost the 48 producing launches 0.85 ms of epilogue
+// (32 instead of 16 store instructions per lane and strip).
+bool fused_ok(const rpr_ctx* c, int M, int N) {
+  static const bool on = [] { const char* e = dev_getenv("RPR_TRAIN_FUSE_FF"); return !(e && atoi(e) == 0); }();
+  return on && c->precision == RPR_PREC_BF16 && M % 256 == 0 && N % 256 == 0 && (long)(M / 256) * (N / 256) >= 200;
+}
 void gemm_bf16(Launcher& Ln, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const float* resid,
-               int relu, DevBuf* part = nullptr, bool whole_k = false) {
+               int relu, DevBuf* part = nullptr, bool whole_k = false, const BOut* bo = nullptr) {
   GemmH2Args g{};
   g.A = reinterpret_cast<const __half*>(A); g.lda = lda; g.W = reinterpret_cast<const __half*>(B); g.ldw = ldb;
   g.resid = resid; g.ldr = ldc;
   g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = ldc; g.split_n = N;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.bf16 = 1;
+  if (bo) { g.out_b = bo->rows; g.ldob = N; g.out_bt = bo->tr; g.ldobt = bo->ldt; g.mask_src = bo->mask; g.ldmask = N; }
   if (!part) part = &Ln.c->tws->part;
   if (whole_k) g.prefer_pp = 1;
   else { g.part = P<float>(*part); g.part_cap = part->cap / sizeof(float); }
@@ -179,21 +197,24 @@ void gemm_bf16(Launcher& Ln, const void* A, int lda, const void* B, int ldb, flo
 }
 
 // save_xt (bf16 mode): where to leave the transposed copy [K][pad64(M)] (row stride ldT(M)) of A for the weight-gradient product
+// a_ready (bf16 mode): A's bf16 rows — and its transposed copy in save_xt — were written by the epilogue that produced A
 void gemm(Launcher& Ln, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-          const float* resid = nullptr, int relu = 0, void* save_xt = nullptr) {
+          const float* resid = nullptr, int relu = 0, void* save_xt = nullptr, const void* a_ready = nullptr) {
   if (Ln.c->precision == RPR_PREC_BF16) {
     // the reference's bf16 autocast (main.py:152 bf16=args.use_fp16; tasks/trainer.py:229): operands rounded to bf16, fp32
     // accumulation. One conversion pass per operand, no maxima, no second plane.
     TrainWs& w = *Ln.c->tws;
     if (lda != K || ldb != K) { Ln.err = RPR_ERR_INVALID; return; }
     hipStream_t s = Ln.s;
-    if (save_xt) Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_to_bf16_T(A, M, K, lda, pad64(M), save_xt, w.tA.p, s, nullptr, ldT(M)); });
+    const void* ab = a_ready ? a_ready : w.tA.p;
+    if (a_ready) {}
+    else if (save_xt) Ln.run(RPR_K_OTHER, 0, 8.0 * M * K, [&] { return launch_to_bf16_T(A, M, K, lda, pad64(M), save_xt, w.tA.p, s, nullptr, ldT(M)); });
     else Ln.run(RPR_K_OTHER, 0, 6.0 * M * K, [&] { return launch_to_bf16(A, M, K, lda, w.tA.p, s); });
     const void* wb = w.wT.p;
     auto it = w.wc_off.find(B);
     if (it != w.wc_off.end() && w.wc.p) wb = reinterpret_cast<const __half*>(w.wc.p) + it->second;   // converted once per step
     else Ln.run(RPR_K_OTHER, 0, 6.0 * N * K, [&] { return launch_to_bf16(B, N, K, ldb, w.wT.p, s); });
-    gemm_bf16(Ln, w.tA.p, K, wb, K, C, ldc, M, N, K, resid, relu);
+    gemm_bf16(Ln, ab, K, wb, K, C, ldc, M, N, K, resid, relu);
     return;
   }
   if (Ln.c->precision == RPR_PREC_F16X2) {
@@ -348,8 +369,11 @@ struct Bwd {
   // dX[M, K] = dY[M, N] W[N, K]  and  dW[N, K] = dY[M, N]^T X[M, K]  (dX may alias X: X is consumed first)
   // relu_act (bf16 mode only): dY is the gradient w.r.t. relu(.) and relu_act the stored activation; the mask is applied
   // while dY is converted (the caller skips launch_relu_bwd)
+  // fuse_mask (bf16 mode, grouped route): dX is only read by the NEXT dxdw call, as its dY with relu_act = fuse_mask (the
+  // feed-forward block: dX = gradient w.r.t. relu(.), [M, K]); when the shapes allow it the dX product's epilogue writes that
+  // dY's bf16 rows and transposed copy itself (masked), no fp32 dX is written, and the next call finds them in w.pre
   void dxdw(const float* dY, const float* W, const float* X, float* dX, float* dW, int M, int N, int K, const void* saved_xt = nullptr,
-            const float* relu_act = nullptr) {
+            const float* relu_act = nullptr, const float* fuse_mask = nullptr) {
     const int Mp = pad32(M);
     hipStream_t s = Ln.s;
     if (c->precision == RPR_PREC_BF16) {
@@ -360,17 +384,26 @@ struct Bwd {
       const int Ml = ldT(M);
       const size_t need = (((size_t)N * Ml * sizeof(__half)) + 255) & ~(size_t)255;
       const int ptiles = ((N + 255) / 256) * ((K + 255) / 256);
-      if (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && ptiles <= GemmGroupArgs::MAX_TILES &&
+      // a dY the previous call's dX product left converted (rows + transposed copy in this group's set): nothing to convert,
+      // and the group has room (checked when the slot was reserved)
+      const bool pre = w.pre.dY == dY && w.pre.gset == w.gset && grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p;
+      if (w.pre.dY && !pre) { Ln.err = RPR_ERR_INVALID; set_error("dxdw: a pre-converted gradient was not consumed by the next product"); return; }
+      if (!pre && grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && ptiles <= GemmGroupArgs::MAX_TILES &&
           (w.grp.n == 0 || w.grp.K != Mp || w.grp.n >= GemmGroupArgs::MAXP || w.grp_tiles + ptiles > GemmGroupArgs::MAX_TILES ||
            w.dyT_used + need > w.dyT[w.gset].cap))
         flush_group();   // the product does not fit the group being collected: send that one off, start the next
-      if (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && w.dyT_used + need <= w.dyT[w.gset].cap &&
-          ptiles <= GemmGroupArgs::MAX_TILES) {
+      if (pre || (grouped() && saved_xt && wit_g != w.wc_off.end() && w.wcT.p && w.dyT[w.gset].p && w.dyT_used + need <= w.dyT[w.gset].cap &&
+                  ptiles <= GemmGroupArgs::MAX_TILES)) {
         // grouped route: dY^T into this layer's set, the product into the group, dX on the main stream at once
-        void* py = w.tA.p;
-        __half* pyt = reinterpret_cast<__half*>(static_cast<char*>(w.dyT[w.gset].p) + w.dyT_used);
-        w.dyT_used += need;
-        Ln.run(RPR_K_OTHER, 0, (relu_act ? 12.0 : 8.0) * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, py, s, relu_act, Ml); });
+        const void* py = w.tA.p;
+        __half* pyt;
+        if (pre) { py = w.pre.py; pyt = w.pre.pyt; w.pre = TrainWs::Pre{}; }
+        else {
+          pyt = reinterpret_cast<__half*>(static_cast<char*>(w.dyT[w.gset].p) + w.dyT_used);
+          w.dyT_used += need;
+          void* pyw = w.tA.p;
+          Ln.run(RPR_K_OTHER, 0, (relu_act ? 12.0 : 8.0) * M * N, [&] { return launch_to_bf16_T(dY, M, N, N, Mp, pyt, pyw, s, relu_act, Ml); });
+        }
         GemmGroupArgs& gp = w.grp;
         const int i = gp.n++;
         gp.A[i] = pyt; gp.W[i] = reinterpret_cast<const __half*>(saved_xt); gp.out[i] = dW;
@@ -379,6 +412,19 @@ struct Bwd {
         w.grp_flops += 2.0 * N * (double)K * Mp;
         w.grp_bytes += 2.0 * ((double)N * Mp + (double)K * Mp) + 4.0 * (double)N * K;
         const void* pwt = reinterpret_cast<const __half*>(w.wcT.p) + wit_g->second;
+        // the next product (dY = this dX, [M, K]) joins the same group: its dY^T slot is reserved now and this product's
+        // epilogue fills it, with the rows for its dX product beside it
+        const size_t need2 = (((size_t)K * Ml * sizeof(__half)) + 255) & ~(size_t)255;
+        const int ptiles2 = ((K + 255) / 256) * ((N + 255) / 256);    // the next product is dW2[K, N2]; N2 is not known here: bound by this one's N
+        if (fuse_mask && fused_ok(c, M, K) && Mp == M && w.bfb.p && w.bfb.cap >= (size_t)M * K * sizeof(__half) && w.grp.n < GemmGroupArgs::MAXP &&
+            w.grp_tiles + ptiles2 <= GemmGroupArgs::MAX_TILES && w.dyT_used + need2 <= w.dyT[w.gset].cap) {
+          __half* pyt2 = reinterpret_cast<__half*>(static_cast<char*>(w.dyT[w.gset].p) + w.dyT_used);
+          w.dyT_used += need2;
+          const BOut bo{w.bfb.p, pyt2, Ml, fuse_mask};
+          gemm_bf16(Ln, py, N, pwt, N, nullptr, K, M, K, N, nullptr, 0, nullptr, false, &bo);
+          w.pre.dY = dX; w.pre.py = w.bfb.p; w.pre.pyt = pyt2; w.pre.gset = w.gset;
+          return;
+        }
         gemm_bf16(Ln, py, N, pwt, N, dX, K, M, K, N, nullptr, 0);
         return;
       }
@@ -507,6 +553,7 @@ int alloc_train(rpr_ctx* c, const rpr_model* m, const Dims& D) {
       const size_t dec = (3 * dm + dff + 4 * inner) * Rp, enc = (2 * dm + dff + 3 * inner) * Tp, xkv = (size_t)D.xld * Tp;
       const size_t need = std::max(std::max(dec, enc), xkv) * sizeof(__half) + 8 * 256;
       E(w.dyT[0], need); E(w.dyT[1], need);
+      E(w.bfb, rp * dff * sizeof(__half));
       static_assert(GemmGroupArgs::MAXP * sizeof(GemmH2Args) <= GemmGroupArgs::TABLE_BYTES, "argument table");
       E(w.gtab, GemmGroupArgs::SCRATCH_BYTES);
     }
@@ -561,17 +608,24 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
   // out = act(norm(x) W^T): in bf16 mode the norm writes the product's bf16 operand and its transposed copy itself
   // (rmsnorm_bf16_T_kernel); otherwise norm into h, then gemm() converts. RPR_TRAIN_NORM_FUSE=0: the two-kernel route.
   static const bool norm_fuse = [] { const char* e = dev_getenv("RPR_TRAIN_NORM_FUSE"); return !(e && atoi(e) == 0); }();
-  auto norm_gemm = [&](const float* x, const float* ln, const float* W, float* C, int rows, int N, int relu, void* save_xt) {
+  // next_xt: where the NEXT product (the one that reads C) wants C's transposed bf16 copy; when the shapes allow it (fused_ok)
+  // this product's epilogue writes it, and C's bf16 rows into w.bfb: returns those rows (the next gemm()'s a_ready) or null
+  auto norm_gemm = [&](const float* x, const float* ln, const float* W, float* C, int rows, int N, int relu, void* save_xt,
+                       void* next_xt = nullptr) -> const void* {
     auto it = w.wc_off.find(W);
     if (norm_fuse && c->precision == RPR_PREC_BF16 && save_xt && it != w.wc_off.end() && w.wc.p && dm <= 1024 && (dm & 63) == 0) {
       Ln.run(RPR_K_RMSNORM, 0, 8.0 * rows * dm, [&] {
         return launch_rmsnorm_bf16_T(x, ln, rows, dm, D.eps, 1.0f, w.tA.p, save_xt, pad64(rows), ldT(rows), s);
       });
-      gemm_bf16(Ln, w.tA.p, dm, reinterpret_cast<const __half*>(w.wc.p) + it->second, dm, C, N, rows, N, dm, nullptr, relu);
-      return;
+      const bool fuse = next_xt && fused_ok(c, rows, N) && w.bfb.p && w.bfb.cap >= (size_t)rows * N * sizeof(__half) && pad64(rows) == rows;
+      const BOut bo{w.bfb.p, next_xt, ldT(rows), nullptr};
+      gemm_bf16(Ln, w.tA.p, dm, reinterpret_cast<const __half*>(w.wc.p) + it->second, dm, C, N, rows, N, dm, nullptr, relu, nullptr, false,
+                fuse ? &bo : nullptr);
+      return fuse ? w.bfb.p : nullptr;
     }
     norm(x, ln, h, rows);
     gemm(Ln, h, dm, W, dm, C, N, rows, N, dm, nullptr, relu, save_xt);
+    return nullptr;
   };
   Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_mask_lengths(mask, last, D.bz, D.Lq, s, c->status + 1); });
   // ---- encoder over the padded [bz, Lq] layout (padded positions get no gradient: nothing downstream reads them)
@@ -585,8 +639,8 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
                    nullptr, 0, 1};
     Ln.run(RPR_K_ENC_ATTN, 0, 0, [&] { return launch_enc_attn(ea, s); });
     gemm(Ln, a.attn, inner, m->enc_o[i], inner, a.xm, dm, T, dm, inner, a.x, 0, xt.enc(i, XT_O));
-    norm_gemm(a.xm, m->enc_ln1[i], m->enc_wi[i], a.ff, T, dff, 1, xt.enc(i, XT_WI));
-    gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm, 0, xt.enc(i, XT_WO));
+    const void* ffb = norm_gemm(a.xm, m->enc_ln1[i], m->enc_wi[i], a.ff, T, dff, 1, xt.enc(i, XT_WI), xt.enc(i, XT_WO));
+    gemm(Ln, a.ff, dff, m->enc_wo[i], dff, xnext, dm, T, dm, dff, a.xm, 0, xt.enc(i, XT_WO), ffb);
   }
   norm(xe_last, d.enc_final_ln, P<float>(w.enc_out), T);
   gemm(Ln, P<float>(w.enc_out), dm, d.dec_xkv, dm, P<float>(w.xkv), D.xld, T, D.xld, dm, nullptr, 0, xt.xkv());
@@ -607,8 +661,8 @@ void forward(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const Dims& D, const 
     // (the query's 2 L decoder rows as 32-row tiles on the fp32-MFMA kernel of the search tail when Lq <= 64)
     Ln.run(RPR_K_DEC_CROSS_ATTN, 0, 0, [&] { return launch_tail_cross_attn(ca, s); });
     gemm(Ln, a.a1, inner, m->dec_xo[i], inner, a.x2, dm, R, dm, inner, a.x1, 0, xt.dec(i, XT_XO));
-    norm_gemm(a.x2, m->dec_ln2[i], m->dec_wi[i], a.ff, R, dff, 1, xt.dec(i, XT_WI));
-    gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2, 0, xt.dec(i, XT_WO));
+    const void* ffb = norm_gemm(a.x2, m->dec_ln2[i], m->dec_wi[i], a.ff, R, dff, 1, xt.dec(i, XT_WI), xt.dec(i, XT_WO));
+    gemm(Ln, a.ff, dff, m->dec_wo[i], dff, xnext, dm, R, dm, dff, a.x2, 0, xt.dec(i, XT_WO), ffb);
   }
   Ln.run(RPR_K_OTHER, 0, 0, [&] {
     return launch_gold_scores(P<float>(w.x_last), d.dec_final_ln, d.out_embeds, codes, P<float>(w.scores), D.S, D.L, dm, D.V, D.eps,
@@ -658,7 +712,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   const int T = D.T, R = D.R, dm = D.dm, inner = D.inner, dff = D.dff, H = D.H;
   // a backward that aborted on Ln.err leaves collected-but-unflushed products behind: never carry them into this step's
   // gradient buffer
-  w.grp.n = 0; w.grp_tiles = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0;
+  w.grp.n = 0; w.grp_tiles = 0; w.grp_flops = w.grp_bytes = 0; w.dyT_used = 0; w.pre = TrainWs::Pre{};
   Bwd B{Ln, c, w, D};
   const XtSlots xt{c->precision == RPR_PREC_BF16 ? P<__half>(w.xT) : nullptr, XtLayout(D)};
   const bool saved = xt.base != nullptr;   // the normalised inputs are only recomputed for their weight-gradient products
@@ -682,7 +736,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   for (int i = D.nd - 1; i >= 0; --i) {
     DecAct a = dec_act(w, D, i);
     // feed-forward: x3 = x2 + relu(norm(x2) Wi^T) Wo^T
-    B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff, xt.dec(i, XT_WO));
+    B.dxdw(dx, m->dec_wo[i], a.ff, dbig, g(K_DEC_WO, i), R, dm, dff, xt.dec(i, XT_WO), nullptr, bf16 ? a.ff : nullptr);
     if (!bf16) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)R * dff, s); });
     if (!saved) B.norm(a.x2, m->dec_ln2[i], R);
     B.dxdw(dbig, m->dec_wi[i], h, h, g(K_DEC_WI, i), R, dff, dm, xt.dec(i, XT_WI), bf16 ? a.ff : nullptr);     // dh into the (now free) h buffer
@@ -728,7 +782,7 @@ void backward(Launcher& Ln, rpr_ctx* c, rpr_model* m, const Dims& D, const int32
   dx = dxa; dx2 = dxb;
   for (int i = D.ne - 1; i >= 0; --i) {
     EncAct a = enc_act(w, D, i);
-    B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff, xt.enc(i, XT_WO));
+    B.dxdw(dx, m->enc_wo[i], a.ff, dbig, g(K_ENC_WO, i), T, dm, dff, xt.enc(i, XT_WO), nullptr, bf16 ? a.ff : nullptr);
     if (!bf16) Ln.run(RPR_K_OTHER, 0, 0, [&] { return launch_relu_bwd(dbig, a.ff, (size_t)T * dff, s); });
     if (!saved) B.norm(a.xm, m->enc_ln1[i], T);
     B.dxdw(dbig, m->enc_wi[i], h, h, g(K_ENC_WI, i), T, dff, dm, xt.enc(i, XT_WI), bf16 ? a.ff : nullptr);
@@ -778,7 +832,7 @@ void rpr::free_train_ws(rpr_ctx* c) {
   TrainWs& w = *c->tws;
   DevBuf* all[] = {&w.enc_act, &w.dec_act, &w.enc_out, &w.xkv, &w.x_last, &w.scores, &w.margins, &w.dscores, &w.in_idx, &w.out_idx,
                    &w.tok_idx, &w.h, &w.dxa, &w.dxb, &w.dbig, &w.dattn, &w.dxkv, &w.denc, &w.tA, &w.wT, &w.w_part, &w.bias_part,
-                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT, &w.aseg, &w.apref};
+                   &w.fix, &w.gn_part, &w.gn_out, &w.amax, &w.part, &w.part2, &w.wc, &w.wcT, &w.wseg, &w.wpref, &w.xT, &w.aseg, &w.apref, &w.bfb};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < 2; ++i) {
     if (w.dyT[i].p) (void)hipFree(w.dyT[i].p);

@@ -7,6 +7,8 @@ sums of 2 x L fp32 scores of O(10) and enter squared); every per-position score 
 import json
 import os
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 import torch
@@ -600,3 +602,52 @@ def test_bf16_grouped_weight_gradient_launch(M, N, K, n):
         assert not out[i, rows:].any(), "a product wrote past its rows"
     again = ctx.linear_bf16(A, W, n_products=n)
     assert torch.equal(out, again), "grouped bf16 GEMM is not repeatable bitwise"
+
+
+_FUSE_SCRIPT = r"""
+import hashlib, json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from ripor_amd import engine as E
+from ripor_amd.utils import synth
+L, V, bz = 32, 256, 72
+dims = synth.ModelDims(d_model=768, d_kv=64, d_ff=3072, num_layers=2, num_decoder_layers=12, num_heads=12, decoder_vocab_sizes=[V] * L)
+ctx = E.Context.get(0)
+ctx.set_precision("bf16")
+model = E.DeviceModel(ctx, synth.make_state_dict(dims, seed=3), dims)
+state = E.TrainState(model)
+ids, mask = synth.make_queries(bz, vocab_size=dims.vocab_size, seed=5, fixed_len=64)
+codes = synth.make_codes(2 * bz, L, V, seed=5).astype(np.int64).reshape(2, bz, L).transpose(1, 0, 2).copy()
+prefix = [L, 4, 8, 16]
+tp = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/p{k}", (bz,), 30.0) for k in prefix]))
+tn = torch.from_numpy(np.stack([synth.uniform_f32(f"tb/n{k}", (bz,), 30.0) for k in prefix]))
+losses = E.lngknp_backward(model, state, torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(codes).cuda(), tp, tn, prefix)
+torch.cuda.synchronize()
+g = state.grads.cpu().numpy()
+assert np.isfinite(g).all() and float(np.abs(g).max()) > 0
+ctx.profile_reset(); ctx.profile_enable(True)
+E.lngknp_backward(model, state, torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(codes).cuda(), tp, tn, prefix)
+torch.cuda.synchronize()
+st = ctx.profile_get(); ctx.profile_enable(False)
+print("RESULT " + json.dumps({"sha": hashlib.sha256(g.tobytes()).hexdigest(), "losses": [float(x) for x in losses],
+                              "launches": int(sum(v["launches"] for v in st.values()))}))
+"""
+
+
+def test_bf16_feed_forward_operands_from_the_gemm_epilogue_change_nothing():
+    """Round 6: in bf16 mode the feed-forward block's wide intermediate leaves the producing GEMM's epilogue as bf16 rows + the
+    transposed copy its consumers want (forward: relu(h Wi^T); backward: the masked gradient w.r.t. it) when the product fills
+    the 256 x 256 kernel, instead of going through one conversion launch per consumer. Same fp32 values rounded once to bf16
+    either way (and the same kernel computes the product: 4608 rows x 3072 columns = 216 tiles go to the ping-pong kernel in both
+    runs): the gradients must be bit-identical with the fused epilogue and with
+    the conversion launches (RPR_TRAIN_FUSE_FF=0, development build), and the fused run must use fewer launches."""
+    import json
+    import subprocess
+    import sys
+    got = {}
+    for fuse in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", _FUSE_SCRIPT % REPO], env=dict(os.environ, RPR_DEV_LIB="1", RPR_TRAIN_FUSE_FF=fuse),
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        got[fuse] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert got["1"]["sha"] == got["0"]["sha"] and got["1"]["losses"] == got["0"]["losses"]
+    assert got["1"]["launches"] <= got["0"]["launches"] - 2 * 14, (got["1"]["launches"], got["0"]["launches"])   # 14 layers x 2 conversion launches
