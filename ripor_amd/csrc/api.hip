@@ -511,7 +511,7 @@ StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_t
   }
   nv.Qcap = Q; nv.nq_dev = P<int>(nb.cnt); nv.nrows_dev = P<int>(nb.cnt) + 1;
   nv.io = StageIO{P<int32_t>(nb.qmap), P<int32_t>(nb.offs), P<int32_t>(nb.last), P<int32_t>(nb.mask)};
-  nv.kcache = P<float>(nb.kcache); nv.vcache = P<float>(nb.vcache); nv.depth = next_depth;
+  nv.kcache = P<float>(nb.kcache); nv.vcache = P<float>(nb.vcache); nv.depth = next_depth; nv.dkv = sv.dkv;
   for (int i = 0; i < 2; ++i) nv.st[i] = beam_state(nb.score, nb.lo, nb.hi, nb.tokens, nb.anc, i, L);
   Ln.run(RPR_K_FORK, 0, 0, [&] {
     return launch_gather_stage_io(sv.io, StageOut{P<int32_t>(nb.qmap), P<int32_t>(nb.offs), P<int32_t>(nb.last), P<int32_t>(nb.mask)},
@@ -519,7 +519,7 @@ StageView enqueue_fork(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const rpr_t
   });
   Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_compact_beams(st, nv.st[T & 1], P<int32_t>(nb.src), nv.nq_dev, Q, B, T, s); });
   KvCopyArgs kc{sv.kcache, sv.vcache, nv.kcache, nv.vcache, sv.kv_layer(B, inner), sv.kv_q(B, inner), sv.kv_h(B),
-                nv.kv_layer(B, inner), nv.kv_q(B, inner), nv.kv_h(B), P<int32_t>(nb.src), nv.nq_dev, Q, nd, H, T * B * DKV};
+                nv.kv_layer(B, inner), nv.kv_q(B, inner), nv.kv_h(B), P<int32_t>(nb.src), nv.nq_dev, Q, nd, H, T * B * sv.dkv};
   Ln.run(RPR_K_FORK, 0, 0, [&] { return launch_kv_copy(kc, s); });
   return nv;
 }
@@ -557,16 +557,17 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
     return launch_tail_embed(d.in_embeds, P<uint16_t>(tb.tokens), x, R, nrows_dev, T, L, dm, V, s,
                              h2 ? XOut{xs.x_h, ps_d, xs.ssq, c->status} : XOut{});
   });
-  const size_t kv_pos = (size_t)B * DKV;
+  const size_t kv_pos = (size_t)B * sv.dkv;
   for (int i = 0; i < nd; ++i) {
     if (!h2) norm(m->dec_ln0[i]);
     linear(Ln, h2 ? xs.in(3 * i) : in_h, {m->dec_qkv[i], m->h_dec_qkv[i], 3 * inner, dm}, R, out_f32(qkv, 3 * inner, 3 * inner), nrows_dev, Ra);
     {
       const size_t ls = sv.kv_layer(B, inner);
-      TailSelfAttnArgs a{qkv, sv.kcache + i * ls, sv.vcache + i * ls, sv.kv_q(B, inner), sv.kv_h(B), kv_pos, (size_t)DKV,
+      TailSelfAttnArgs a{qkv, sv.kcache + i * ls, sv.vcache + i * ls, sv.kv_q(B, inner), sv.kv_h(B), kv_pos, (size_t)sv.dkv,
                          sv.st[T & 1].anc, L, P<int32_t>(tb.flist), nseq_dev, d.dec_rel_bias, m->dec_bucket, attn,
                          h2 ? attn_h : nullptr, ps_i, c->status, S, B, H, T, L};
-      Ln.run(RPR_K_TAIL_SELF_ATTN, 2.0 * Ra * H * (double)(L + T + 1) * DKV, 4.0 * ((double)Ra * 4 * inner + 2.0 * (Ra / Lt) * (double)T * inner),
+      a.dkv = d.d_kv;
+      Ln.run(RPR_K_TAIL_SELF_ATTN, 2.0 * Ra * H * (double)(L + T + 1) * sv.dkv, 4.0 * ((double)Ra * 4 * inner + 2.0 * (Ra / Lt) * (double)T * inner),
              [&] { return launch_tail_self_attn(a, s); });
     }
     linear(Ln, in_attn, {m->dec_o[i], m->h_dec_o[i], dm, inner}, R, h2 ? xs.out(3 * i + 1) : out_f32(x, dm, dm, x), nrows_dev, Ra);
@@ -576,7 +577,8 @@ void enqueue_tail(Launcher& Ln, rpr_ctx* c, const rpr_model* m, const SearchDims
       const float* xk = P<float>(w.xkv) + (size_t)i * 2 * inner;
       DecCrossAttnArgs a{qb, xk, xk + inner, xld, P<int32_t>(tb.mask), attn, Q, B * Lt, H, Lq, h2 ? attn_h : nullptr, ps_i,
                          P<int32_t>(tb.last), P<int32_t>(tb.offs), 0, c->status, nf_dev};
-      Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ra * H * (double)Lq * DKV, 4.0 * ((double)Ra * inner * 2 + 2.0 * (Ra / (B * Lt)) * (double)Lq * inner),
+      a.dkv = d.d_kv;
+      Ln.run(RPR_K_DEC_CROSS_ATTN, 4.0 * Ra * H * (double)Lq * sv.dkv, 4.0 * ((double)Ra * inner * 2 + 2.0 * (Ra / (B * Lt)) * (double)Lq * inner),
              [&] { return launch_tail_cross_attn(a, s); });
     }
     linear(Ln, in_attn, {m->dec_xo[i], m->h_dec_xo[i], dm, inner}, R, h2 ? xs.out(3 * i + 2) : out_f32(x, dm, dm, x), nrows_dev, Ra);
@@ -1275,7 +1277,6 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   std::vector<int> forks;
   *drop_last = false;
   if (!c->forced_tail || taps || L < 3 || !std::isfinite(m->logit_bound)) return forks;
-  if (m->d.d_kv != DKV) return forks;   // 128-dim heads (t5-3b): the tail kernels are written for 64; the plain loop runs
   const double per_step = 2.0 * (double)m->logit_bound + ((flags & RPR_FLAG_LOG_SOFTMAX) ? log((double)m->d.V) : 0.0);
   if (1e8 - L * per_step <= 1e7) return forks;   // logits too large for the masked-candidate proof
   if (c->n_fork_override >= 0) {

@@ -444,6 +444,7 @@ struct TailSelfAttnArgs {
   const float* rel_bias; const int32_t* bucket;
   float* out; __half* out_h; size_t o_ps; unsigned int* sat;
   int nseq_cap, B, H, T, L;
+  int dkv = 0;               // head dim (0 = 64); 128 (t5-3b) takes the VALU kernel tail_self_attn_kernel<128>
 };
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s);
 // cross-attention of the tail rows (a.B = rows per query): fp32-MFMA tiles for Lq <= 64, else the block kernel

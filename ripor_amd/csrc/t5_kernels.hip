@@ -709,12 +709,19 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a_in, hipStream_t s) {
   if (a.Lq > MAX_LQ) return hipErrorInvalidValue;
   if (a.dkv == 128) {   // t5-3b heads
     // the block kernel (K / V of the (query, head) staged once for all beams) when everything fits one block's LDS ...
-    const size_t smem128 = ((size_t)a.Lq * (132 + 128) + (size_t)a.B * (132 + 2 * (a.Lq + 1)) + 4) * sizeof(float);
-    if (smem128 <= 160 * 1024) {
-      a.bchunk = 0;
-      hipLaunchKernelGGL(dec_cross_attn_block_kernel<128>, dim3(a.Q * a.H, 1), dim3(256), smem128, s, a);
+    auto smem128 = [&](int nb) { return ((size_t)a.Lq * (132 + 128) + (size_t)nb * (132 + 2 * (a.Lq + 1)) + 4) * sizeof(float); };
+    a.bchunk = 0;
+    int chunks128 = 1;
+    if (smem128(a.B) > 96 * 1024) {   // many rows per query (the tail pass: beams x remaining positions): chunks of the rows over blockIdx.y
+      a.bchunk = 64;
+      while (a.bchunk > 1 && smem128(a.bchunk) > 96 * 1024) a.bchunk >>= 1;
+      chunks128 = (a.B + a.bchunk - 1) / a.bchunk;
+    }
+    if (smem128(a.bchunk ? a.bchunk : a.B) <= 160 * 1024) {
+      hipLaunchKernelGGL(dec_cross_attn_block_kernel<128>, dim3(a.Q * a.H, chunks128), dim3(256), smem128(a.bchunk ? a.bchunk : a.B), s, a);
       return hipGetLastError();
     }
+    a.bchunk = 0;
     // ... else one wave per (beam, head) over the query's encoder K / V rows (unattended keys masked)
     const long items = (long)a.Q * a.B * a.H;
     hipLaunchKernelGGL((dec_attn_kernel<false, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a.q, a.xk, a.xv,

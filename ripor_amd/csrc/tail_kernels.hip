@@ -206,23 +206,26 @@ hipError_t launch_tail_embed(const float* in_embeds, const uint16_t* tokens, flo
 // positions T + wave, T + wave + 4, ...: lane j scores key j (L <= 64), the q row is broadcast with v_readlane,
 // softmax across the wave, P.V with lane = output dim. Arithmetic of dec_self_attn_fast_kernel / enc_attn_kernel
 // (unscaled scores + unidirectional relative bias, fp32 softmax normalised before P.V).
+// D = head dim: 64, or 128 (t5-3b; two q / output values per lane) — the fp32-MFMA tiles below are written for 64.
+template <int D>
 __global__ __launch_bounds__(256) void tail_self_attn_kernel(TailSelfAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * DKV, ld = 3 * inner;
+  constexpr int NV = D / 64;           // q / output values per lane
+  const int H = a.H, L = a.L, T = a.T, Lt = L - T, inner = H * D, ld = 3 * inner;
   const int seq = blockIdx.x / H, h = blockIdx.x - seq * H;
   if (seq >= *a.nseq_dev) return;
-  float* Ks = smem;                    // [L][65]
-  float* Vs = smem + (size_t)L * 65;   // [L][64]
-  float* Ps = Vs + (size_t)L * 64;     // [4][64]
-  float* Bs = Ps + 4 * 64;             // [buckets <= 64]
+  float* Ks = smem;                          // [L][D + 1]
+  float* Vs = smem + (size_t)L * (D + 1);    // [L][D]
+  float* Ps = Vs + (size_t)L * D;            // [4][64]
+  float* Bs = Ps + 4 * 64;                   // [buckets <= 64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = seq / a.B, b = seq - fi * a.B;
   const int qi = a.flist[fi];
   const uint16_t* ancr = a.anc + ((size_t)qi * a.B + b) * a.anc_ld;
   const size_t cbase = (size_t)qi * a.q_stride + (size_t)h * a.h_stride;
-  const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * DKV;
-  for (int i = tid; i < L * 16; i += 256) {
-    const int j = i >> 4, c = (i & 15) * 4;
+  const float* tbase = a.qkv + (size_t)seq * Lt * ld + h * D;
+  for (int i = tid; i < L * (D / 4); i += 256) {
+    const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
     float4 kv, vv;
     if (j < T) {
       const size_t off = cbase + (size_t)j * a.pos_stride + (size_t)ancr[j] * a.slot_stride + c;
@@ -233,39 +236,50 @@ __global__ __launch_bounds__(256) void tail_self_attn_kernel(TailSelfAttnArgs a)
       kv = *reinterpret_cast<const float4*>(r + inner);
       vv = *reinterpret_cast<const float4*>(r + 2 * inner);
     }
-    float* kd = Ks + j * 65 + c;
+    float* kd = Ks + j * (D + 1) + c;
     kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<float4*>(Vs + j * 64 + c) = vv;
+    *reinterpret_cast<float4*>(Vs + j * D + c) = vv;
   }
   if (tid < 64) Bs[tid] = a.rel_bias[a.bucket[tid] * H + h];   // bias of distance n = i - j (bucket table: MAX_DEC_LEN = 64 entries)
   __syncthreads();
   float* P = Ps + wave * 64;
   for (int i = T + wave; i < L; i += 4) {
-    const float qv = tbase[(size_t)(i - T) * ld + lane];  // lane d holds q_i[d]
+    float qv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) qv[v] = tbase[(size_t)(i - T) * ld + 64 * v + lane];  // lane d holds q_i[d], q_i[64 + d]
     const int jc = lane <= i ? lane : i;
-    const float* kr = Ks + jc * 65;
+    const float* kr = Ks + jc * (D + 1);
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < DKV; ++d) {
-      const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), d));
-      acc = fmaf(qd, kr[d], acc);
-    }
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int d = 0; d < 64; ++d) {
+        const float qd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[v]), d));
+        acc = fmaf(qd, kr[64 * v + d], acc);
+      }
     const float sc = lane <= i ? acc + Bs[i - lane] : -INFINITY;
     const float mx = wave_max(sc);
     const float e = (sc == -INFINITY) ? 0.f : expf(sc - mx);
     const float sum = wave_sum(e);
     P[lane] = e / sum;
     __builtin_amdgcn_wave_barrier();
-    float o = 0.f;
-    for (int j = 0; j <= i; ++j) o = fmaf(P[j], Vs[j * 64 + lane], o);
-    const size_t oidx = ((size_t)seq * Lt + (i - T)) * inner + h * DKV + lane;
-    if (a.out_h) {
-      __half hi, lo;
-      split_f16(o * A_PLANE_SCALE, hi, lo, a.sat);
-      a.out_h[oidx] = hi;
-      a.out_h[a.o_ps + oidx] = lo;
-    } else {
-      a.out[oidx] = o;
+    float o[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) o[v] = 0.f;
+    for (int j = 0; j <= i; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) o[v] = fmaf(P[j], Vs[j * D + 64 * v + lane], o[v]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const size_t oidx = ((size_t)seq * Lt + (i - T)) * inner + h * D + 64 * v + lane;
+      if (a.out_h) {
+        __half hi, lo;
+        split_f16(o[v] * A_PLANE_SCALE, hi, lo, a.sat);
+        a.out_h[oidx] = hi;
+        a.out_h[a.o_ps + oidx] = lo;
+      } else {
+        a.out[oidx] = o[v];
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1070,7 +1084,7 @@ bool launch_enc_attn_mfma_v2(const EncAttnArgs& a, hipStream_t s, hipError_t* er
 
 hipError_t launch_tail_cross_attn(const DecCrossAttnArgs& a, hipStream_t s) {
   static const bool off = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
-  if (off || a.Lq > 64) return launch_dec_cross_attn(a, s);   // long queries: the block kernel (any Lq <= 256)
+  if (off || a.Lq > 64 || a.dkv == 128) return launch_dec_cross_attn(a, s);   // long queries, 128-dim heads: the block kernel (any Lq <= 256)
   const int tiles = (a.B + 31) / 32;
   if (g_tail_attn_gen == 2 && a.Lq <= 32) {
     // tiles per wave: many tiles -> a wave keeps K / V for nine of them (fewer, longer waves: better on a lane's half of
@@ -1359,10 +1373,14 @@ hipError_t launch_train_self_attn_bwd_mfma(const float* qkv, const float* dO, co
   return hipGetLastError();
 }
 
-static size_t tail_self_attn_smem(int L) { return ((size_t)L * 65 + (size_t)L * 64 + 4 * 64 + 64) * sizeof(float); }
+static size_t tail_self_attn_smem(int L, int D = 64) { return ((size_t)L * (D + 1) + (size_t)L * D + 4 * 64 + 64) * sizeof(float); }
 
 hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
   if (a.L > MAX_DEC_LEN || a.T < 1 || a.T >= a.L) return hipErrorInvalidValue;
+  if (a.dkv == 128) {   // t5-3b heads: the VALU kernel (the MFMA tiles below are written for 64-dim heads)
+    hipLaunchKernelGGL(tail_self_attn_kernel<128>, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L, 128), s, a);
+    return hipGetLastError();
+  }
   static const bool off = [] { const char* e = dev_getenv("RPR_TAIL_ATTN_MFMA"); return e && atoi(e) == 0; }();
   if (!off) {
     const long waves = (long)a.nseq_cap * a.H;
@@ -1384,7 +1402,7 @@ hipError_t launch_tail_self_attn(const TailSelfAttnArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(tail_self_attn_mfma_kernel<2>, grid, blk, 4 * (64 * 64 + 64 + 32 * 64) * sizeof(float), s, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(tail_self_attn_kernel, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L), s, a);
+  hipLaunchKernelGGL(tail_self_attn_kernel<64>, dim3((unsigned)a.nseq_cap * a.H), dim3(256), tail_self_attn_smem(a.L), s, a);
   return hipGetLastError();
 }
 
@@ -1586,8 +1604,11 @@ hipError_t launch_max_row_norm(const float* E, const float* w, int rows, int d, 
 }
 
 hipError_t init_tail_kernel_attributes() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel<64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)tail_self_attn_smem(MAX_DEC_LEN, 128));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_self_attn_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
   if (e != hipSuccess) return e;

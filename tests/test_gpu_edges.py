@@ -306,7 +306,7 @@ def test_long_docids_beyond_the_register_attention_path(setup):
 def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
     """d_kv = 128 (the head size of t5-3b, t5_generative_retriever.py:128-133) on a small stack: the generic attention kernels
     (enc_attn_kernel<128>, dec_attn_kernel<., 128>), the d_kv-strided KV cache map of the q/k/v GEMM and the packed encoder
-    at ragged query lengths up to 120 tokens; both GEMM modes; forks are not taken for this head size (plain loop)."""
+    at ragged query lengths up to 120 tokens; both GEMM modes; the plain loop and the forced tail (explicit forks)."""
     from oracle import beam_ref, t5_ref
     E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
     L, V, N, B, Q, qlen = {"short": (8, 256, 3000, 10, 5, 14), "long_queries": (6, 256, 3000, 4, 3, 120),
@@ -321,20 +321,29 @@ def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
     ids, mask = synth.make_queries(Q, vocab_size=512, seed=92, max_len=qlen, mean_len=0.75 * qlen, std_len=0.2 * qlen)
     seqs, sc = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)
     exp_tok, exp_sc = seqs.numpy().reshape(Q, B, L + 1)[:, :, 1:], sc.numpy().reshape(Q, B)
-    assert ctx.fork_depths(model, trie, Q, B, L, False) == []
     ctx.status(clear=True)
-    for precision in ("f16x2", "f32"):
-        ctx.set_precision(precision)
-        try:
+    # the plain step loop, and (round 6) the forced tail at this head size: tail_self_attn_kernel<128> + the chunked block
+    # cross-attention; explicit fork depths so that every case really leaves the loop early
+    modes = [("f16x2", None), ("f32", None), ("f16x2", [1]), ("f16x2", [2, 3] if L >= 5 else [2]), ("f32", [L - 1])]
+    try:
+        for precision, forks in modes:
+            ctx.set_precision(precision)
+            ctx.set_forced_tail(forks is not None)
+            ctx.set_fork_depths(forks)
             res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
             torch.cuda.synchronize()
-        finally:
-            ctx.set_precision("f16x2")
-        got_sc = res.scores.cpu().numpy()
-        np.testing.assert_allclose(got_sc, exp_sc, atol=1e-4, rtol=0, err_msg=f"{case} {precision}")
-        same = (res.tokens.cpu().numpy() == exp_tok).all(axis=2)
-        # a rank may differ from the oracle's only where two candidates tie within the score tolerance
-        assert bool((same | (np.abs(got_sc - exp_sc) <= 1e-4)).all()) and same.mean() >= 0.98, (case, precision, same.mean())
+            if forks is not None:
+                st = ctx.last_fork_stats()
+                assert st and sum(f["forced"] + f["left"] for f in st[:1]) == Q, (case, forks, st)
+            got_sc = res.scores.cpu().numpy()
+            np.testing.assert_allclose(got_sc, exp_sc, atol=1e-4, rtol=0, err_msg=f"{case} {precision} forks {forks}")
+            same = (res.tokens.cpu().numpy() == exp_tok).all(axis=2)
+            # a rank may differ from the oracle's only where two candidates tie within the score tolerance
+            assert bool((same | (np.abs(got_sc - exp_sc) <= 1e-4)).all()) and same.mean() >= 0.98, (case, precision, forks, same.mean())
+    finally:
+        ctx.set_precision("f16x2")
+        ctx.set_fork_depths(None)
+        ctx.set_forced_tail(True)
     assert ctx.status() == 0
     if case == "short":   # the documented limit of this head size fails with a message, not with a launch error
         long_ids, long_mask = synth.make_queries(2, vocab_size=512, seed=93, fixed_len=129)
