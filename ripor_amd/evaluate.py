@@ -128,7 +128,11 @@ def constrained_decode_doc(model, dataloader, prefix_constrain_processor, smtid_
             break
         t0 = time.perf_counter()
         with torch.no_grad():
-            inputs = {k: v.to(device) for k, v in batch.items() if k != "id"}
+            # pinned + non_blocking: a pageable host-to-device copy is ordered behind the previous batch's search on the
+            # stream and blocks the host until then (tools/cli_end_to_end.py at beam 1000: the host sat 136 of 145 s in this
+            # call and turned the previous batch into run.json entries only afterwards)
+            inputs = {k: (v.pin_memory().to(device, non_blocking=True) if _dev.type == "cuda" else v.to(device))
+                      for k, v in batch.items() if k != "id"}
             outputs = generate_for_constrained_prefix_beam_search(
                 model, prefix_constrain_processor, input_ids=inputs["input_ids"].long(),
                 attention_mask=inputs["attention_mask"].long(), max_new_tokens=max_new_token, output_scores=True,

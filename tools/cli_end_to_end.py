@@ -147,7 +147,7 @@ def main():
         # merge + metrics, as the script's second command (synthetic qrels: the top document of every query is relevant)
         t0 = time.perf_counter()
         runj = json.load(open(run_path))
-        qrel_path = os.path.join(root, f"qrel_b{B}.json")
+        qrel_path = os.path.join(data, f"dev_qrel_b{B}.json")     # under the msmarco_* directory: evaluate() names the dataset from the path
         json.dump({qid: {max(docs, key=docs.get): 1} for qid, docs in runj.items() if docs}, open(qrel_path, "w"))
         e["docs_per_query_mean"] = round(float(np.mean([len(d) for d in runj.values()])), 1)
         del runj
