@@ -314,7 +314,7 @@ def board_power_under(run, seconds=2.5):
             "sclk_mhz_nominal": 2400,
             "note": "rocm-smi sampled while the headline step repeats (outside the timed region; GPU use >= 90 % samples only): "
                     "power_w_mean against power_cap_w and sclk_mhz_mean against the 2400 MHz nominal clock say how far DVFS throttles "
-                    "the GEMM-dominated step (default batch: ~1340 W of 1400 W at ~1.85 GHz, profiles/r03e_power_samples.txt)"}
+                    "the GEMM-dominated step (default batch: ~1340 W of 1400 W at ~1.85 GHz, profiles/archive/r03e_power_samples.txt)"}
 
 
 def secondary_latency(E, synth, ctx, model, trie, dims, dev, L, steps=8):
@@ -1034,6 +1034,25 @@ def main():
                                "avg_launch_us": v["total_ms"] * 1e3 / max(1, v["launches"]),
                                "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"])}
             if hk:
+                # counter evidence: mean (2 FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the class's
+                # kernels from the committed PMC passes — those ran the TIMED configuration, i.e. per half-batch launch on a lane's
+                # 128 CUs when the lanes are on, while achieved / frac above are whole-chip launches of the unsplit profile pass
+                try:
+                    pmc = json.load(open(os.path.join(REPO, "profiles", "latest_hbm_pmc.json")))
+                    names = {"tail_self_attn": ("tail_self_attn_mfma",), "dec_cross_attn": ("tail_cross_attn_mfma", "step_cross_attn_mfma16"),
+                             "enc_attn": ("enc_attn_mfma",)}
+                    for cls, e in hk.items():
+                        ks = [k for k in pmc["FETCH_SIZE"] if any(n in k for n in names[cls]) and k in pmc["WRITE_SIZE"]]
+                        n = sum(pmc["FETCH_SIZE"][k]["launches"] for k in ks)
+                        if n:
+                            tot = sum((2.0 * pmc["FETCH_SIZE"][k]["sum"] + pmc["WRITE_SIZE"][k]["sum"]) * 1024.0 for k in ks)
+                            e["traffic"] = tot / n
+                            e["traffic_launches"] = n
+                            e["traffic_source"] = ("profiles/latest_hbm_pmc.json, mean per launch over " + ", ".join(k.split("(")[0].replace("void ", "") for k in ks)
+                                                   + (": launches of the timed two-lane configuration (half batches on 128 CUs each) — compare with "
+                                                      "algorithmic_bytes_per_launch / 2" if lanes_on else ""))
+                except Exception:
+                    pass
                 out["roofline_hbm_attention"] = hk
         if world == 1 and not args.no_roofline:
             try:

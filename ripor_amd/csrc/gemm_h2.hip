@@ -1152,7 +1152,7 @@ static hipError_t launch_wsplit_cfg(const GemmH2Args& k, hipStream_t s) {
 // Tile shape and K split of a wave-split launch. These launches are latency-bound by LDS capacity: a block keeps at most its
 // rings in flight (64-96 KB) against a loaded L2 / Infinity-Cache latency of ~3 us, i.e. 40-50 GB/s per CU whatever the tile
 // (tools/attic/fill_probe.hip: the LDS-DMA path itself sustains > 100 GB/s per CU from L2), one block per CU (128-144 KB of LDS).
-// Model fitted to tools/wsplit_bench.sh on MI355X (profiles/r05d_wsplit_gemm_bench.txt): launch = 5 us + rounds of blocks over
+// Model fitted to tools/wsplit_bench.sh on MI355X (profiles/archive/r05d_wsplit_gemm_bench.txt): launch = 5 us + rounds of blocks over
 // the CUs x (3 us + KB per block / rate), + one reduction launch for a K split over blocks.
 // cfg 0: 32 x 32 (four stages), 1: 64 x 32 (three), 2: 64 x 64 (two).
 struct WsplitChoice { int cfg, ks; double us; long rounds; };
@@ -1509,7 +1509,7 @@ hipError_t launch_gemm_h2(GemmH2Args& a_in, hipStream_t s) {
     // the ping-pong kernel, the rows behind them to the 128 x 128 tile kernel (a quarter of the work per block, 1.22 x the
     // time per flop), as a second launch on the same stream. Taken when the estimate — whole rounds + 0.43 per round of
     // 128^2 tiles (measured: 5240 rows x 768 columns = 246 such tiles in 35.7 us against 87.1 us for the 255 tiles of 256^2
-    // in front of them, profiles/r05x_rowsplit_gemm.txt) + ~6 us for the second launch — is under 0.9 of the rounds the
+    // in front of them, profiles/archive/r05x_rowsplit_gemm.txt) + ~6 us for the second launch — is under 0.9 of the rounds the
     // ping-pong kernel alone would need. RPR_GEMM_ROWSPLIT=0: off; =2 (tests): every launch of this route with two or more
     // row tiles is split in the middle.
     static const int row_split = [] { const char* e = dev_getenv("RPR_GEMM_ROWSPLIT"); return e ? atoi(e) : 1; }();

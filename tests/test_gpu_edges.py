@@ -462,11 +462,11 @@ def test_lane_split_gives_the_results_of_one_call(setup):
     """rpr_set_lane_split: a batch run as two halves on the two CU-masked lane streams (own workspaces, own hipGraphs)
     returns what the unsplit call returns, for an odd batch, in graph and eager mode, repeatedly (graph replay), and the
     caller's stream order holds (results are read right after the call on the same stream).
-    Bit equality holds when both runs take the same GEMM kernels (their accumulation orders differ): the library splits
-    batches of >= 10 240 decoder rows, where every launch of either run is on the 256 x 256 (or the 128-row) tile kernel —
-    second part, 2600 queries at the default threshold. The forced split of 81 queries puts the halves' launches on other
-    small-tile routes than the whole batch's (row thresholds of the wave-split tiles): same smtids and row ranges, scores
-    within fp32 summation-order noise."""
+    Every query is computed on its own rows either way, but a half batch may take another GEMM route than the whole one
+    (row thresholds of the wave-split tiles, K splits chosen from the tile count and the CUs of a lane) and the routes sum K
+    in different orders: same smtids and row ranges, scores within fp32 summation-order noise (3e-5; the parity bar is
+    1e-4) — for a forced split of 81 queries and for 2600 queries at the library's own threshold of 10 240 decoder rows.
+    Replays and eager launches of the split call itself agree bit for bit."""
     E, ctx, dims, synth = setup["E"], setup["ctx"], setup["dims"], setup["synth"]
     L, V, B, Q = setup["L"], dims.decoder_vocab_sizes[0], 4, 81
     model = E.DeviceModel(ctx, synth.make_state_dict(dims, seed=31), dims)
@@ -520,7 +520,10 @@ def test_lane_split_gives_the_results_of_one_call(setup):
         ctx.set_lane_split(10240)
         got = E.search(model, trie, ids2, mask2, B, L)
         torch.cuda.synchronize()
-        same(got, want, bits=True)
+        same(got, want, bits=False)
+        again = E.search(model, trie, ids2, mask2, B, L, use_graph=False)
+        torch.cuda.synchronize()
+        same(again, got, bits=True)
     finally:
         ctx.set_lane_split(saved if saved else 10240)
 

@@ -19,7 +19,7 @@ t0=rows[j][1]
 busy=0; n=0
 with open("$O/last_search.txt","w") as f:
     for n_,s,d,g,w in rows[j:]:
-        f.write(f"{(s-t0)/1e3:10.1f} {d/1e3:8.1f} {g//max(w,1):6d} {n_.split('(')[0][:70]}\n")
+        f.write(f"{(s-t0)/1e3:10.1f} {d/1e3:8.1f} {g//max(w,1):6d} {n_.replace('(anonymous namespace)::', '').split('(')[0][:70]}\n")
         busy+=d; n+=1
     end=rows[-1][1]+rows[-1][2]
     f.write(f"# {n} launches, wall {(end-t0)/1e3:.1f} us, kernel busy {busy/1e3:.1f} us\n")

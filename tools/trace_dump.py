@@ -19,7 +19,7 @@ t0, t1 = rows[0][1], rows[-1][1] + rows[-1][2]
 agg = defaultdict(lambda: [0, 0.0])
 short_n, short_t = 0, 0.0
 for n, s, d in rows:
-    k = n.split("(")[0].replace("rpr::", "")
+    k = n.replace("(anonymous namespace)::", "").split("(")[0].replace("rpr::", "")
     agg[k][0] += 1
     agg[k][1] += d
     if d < 6000:
@@ -45,6 +45,6 @@ if "--seq" in sys.argv:
     N = int(sys.argv[sys.argv.index("--seq") + 1])
     big = sorted(rows, key=lambda r: -r[2])[:N]
     for n, s, d in sorted(big, key=lambda r: r[1]):
-        print(f"  t={(s - t0) / 1e6:9.3f} ms  {d / 1e3:9.1f} us  {n.split('(')[0][:90]}")
+        print(f"  t={(s - t0) / 1e6:9.3f} ms  {d / 1e3:9.1f} us  {n.replace('(anonymous namespace)::', '').split('(')[0][:90]}")
 if "--json" in sys.argv:
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
