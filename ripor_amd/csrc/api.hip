@@ -1299,9 +1299,13 @@ std::vector<int> choose_forks(rpr_ctx* c, const rpr_model* m, rpr_trie* tr, int 
   int t0 = 0;
   for (int t = 1; t <= L - 2 && !t0; ++t) if (p_forced(t) >= 0.5) t0 = t;
   // a tail pass costs what its positions cost step by step minus the K/V gathering, plus a fork (~100 launches, two
-  // partly filled launches for the leftovers): below 8 remaining positions the plain loop is as fast (measured at
-  // beam 100, len 8: 1890 queries/s without forks, 1510 with)
-  if (!t0 || L - t0 < 8) return forks;
+  // partly filled launches for the leftovers): with thousands of decoder rows in flight — steps bound by the matrix
+  // pipes — the plain loop is as fast below 8 remaining positions (measured at beam 100, len 8, 214 queries: 1890
+  // queries/s without forks, 1510 with). A few hundred rows (the reference's rank-data flags: beam 100, batch 4, len 8)
+  // are bound by the launch chain instead: a step of 12 layers costs 1.6 ms whatever it computes, the four remaining
+  // positions as ONE pass of 1600 rows cost as much as one and a half steps (round 6: 306 -> 378 queries/s)
+  const int min_tail = (int64_t)Q * B <= 4096 ? 2 : 8;
+  if (!t0 || L - t0 < min_tail) return forks;
   forks.push_back(t0);
   // Optimistic mode (rpr_set_forced_tail(ctx, 2)): when the statistics promise an (almost always) empty last stage, that
   // stage is not enqueued at all — ~100 launches per step for nobody — and a query that is still unforced at the last
@@ -1630,7 +1634,10 @@ int rpr_op_linear_bf16(rpr_ctx* c, const float* A, const float* W, const float* 
     g.out[0] = g.out[1] = g.out[2] = C; g.ldo[0] = g.ldo[1] = g.ldo[2] = N; g.split_n = N;
     g.M = M; g.N = N; g.K = K; g.relu = relu; g.acc_scale = 1.0f; g.bf16 = 1;
     g.part = part.as<float>(); g.part_cap = part_bytes / sizeof(float);
-    RPR_HIP(launch_gemm_h2(g, s));
+    Launcher Ln{c, s};                                    // (profile accounting: tools/gemm_bf16_bench.py times the launch alone)
+    Ln.run(RPR_K_GEMM, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, [&] { return launch_gemm_h2(g, s); },
+           &g.kernel_cls);
+    if (Ln.err) return Ln.err;
   } else {
     RPR_HIP(tab.alloc(GemmGroupArgs::SCRATCH_BYTES));
     GemmGroupArgs p{};

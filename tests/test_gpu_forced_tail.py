@@ -66,7 +66,10 @@ def test_dense_trie_most_queries_forced_some_not(E):
     ctx, model, trie, sd, dims, ids, mask = _setup(E, codes, L, V, Q=48)
     depths = ctx.fork_depths(model, trie, ids.shape[0], B, L)
     assert len(depths) >= 1 and depths[0] in (2, 3, 4), depths
-    assert ctx.fork_depths(model, trie, ids.shape[0], B, 8) == [], "a tail of fewer than 8 positions is not worth a fork"
+    # thousands of decoder rows in flight: a tail of fewer than 8 positions is not worth a fork; a few hundred rows (steps bound
+    # by the launch chain) fork down to two remaining positions (round 6)
+    assert ctx.fork_depths(model, trie, 1000, B, 8) == []
+    assert ctx.fork_depths(model, trie, ids.shape[0], B, 8) != [] and ctx.fork_depths(model, trie, ids.shape[0], B, 8)[0] <= 6
     res, plain, stats = _same_as_plain(ctx, E, model, trie, ids, mask, B, L, "dense 60k")
     assert stats[0]["forced"] + stats[0]["left"] == ids.shape[0]
     assert stats[0]["forced"] > 0, "the fork took no query: the test does not exercise the tail pass"
