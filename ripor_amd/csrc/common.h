@@ -165,6 +165,10 @@ struct GemmH2Args {
   // product); mask_src [M][ldmask] fp32 (nullable): elements whose mask_src is not positive are written as zero (the ReLU
   // backward of the feed-forward block). out[0] may then be null (no fp32 result). M % 256 == 0, N % 256 == 0.
   void* out_b; int ldob; void* out_bt; int ldobt; const float* mask_src; int ldmask;
+  // tile order of the persistent 256x256 kernel (set by its launcher): 0 = row-major; > 0 = bands of tile_rb row panels,
+  // inside a band column groups of tile_cw tiles, inside a group panel by panel — the blocks of an XCD that run side by side
+  // then cover tile_rb x tile_cw tiles and share tile_rb A panels and tile_cw W panels in their L2 (gemm_h2_pp_body.inc)
+  int tile_cw, tile_rb;
 };
 
 // f16 has 5 exponent bits: a plane element below 2^-14 is subnormal, so the lo plane of x = hi + lo (|lo| ~ 2^-11 |x|)

@@ -1200,7 +1200,8 @@ static hipError_t launch_cfg(const GemmH2Args& a, hipStream_t s) {
 
 // 256x256 tile, 8 waves (2x4) of 128x64, ping-pong schedule: half the staged bytes per MFMA of the 128x128 tile;
 // >= ~112 tiles to beat the 128x128 kernel (measured), i.e. M = Q*B >= ~10k rows for N = 768
-static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
+static hipError_t launch_256(const GemmH2Args& a_in, hipStream_t s) {
+  GemmH2Args a = a_in;
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const bool full = (a.M % 256 == 0) && (a.N % 256 == 0) && !a.m_dev;
   // persistent blocks: one per CU of the stream (a whole number per XCD), fewer when the launch has fewer tiles
@@ -1208,6 +1209,14 @@ static hipError_t launch_256(const GemmH2Args& a, hipStream_t s) {
   const int grid = nt > cus ? cus : nt;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const dim3 gr(ks > 1 ? nt : grid, ks), bl(512);      // split-K launches are not persistent: one block per (tile, K range)
+  // super-tile order for products more than four column tiles wide (N = 2304, 3072): column groups of 3 or 4 tiles, bands of
+  // as many row panels as the blocks of one XCD fill with such a group. RPR_PP_SUPERTILE=0 (development builds): row-major
+  static const int sup = [] { const char* e = dev_getenv("RPR_PP_SUPERTILE"); return e ? atoi(e) : 1; }();
+  a.tile_cw = a.tile_rb = 0;
+  if (sup && ks == 1 && tiles_n > 4 && nt > grid) {
+    a.tile_cw = sup > 1 ? sup : (tiles_n % 4 == 0 ? 4 : (tiles_n % 3 == 0 ? 3 : 4));
+    a.tile_rb = std::max(1, (grid / 8) / a.tile_cw);
+  }
   if (a.bf16) {
     if (full) hipLaunchKernelGGL((gemm_h2_pp_kernel<true, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
     else hipLaunchKernelGGL((gemm_h2_pp_kernel<false, false, true>), gr, bl, 0, s, a, tiles_m, tiles_n);
