@@ -48,7 +48,7 @@ typedef struct rpr_trie rpr_trie;
  * pointers with num_layers / num_decoder_layers entries. */
 typedef struct {
   int32_t vocab_size, d_model, d_kv, d_ff, num_heads;   /* d_kv: 64 (t5-base / t5-large) or 128 (t5-3b: rpr_search / rpr_encode only,
-                                                         * queries of up to 128 tokens, no forced tail, no training entry points) */
+                                                         * no training entry points) */
   int32_t num_layers, num_decoder_layers;
   int32_t rel_buckets, rel_max_distance;
   int32_t L;                     /* len(config.decoder_vocab_sizes) = max decoder positions      */

@@ -1395,7 +1395,6 @@ int rpr_search(rpr_ctx* c, rpr_model* m, rpr_trie* tr, const int32_t* input_ids,
   RPR_REQUIRE(m->ctx == c && tr->ctx == c, "model/trie belong to another ctx");
   RPR_REQUIRE(Q >= 1 && B >= 1 && B <= 65535, "Q or B out of range");
   RPR_REQUIRE(Lq >= 1 && Lq <= MAX_LQ, "Lq out of range (1..256)");
-  RPR_REQUIRE(m->d.d_kv == DKV || Lq <= 128, "d_kv = 128 models take queries of up to 128 tokens (the encoder attention kernel holds a head's K and V in LDS)");
   RPR_REQUIRE(L >= 1 && L <= m->d.L && L <= tr->L, "L exceeds the model's decoder length or the trie depth");
   RPR_REQUIRE(tr->V == m->d.V, "trie V differs from the model's decoder vocab size");
   RPR_REQUIRE((int64_t)Q * B < ((int64_t)1 << 24), "Q*B too large");
@@ -1550,7 +1549,6 @@ int rpr_encode(rpr_ctx* c, rpr_model* m, const int32_t* input_ids, const int32_t
                int32_t Lq, float* out, void* stream) {
   RPR_REQUIRE(c && m && input_ids && attention_mask && out, "NULL argument");
   RPR_REQUIRE(Q >= 1 && Lq >= 1 && Lq <= MAX_LQ, "Q or Lq out of range");
-  RPR_REQUIRE(m->d.d_kv == DKV || Lq <= 128, "d_kv = 128 models take queries of up to 128 tokens (the encoder attention kernel holds a head's K and V in LDS)");
   RPR_HIP(hipSetDevice(c->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int e = ensure_weight_planes(c, m, s);

@@ -154,15 +154,18 @@ hipError_t launch_dec_embed(const float* start, const float* in_embeds, const ui
 // table, two dependent loads), the key mask and the q rows (eight rows of the wave per batch, requested together) are
 // staged in LDS first. With those three loads in the loop a row cost two memory round trips: 61 us for the 3072 blocks of
 // a teacher-forced decoder layer (32 positions), 290 us for 2150 packed queries of the search encoder.
-template <int D>   // head dim: 64 (every kernel argument / LDS row as before) or 128 (t5-3b): a lane holds D / 64 dims of a row
+// VG (128-dim heads, queries of more than ~150 tokens: K and V of a head together exceed the 160 KB of LDS): only K is staged,
+// the weighted sum reads the V rows from global memory (512 contiguous bytes per row and wave, requested eight rows at a time;
+// the rows of a query stay in the XCD's L2 between its heads' blocks).
+template <int D, bool VG = false>   // head dim: 64 (every kernel argument / LDS row as before) or 128 (t5-3b): a lane holds D / 64 dims of a row
 __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NV = D / 64;
   const int Lq = a.Lq, H = a.H, inner = H * D, ld = 3 * inner;
   const int qi = blockIdx.x / H, h = blockIdx.x - qi * H;
   float* Ks = smem;                         // [Lq][D + 1]
-  float* Vs = smem + (size_t)Lq * (D + 1);  // [Lq][D]
-  float* Ps = Vs + (size_t)Lq * D;          // [4][Lq] normalised weights per wave
+  float* Vs = smem + (size_t)Lq * (D + 1);  // [Lq][D] (VG: not staged)
+  float* Ps = Vs + (VG ? 0 : (size_t)Lq * D);   // [4][Lq] normalised weights per wave
   float* RB = Ps + 4 * Lq;                  // [2 Lq] bias of this head per key offset (causal: i - j; else j - i + nrow - 1)
   float* Qs = RB + 2 * Lq;                  // [4][8][D] q rows of the wave's current batch
   int* Ms = reinterpret_cast<int*>(Qs + 4 * 8 * D);   // [Lq] key mask
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * inner + c);
     float* kd = Ks + j * (D + 1) + c;
     kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<float4*>(Vs + j * D + c) = vv;
+    if (!VG) *reinterpret_cast<float4*>(Vs + j * D + c) = vv;
   }
   const int nrb = a.causal ? nrow : 2 * nrow - 1, rb0 = a.causal ? 0 : MAX_LQ - nrow;
   for (int k = tid; k < nrb; k += 256) RB[k] = a.rel_bias[a.bucket[rb0 + k] * H + h];
@@ -253,9 +256,29 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
     float o[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) o[v] = 0.f;
-    for (int j = 0; j < nrow; ++j)
+    if (VG) {
+      const float* vg = base + 2 * inner + lane;
+      for (int j0 = 0; j0 < nrow; j0 += 8) {
+        float vv[8][NV];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) o[v] = fmaf(P[j], Vs[j * D + 64 * v + lane], o[v]);
+        for (int u2 = 0; u2 < 8; ++u2) {
+          const int j = min(j0 + u2, nrow - 1);           // clamped, unconditional: all eight requests go out together
+#pragma unroll
+          for (int v = 0; v < NV; ++v) vv[u2][v] = vg[(size_t)j * ld + 64 * v];
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < 8; ++u2) {
+          if (j0 + u2 < nrow) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) o[v] = fmaf(P[j0 + u2], vv[u2][v], o[v]);
+          }
+        }
+      }
+    } else {
+      for (int j = 0; j < nrow; ++j)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) o[v] = fmaf(P[j], Vs[j * D + 64 * v + lane], o[v]);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const size_t oidx = (row0 + i) * inner + h * D + 64 * v + lane;
@@ -273,15 +296,20 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(EncAttnArgs a) {
   }
 }
 
-static size_t enc_attn_smem(int Lq, int D) {
-  return ((size_t)Lq * (D + 1) + (size_t)Lq * D + 4 * (size_t)Lq + 2 * (size_t)Lq + 4 * 8 * (size_t)D + (size_t)Lq) * sizeof(float);
+static size_t enc_attn_smem(int Lq, int D, bool stage_v = true) {
+  return ((size_t)Lq * (D + 1) + (stage_v ? (size_t)Lq * D : 0) + 4 * (size_t)Lq + 2 * (size_t)Lq + 4 * 8 * (size_t)D + (size_t)Lq) * sizeof(float);
 }
 hipError_t launch_enc_attn(const EncAttnArgs& a, hipStream_t s) {
   if (a.Lq > MAX_LQ || a.buckets > 64) return hipErrorInvalidValue;
   if (a.dkv == 128) {   // t5-3b heads: the generic kernel only
     const size_t smem = enc_attn_smem(a.Lq, 128);
-    if (smem > 160 * 1024) return hipErrorInvalidValue;   // Lq <= ~150 at 128-dim heads
-    hipLaunchKernelGGL(enc_attn_kernel<128>, dim3(a.Q * a.H), dim3(256), smem, s, a);
+    if (smem <= 160 * 1024) {                               // Lq <= ~150: K and V of a head in LDS
+      hipLaunchKernelGGL(enc_attn_kernel<128>, dim3(a.Q * a.H), dim3(256), smem, s, a);
+      return hipGetLastError();
+    }
+    const size_t smem_k = enc_attn_smem(a.Lq, 128, false);  // up to MAX_LQ = 256 tokens: K in LDS (155 KB), V from global memory
+    if (smem_k > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((enc_attn_kernel<128, true>), dim3(a.Q * a.H), dim3(256), smem_k, s, a);
     return hipGetLastError();
   }
   static const bool mfma_off = [] { const char* e = dev_getenv("RPR_TRAIN_ATTN_MFMA"); return e && atoi(e) == 0; }();
@@ -697,6 +725,8 @@ hipError_t init_t5_kernel_attributes() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;

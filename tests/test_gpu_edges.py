@@ -302,14 +302,17 @@ def test_long_docids_beyond_the_register_attention_path(setup):
     np.testing.assert_allclose(res.scores.cpu().numpy(), sc.numpy().reshape(Q, B), atol=1e-4, rtol=0)
 
 
-@pytest.mark.parametrize("case", ["short", "long_queries", "deep_docids", "beam1000"])
+@pytest.mark.parametrize("case", ["short", "long_queries", "longest_queries", "deep_docids", "beam1000"])
 def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
     """d_kv = 128 (the head size of t5-3b, t5_generative_retriever.py:128-133) on a small stack: the generic attention kernels
     (enc_attn_kernel<128>, dec_attn_kernel<., 128>), the d_kv-strided KV cache map of the q/k/v GEMM and the packed encoder
-    at ragged query lengths up to 120 tokens; both GEMM modes; the plain loop and the forced tail (explicit forks)."""
+    at ragged query lengths up to 120 tokens — and up to the reference's 256 (evaluate.py:465), where K and V of a head no
+    longer fit the LDS together (enc_attn_kernel<128, true>: V rows from global memory); both GEMM modes; the plain loop and
+    the forced tail (explicit forks)."""
     from oracle import beam_ref, t5_ref
     E, synth, ctx = setup["E"], setup["synth"], setup["ctx"]
     L, V, N, B, Q, qlen = {"short": (8, 256, 3000, 10, 5, 14), "long_queries": (6, 256, 3000, 4, 3, 120),
+                           "longest_queries": (5, 256, 3000, 3, 3, 256),
                            "deep_docids": (40, 256, 300, 3, 2, 9), "beam1000": (4, 256, 60000, 1000, 1, 11)}[case]
     dims = synth.ModelDims(vocab_size=512, d_model=256, d_kv=128, d_ff=128, num_layers=2, num_decoder_layers=3, num_heads=4,
                            decoder_vocab_sizes=[V] * L)
@@ -345,9 +348,9 @@ def test_128_dim_heads_against_the_kv_cached_oracle(setup, case):
         ctx.set_fork_depths(None)
         ctx.set_forced_tail(True)
     assert ctx.status() == 0
-    if case == "short":   # the documented limit of this head size fails with a message, not with a launch error
-        long_ids, long_mask = synth.make_queries(2, vocab_size=512, seed=93, fixed_len=129)
-        with pytest.raises(E.RiporHipError, match="up to 128 tokens"):
+    if case == "short":   # beyond the reference's truncation length: a message, not a launch error
+        long_ids, long_mask = synth.make_queries(2, vocab_size=512, seed=93, fixed_len=257)
+        with pytest.raises(E.RiporHipError, match="Lq out of range"):
             E.search(model, trie, torch.from_numpy(long_ids), torch.from_numpy(long_mask), B, L)
 
 
