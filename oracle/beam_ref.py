@@ -7,7 +7,8 @@ optional full-prefix decoder recompute) so it can double as the ``cpu_baseline``
 Follows:
   * reference t5_pretrainer/evaluate.py:410-424 and aq_preprocess/build_list_smtid_to_nextids.py:21-41
     -> :func:`build_list_smtid_to_nextids`
-  * reference t5_pretrainer/tasks/generation.py:603-677 -> :class:`PrefixMaskRef`
+  * reference t5_pretrainer/tasks/generation.py:603-677 -> :class:`PrefixMaskRef` (and :class:`SortedPrefixMaskRef`, the same
+    mask from the sorted code matrix for corpora whose dicts do not fit host RAM)
   * reference t5_pretrainer/tasks/generation.py:35-251 (wrapper: encoder once, expand xB, scorer)
     and :253-575 (loop) -> :func:`beam_search_ref`
   * third-party transformers==4.17.0 ``BeamSearchScorer.process/finalize`` (source not available
@@ -89,6 +90,54 @@ class PrefixMaskRef:
         if unknown:
             mask[np.asarray(unknown)] = 0.0
         return mask  # float64 [R, V]
+
+
+class SortedPrefixMaskRef:
+    """The same function as :class:`PrefixMaskRef` — ``mask[r, v] = 1`` iff some document's code sequence starts with
+    the prefix of row r followed by v, an unknown prefix gives an all-zero row (reference generation.py:656-661,675) —
+    evaluated on the lexicographically sorted code matrix instead of the reference's dict of strings: the dicts of the
+    8.8 M-document corpus do not fit host RAM (tests/test_gpu_fullsize.py), the matrix is 283 MB. A prefix is a row
+    range, narrowed one ``np.searchsorted`` pair per new token and remembered per prefix (a beam extends its parent's
+    prefix). Pinned to PrefixMaskRef by tests/test_oracle_golden.py::test_sorted_matrix_mask_equals_the_dict_mask.
+    Codes < 256 (one byte per position)."""
+
+    def __init__(self, codes: np.ndarray, vocab_size: int):
+        codes = np.asarray(codes)
+        assert codes.ndim == 2 and 0 <= int(codes.min()) and int(codes.max()) < 256
+        self.vocab_size = vocab_size
+        N, L = codes.shape
+        Lp = (L + 7) // 8 * 8
+        b = np.zeros((N, Lp), dtype=np.uint8)
+        b[:, :L] = codes
+        keys = b.view(">u8")                                   # [N, Lp / 8] big-endian words: word order = lexicographic order
+        order = np.lexsort(tuple(keys[:, k] for k in range(keys.shape[1] - 1, -1, -1)))
+        self.sorted = np.ascontiguousarray(b[order, :L])
+        self.ranges = {(): (0, N)}
+
+    def _range(self, prefix: tuple):
+        r = self.ranges.get(prefix)
+        if r is None:
+            lo, hi = self._range(prefix[:-1])
+            k = len(prefix) - 1
+            if hi > lo and k < self.sorted.shape[1] and 0 <= prefix[-1] < 256:
+                col = self.sorted[lo:hi, k]
+                r = (lo + int(np.searchsorted(col, prefix[-1], "left")), lo + int(np.searchsorted(col, prefix[-1], "right")))
+            else:
+                r = (lo, lo)
+            self.ranges[prefix] = r
+        return r
+
+    def __call__(self, ids: np.ndarray) -> np.ndarray:
+        R, T = ids.shape
+        mask = np.zeros((R, self.vocab_size), dtype=np.float64)
+        if T - 1 >= self.sorted.shape[1]:
+            return mask
+        for i, row in enumerate(ids.tolist()):
+            lo, hi = self._range(tuple(row[1:]))
+            if hi > lo:
+                nxt = np.unique(self.sorted[lo:hi, T - 1])
+                mask[i, nxt[nxt < self.vocab_size]] = 1.0
+        return mask
 
 
 # ----------------------------------------------------------------------------- scorer (HF 4.17 behaviour)

@@ -262,3 +262,51 @@ def test_mid_size_trie_against_the_kv_cached_oracle():
                 assert docs == want and docs, (q, b)
     ctx.set_forced_tail(2)
     print(f"[mid-size] {N} docs, forks {forks}: {nq} queries == KV-cached oracle")
+
+
+def test_full_size_trie_against_the_kv_cached_oracle(big_trie):
+    """config 2 itself — t5-base dims, the 8 841 823-doc trie, beam 10, len 32, automatic forks — against
+    the CPU oracle instead of against other runs of the library. The reference's dict-of-strings trie cannot hold this corpus
+    in RAM, so the oracle's mask comes from `SortedPrefixMaskRef` (the same mask function evaluated on the sorted code
+    matrix, pinned to the dict mask by tests/test_oracle_golden.py::test_sorted_matrix_mask_equals_the_dict_mask); model,
+    float64 combine, top-2B, scorer and finalize are the restatement the goldens pin. Four queries (~40 s of CPU work).
+    Comparator of the goldens; the documents under every returned smtid are the oracle's row range, row by row."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    trie, codes = big_trie
+    B, nq = 10, 4
+    ctx = E.Context.get(0)
+    ctx.set_precision("f16x2")
+    dims = synth.t5_base_dims(L=L, V=V)
+    sd = synth.make_state_dict(dims)
+    ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=23)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    pm = beam_ref.SortedPrefixMaskRef(codes, V)
+    seqs, scores = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)[:2]
+    ref_tok = np.asarray(seqs).reshape(nq, B, L + 1)[:, :, 1:]
+    ref_sc = np.asarray(scores, dtype=np.float64).reshape(nq, B)
+    model = E.DeviceModel(ctx, sd, dims)
+    ctx.status(clear=True)
+    saved_mode = ctx.forced_tail()
+    try:
+        for mode in (2, 1, 0):                            # optimistic, exact forced tail, plain step loop
+            ctx.set_forced_tail(mode)
+            res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+            torch.cuda.synchronize()
+            forks = ctx.last_fork_stats()
+            if mode == 2 and ctx.status(clear=True) & 4:
+                continue
+            assert mode == 0 or (forks and forks[0]["depth"] >= 3), forks
+            tok, sc = res.tokens.cpu().numpy(), res.scores.cpu().numpy().astype(np.float64)
+            lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
+            for q in range(nq):
+                _same_ranked(tok[q], sc[q], ref_tok[q], ref_sc[q], f"mode {mode} query {q}")
+                for b in range(B):
+                    olo, ohi = pm._range(tuple(int(t) for t in tok[q, b]))
+                    assert hi[q, b] - lo[q, b] == ohi - olo > 0, (q, b)
+                    assert (codes[trie.perm[lo[q, b]:hi[q, b]]] == tok[q, b][None, :]).all()
+        assert ctx.status() == 0
+    finally:
+        ctx.set_forced_tail(saved_mode)
+    print(f"[full size] {codes.shape[0]} docs, forks {forks}: {nq} queries == KV-cached oracle in three modes")

@@ -74,6 +74,38 @@ def test_prefix_mask_oracle_matches_reference_processor(golden_cache, name):
     assert seen >= 2
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith("g6_")])   # (g6: V = 1024, two bytes per code)
+def test_sorted_matrix_mask_equals_the_dict_mask(golden_cache, name):
+    """SortedPrefixMaskRef (the oracle's mask for corpora whose dicts do not fit host RAM: tests/test_gpu_fullsize.py) against
+    the masks the REFERENCE's processor returned for the prefixes of the golden searches, against the dict mask on the same
+    prefixes, and against the dict mask on random prefixes — known ones, unknown ones, every length."""
+    g = golden_cache(name)
+    if int(np.asarray(g.codes).max()) >= 256:
+        pytest.skip("one byte per code")
+    pm, sm = _mask_fn(g), beam_ref.SortedPrefixMaskRef(g.codes, g.V)
+    seen = 0
+    for key in g.z.files:
+        if key.startswith("pm_prefix_T"):
+            T = int(key[len("pm_prefix_T"):])
+            expect = np.unpackbits(g.z[f"pm_mask_T{T}"], axis=1)[:, : g.V]
+            got = sm(g.z[key])
+            assert got.dtype == np.float64 and (got.astype(np.uint8) == expect).all(), (name, T)
+            seen += 1
+    assert seen >= 2
+    rng = np.random.default_rng(7)
+    codes = np.asarray(g.codes)
+    N, Lc = codes.shape
+    for T in range(1, Lc + 1):
+        known = codes[rng.integers(0, N, 16), : T - 1]
+        junk = rng.integers(0, g.V, (8, T - 1))
+        half = known.copy()
+        if T > 1:
+            half[:, -1] = rng.integers(0, g.V, len(half))          # a known parent with a random last token
+        pre = np.concatenate([known, junk, half], 0)
+        ids = np.concatenate([np.full((len(pre), 1), -1, dtype=np.int64), pre.astype(np.int64)], 1)
+        assert (pm(ids) == sm(ids)).all(), (name, T)
+
+
 def test_relative_position_buckets_known_answers():
     """SURVEY.md Appendix B known answers of HF's bucket function."""
     dec = t5_ref.bucket_table(False, 40)
