@@ -264,25 +264,31 @@ def test_mid_size_trie_against_the_kv_cached_oracle():
     print(f"[mid-size] {N} docs, forks {forks}: {nq} queries == KV-cached oracle")
 
 
-def test_full_size_trie_against_the_kv_cached_oracle(big_trie):
-    """config 2 itself — t5-base dims, the 8 841 823-doc trie, beam 10, len 32, automatic forks — against
-    the CPU oracle instead of against other runs of the library. The reference's dict-of-strings trie cannot hold this corpus
+@pytest.fixture(scope="module")
+def sorted_mask(big_trie):
+    from oracle import beam_ref
+    return beam_ref.SortedPrefixMaskRef(big_trie[1], V)
+
+
+@pytest.mark.parametrize("size,B,nq", [("t5-base", 10, 12), ("t5-large", 100, 2)])
+def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size, B, nq):
+    """config 2 itself — t5-base dims, the 8 841 823-doc trie, beam 10, len 32, automatic forks — and
+    config 4 (t5-large dims, beam 100; two queries) against the CPU oracle instead of against other runs of the library. The reference's dict-of-strings trie cannot hold this corpus
     in RAM, so the oracle's mask comes from `SortedPrefixMaskRef` (the same mask function evaluated on the sorted code
     matrix, pinned to the dict mask by tests/test_oracle_golden.py::test_sorted_matrix_mask_equals_the_dict_mask); model,
-    float64 combine, top-2B, scorer and finalize are the restatement the goldens pin. Four queries (~40 s of CPU work).
+    float64 combine, top-2B, scorer and finalize are the restatement the goldens pin. Twelve queries (a minute of CPU work for both).
     Comparator of the goldens; the documents under every returned smtid are the oracle's row range, row by row."""
     from oracle import beam_ref, t5_ref
     from ripor_amd import engine as E
     from ripor_amd.utils import synth
     trie, codes = big_trie
-    B, nq = 10, 4
     ctx = E.Context.get(0)
     ctx.set_precision("f16x2")
-    dims = synth.t5_base_dims(L=L, V=V)
+    dims = synth.t5_base_dims(L=L, V=V) if size == "t5-base" else synth.t5_large_dims(L=L, V=V)
     sd = synth.make_state_dict(dims)
     ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=23)
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
-    pm = beam_ref.SortedPrefixMaskRef(codes, V)
+    pm = sorted_mask
     seqs, scores = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)[:2]
     ref_tok = np.asarray(seqs).reshape(nq, B, L + 1)[:, :, 1:]
     ref_sc = np.asarray(scores, dtype=np.float64).reshape(nq, B)
@@ -309,4 +315,6 @@ def test_full_size_trie_against_the_kv_cached_oracle(big_trie):
         assert ctx.status() == 0
     finally:
         ctx.set_forced_tail(saved_mode)
-    print(f"[full size] {codes.shape[0]} docs, forks {forks}: {nq} queries == KV-cached oracle in three modes")
+        del model
+        torch.cuda.empty_cache()
+    print(f"[full size] {size}, {codes.shape[0]} docs, beam {B}: {nq} queries == KV-cached oracle in three modes")
