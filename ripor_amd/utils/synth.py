@@ -52,16 +52,67 @@ def hash_u64(name: str, n: int, seed: int = SEED, offset: int = 0) -> np.ndarray
     return splitmix64(ctr)
 
 
+_CHUNK = 1 << 18          # elements per work item: 2 MB of uint64 — the temporaries of a chunk stay in the cache
+_POOL = None
+
+
+def _pool():
+    """Worker threads for the generators below (numpy's ufuncs release the GIL). The value of element i depends on i
+    only, so the chunking and the number of threads cannot change a bit of the result."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, n)))
+    return _POOL
+
+
+def _hash_chunk(base: np.uint64, s: int, e: int) -> np.ndarray:
+    """splitmix64(base + i) for i in [s, e), in place on one buffer."""
+    with np.errstate(over="ignore"):
+        z = np.arange(s, e, dtype=np.uint64)
+        z += base
+        z += np.uint64(0x9E3779B97F4A7C15)
+        t = z >> np.uint64(30)
+        z ^= t
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        np.right_shift(z, np.uint64(27), out=t)
+        z ^= t
+        z *= np.uint64(0x94D049BB133111EB)
+        np.right_shift(z, np.uint64(31), out=t)
+        z ^= t
+    return z
+
+
+def _name_base(name: str, seed: int) -> np.uint64:
+    return np.uint64((fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF)
+
+
 def uniform_f32(name: str, shape, scale: float, seed: int = SEED) -> np.ndarray:
     """Uniform in [-scale, scale) with 24-bit resolution; exact & reproducible."""
     n = int(np.prod(shape))
     out = np.empty(n, dtype=np.float32)
-    chunk = 1 << 24
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        h = hash_u64(name, e - s, seed, offset=s)
-        v = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)
-        out[s:e] = (v.astype(np.float64) * (scale / float(1 << 23))).astype(np.float32)
+    base = _name_base(name, seed)
+    mul = scale / float(1 << 23)
+
+    def work(s):
+        e = min(n, s + _CHUNK)
+        h = _hash_chunk(base, s, e)
+        h >>= np.uint64(40)
+        v = h.astype(np.int64)
+        v -= (1 << 23)
+        out[s:e] = (v.astype(np.float64) * mul).astype(np.float32)
+
+    starts = range(0, n, _CHUNK)
+    if n <= _CHUNK:
+        for s in starts:
+            work(s)
+    else:
+        list(_pool().map(work, starts))
     return out.reshape(shape)
 
 
@@ -69,12 +120,22 @@ def randint(name: str, shape, lo: int, hi: int, seed: int = SEED) -> np.ndarray:
     """Integers uniform in [lo, hi) (modulo bias is irrelevant for synthetic data)."""
     n = int(np.prod(shape))
     out = np.empty(n, dtype=np.int64)
-    chunk = 1 << 24
     span = np.uint64(hi - lo)
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        h = hash_u64(name, e - s, seed, offset=s)
-        out[s:e] = ((h >> np.uint64(11)) % span).astype(np.int64) + lo
+    base = _name_base(name, seed)
+
+    def work(s):
+        e = min(n, s + _CHUNK)
+        h = _hash_chunk(base, s, e)
+        h >>= np.uint64(11)
+        h %= span
+        out[s:e] = h.astype(np.int64) + lo
+
+    starts = range(0, n, _CHUNK)
+    if n <= _CHUNK:
+        for s in starts:
+            work(s)
+    else:
+        list(_pool().map(work, starts))
     return out.reshape(shape)
 
 
@@ -297,13 +358,16 @@ def make_codes_fast(N: int, L: int, V: int, seed: int = SEED, zipf: Optional[flo
     n = N * L
     n4 = (n + 3) // 4
     out = np.empty(n4 * 4, dtype=np.uint16)
-    chunk = 1 << 23
-    for s in range(0, n4, chunk):
-        e = min(n4, s + chunk)
-        h = hash_u64(f"codes_fast/{N}x{L}x{V}", e - s, seed, offset=s)
-        out[4 * s:4 * e] = h.view(np.uint16)
-    if V < 65536:
-        out %= np.uint16(V)
+    base = _name_base(f"codes_fast/{N}x{L}x{V}", seed)
+
+    def work(s):
+        e = min(n4, s + _CHUNK)
+        c = _hash_chunk(base, s, e).view(np.uint16)
+        if V < 65536:
+            c %= np.uint16(V)
+        out[4 * s:4 * e] = c
+
+    list(_pool().map(work, range(0, n4, _CHUNK)))
     out = out[:n].reshape(N, L)
     if zipf is not None:
         lv = min(3, L)
