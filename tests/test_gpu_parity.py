@@ -378,6 +378,54 @@ def test_wave_split_gemm_tiles_agree_with_each_other_and_with_fp64():
         assert v["err"] < 2e-5 * v["scale"] and old[k]["err"] < 2e-5 * old[k]["scale"], (k, v, old[k])
 
 
+_SUPERTILE_SCRIPT = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, %r)
+from ripor_amd import engine as E
+ctx = E.Context.get(0)
+out = {}
+# more tiles than CUs and more than four column tiles: the persistent 256 x 256 kernel in super-tile order; a ragged last row
+# panel and a ragged last column tile, bands that do not divide the row panels, a narrower last column group
+for (M, N, K, relu, resid) in [(24576, 3072, 768, True, False), (20000 + 37, 2304, 768, False, False), (16384, 1280 + 64, 768, False, True),
+                               (23040, 4096, 256, False, False), (17000, 768, 768, False, True)]:
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * K ** -0.5
+    R = torch.randn(M, N, device="cuda") if resid else None
+    first = ctx.linear(A, W, R, relu)
+    assert torch.equal(ctx.linear(A, W, R, relu), first), "not repeatable"
+    ref = A.double() @ W.double().t()
+    ref = torch.relu(ref) if relu else ref
+    ref = ref + R.double() if resid else ref
+    out[f"{M}x{N}x{K}"] = {"err": (first.double() - ref).abs().max().item(), "scale": max(1.0, ref.abs().max().item()),
+                           "sha": hashlib.sha256(first.cpu().numpy().tobytes()).hexdigest()}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_super_tile_order_of_the_persistent_gemm_changes_no_bit():
+    """Round 6: gemm_h2_pp_kernel walks products wider than four column tiles band by band, column group by column group
+    (GemmH2Args::tile_cw / tile_rb). Same tiles, same arithmetic per tile: the result must be the row-major walk's bit for bit
+    (RPR_PP_SUPERTILE=0, development build), every output within the split-precision bar of the fp64 product, also with column
+    groups of 2 and 5 tiles; the product library takes the development build's default."""
+    import json
+    import subprocess
+    import sys
+
+    def run(env):
+        e = dict(os.environ, **{"RPR_DEV_LIB": "1", **env})
+        p = subprocess.run([sys.executable, "-c", _SUPERTILE_SCRIPT % REPO], env=e, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+    base = run({"RPR_PP_SUPERTILE": "0"})
+    for k, v in base.items():
+        assert v["err"] < 2e-5 * v["scale"], (k, v)
+    for sup in ("1", "2", "5"):
+        got = run({"RPR_PP_SUPERTILE": sup})
+        assert {k: v["sha"] for k, v in got.items()} == {k: v["sha"] for k, v in base.items()}, f"super-tile order {sup} changes the result"
+    assert run({"RPR_DEV_LIB": "0"}) == run({})
+
+
 def test_vocab_sizes_off_the_64_grid(engine):
     """Decoder vocab sizes that are not multiples of 64 (rpr_load_model pads every output codebook with zero rows up to the
     next multiple of 64; the selection never picks a padding column; log_softmax runs over the real columns): V = 100, 65,
