@@ -113,6 +113,7 @@ class SortedPrefixMaskRef:
         order = np.lexsort(tuple(keys[:, k] for k in range(keys.shape[1] - 1, -1, -1)))
         self.sorted = np.ascontiguousarray(b[order, :L])
         self.ranges = {(): (0, N)}
+        self.next_tokens = {}
 
     def _range(self, prefix: tuple):
         r = self.ranges.get(prefix)
@@ -133,10 +134,13 @@ class SortedPrefixMaskRef:
         if T - 1 >= self.sorted.shape[1]:
             return mask
         for i, row in enumerate(ids.tolist()):
-            lo, hi = self._range(tuple(row[1:]))
-            if hi > lo:
-                nxt = np.unique(self.sorted[lo:hi, T - 1])
-                mask[i, nxt[nxt < self.vocab_size]] = 1.0
+            key = tuple(row[1:])
+            nxt = self.next_tokens.get(key)
+            if nxt is None:
+                lo, hi = self._range(key)
+                nxt = np.unique(self.sorted[lo:hi, T - 1]) if hi > lo else np.zeros(0, dtype=np.uint8)
+                self.next_tokens[key] = nxt = nxt[nxt < self.vocab_size]
+            mask[i, nxt] = 1.0
         return mask
 
 

@@ -270,10 +270,12 @@ def sorted_mask(big_trie):
     return beam_ref.SortedPrefixMaskRef(big_trie[1], V)
 
 
-@pytest.mark.parametrize("size,B,nq", [("t5-base", 10, 12), ("t5-large", 100, 2)])
-def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size, B, nq):
+@pytest.mark.parametrize("size,B,nq,Ls,lsm", [("t5-base", 10, 12, 32, False), ("t5-large", 100, 2, 32, False),
+                                              ("t5-base", 100, 4, 8, False), ("t5-base", 100, 4, 4, False), ("t5-base", 10, 6, 32, True)])
+def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size, B, nq, Ls, lsm):
     """config 2 itself — t5-base dims, the 8 841 823-doc trie, beam 10, len 32, automatic forks — and
-    config 4 (t5-large dims, beam 100; two queries) against the CPU oracle instead of against other runs of the library. The reference's dict-of-strings trie cannot hold this corpus
+    config 4 (t5-large dims, beam 100; two queries), the rank-data flags (beam 100, prefix searches of 8 and 4 positions, row f2)
+    and log-softmax scores against the CPU oracle instead of against other runs of the library. The reference's dict-of-strings trie cannot hold this corpus
     in RAM, so the oracle's mask comes from `SortedPrefixMaskRef` (the same mask function evaluated on the sorted code
     matrix, pinned to the dict mask by tests/test_oracle_golden.py::test_sorted_matrix_mask_equals_the_dict_mask); model,
     float64 combine, top-2B, scorer and finalize are the restatement the goldens pin. Twelve queries (a minute of CPU work for both).
@@ -289,8 +291,9 @@ def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size
     ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=23)
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     pm = sorted_mask
-    seqs, scores = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, L, use_kv_cache=True)[:2]
-    ref_tok = np.asarray(seqs).reshape(nq, B, L + 1)[:, :, 1:]
+    seqs, scores = beam_ref.beam_search_ref(t5_ref.T5RefCached(sd, dims), pm, ids, mask, B, Ls, apply_log_softmax_for_scores=lsm,
+                                            use_kv_cache=True)[:2]
+    ref_tok = np.asarray(seqs).reshape(nq, B, Ls + 1)[:, :, 1:]
     ref_sc = np.asarray(scores, dtype=np.float64).reshape(nq, B)
     model = E.DeviceModel(ctx, sd, dims)
     ctx.status(clear=True)
@@ -298,12 +301,12 @@ def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size
     try:
         for mode in (2, 1, 0):                            # optimistic, exact forced tail, plain step loop
             ctx.set_forced_tail(mode)
-            res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, L)
+            res = E.search(model, trie, torch.from_numpy(ids), torch.from_numpy(mask), B, Ls, apply_log_softmax_for_scores=lsm)
             torch.cuda.synchronize()
             forks = ctx.last_fork_stats()
             if mode == 2 and ctx.status(clear=True) & 4:
                 continue
-            assert mode == 0 or (forks and forks[0]["depth"] >= 3), forks
+            assert mode == 0 or Ls < 32 or (forks and forks[0]["depth"] >= 3), forks
             tok, sc = res.tokens.cpu().numpy(), res.scores.cpu().numpy().astype(np.float64)
             lo, hi = res.row_lo.cpu().numpy(), res.row_hi.cpu().numpy()
             for q in range(nq):
@@ -311,10 +314,10 @@ def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size
                 for b in range(B):
                     olo, ohi = pm._range(tuple(int(t) for t in tok[q, b]))
                     assert hi[q, b] - lo[q, b] == ohi - olo > 0, (q, b)
-                    assert (codes[trie.perm[lo[q, b]:hi[q, b]]] == tok[q, b][None, :]).all()
+                    assert (codes[trie.perm[lo[q, b]:hi[q, b]], :Ls] == tok[q, b][None, :]).all()
         assert ctx.status() == 0
     finally:
         ctx.set_forced_tail(saved_mode)
         del model
         torch.cuda.empty_cache()
-    print(f"[full size] {size}, {codes.shape[0]} docs, beam {B}: {nq} queries == KV-cached oracle in three modes")
+    print(f"[full size] {size}, {codes.shape[0]} docs, beam {B}, len {Ls}, log_softmax {lsm}: {nq} queries == KV-cached oracle in three modes")
