@@ -321,3 +321,52 @@ def test_full_size_trie_against_the_kv_cached_oracle(big_trie, sorted_mask, size
         del model
         torch.cuda.empty_cache()
     print(f"[full size] {size}, {codes.shape[0]} docs, beam {B}, len {Ls}, log_softmax {lsm}: {nq} queries == KV-cached oracle in three modes")
+
+
+def test_full_size_beam_1000_against_the_kv_cached_oracle(big_trie, sorted_mask):
+    """The reference script's retrieval flags (--topk=1000 --batch_size=1, full_evaluate_t5seq_aq_encoder.sh:191-199) at full size
+    against the CPU oracle: t5-base dims, the 8.8 M-doc trie, one query per search, radix selection + forced tail. With 1000 beams the
+    1000th and 1001st candidate of a step can be closer than the two arithmetics agree (PRUNE_TOL = 1e-3, as compare_ranked):
+    a query whose oracle run has such a step is reported and left out; at least two of the three queries must be checkable."""
+    from oracle import beam_ref, t5_ref
+    from ripor_amd import engine as E
+    from ripor_amd.utils import synth
+    trie, codes = big_trie
+    B, nq = 1000, 3
+    ctx = E.Context.get(0)
+    ctx.set_precision("f16x2")
+    dims = synth.t5_base_dims(L=L, V=V)
+    sd = synth.make_state_dict(dims)
+    ids, mask = synth.make_queries(nq, vocab_size=dims.vocab_size, seed=29)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    ref_model = t5_ref.T5RefCached(sd, dims)
+    model = E.DeviceModel(ctx, sd, dims)
+    ctx.status(clear=True)
+    checked = 0
+    try:
+        for q in range(nq):
+            n = int(mask[q].sum())
+            rec = {}
+            seqs, scores = beam_ref.beam_search_ref(ref_model, sorted_mask, ids[q:q + 1, :n], mask[q:q + 1, :n], B, L, use_kv_cache=True,
+                                                    record=rec)[:2]
+            gaps = [float(st["top_scores"][0][B - 1] - st["top_scores"][0][B]) for st in rec["steps"]
+                    if st["top_scores"].shape[1] > B and st["top_scores"][0][B] > -1e8]
+            margin = min(gaps) if gaps else float("inf")
+            if margin < 1e-3:
+                print(f"[beam 1000] query {q}: the oracle's closest pruning margin is {margin:.2e}: left out")
+                continue
+            ref_tok = np.asarray(seqs).reshape(B, L + 1)[:, 1:]
+            ref_sc = np.asarray(scores, dtype=np.float64).reshape(B)
+            res = E.search_guarded(model, trie, torch.from_numpy(ids[q:q + 1, :n]), torch.from_numpy(mask[q:q + 1, :n]), B, L).result()
+            torch.cuda.synchronize()
+            tok, sc = res.tokens.cpu().numpy()[0], res.scores.cpu().numpy()[0].astype(np.float64)
+            _same_ranked(tok, sc, ref_tok, ref_sc, f"beam 1000 query {q}")
+            lo, hi = res.row_lo.cpu().numpy()[0], res.row_hi.cpu().numpy()[0]
+            assert (hi > lo).all()
+            checked += 1
+        assert checked >= 2, "every query sat on a pruning near-tie: pick another seed"
+        assert not (ctx.status() & 1)
+    finally:
+        del model
+        torch.cuda.empty_cache()
+    print(f"[beam 1000] {checked} of {nq} queries == KV-cached oracle at full size")
